@@ -1,0 +1,143 @@
+"""Generate the committed golden vectors.  Run in the BUILD container only:
+
+    python tests/golden/make_golden.py
+
+Part A (reference-derived, needs /root/reference): imports the two reference Python modules
+that are importable here -- lib/utils/sh_utils.py and lib/utils/graphics_utils.py (torch/numpy
+only) -- by file path and records inputs + outputs of
+
+  * eval_sh(deg, sh, dirs)                 (sh_utils.py:57-112)  == forward.cu:20-71 minus +0.5/clamp
+  * getWorld2View2, getProjectionMatrixK, getProjectionMatrix, fov2focal, focal2fov
+                                           (graphics_utils.py:38-100)
+
+These are the only parts of the path the reference itself can execute in this image (the
+rasterizer proper is CUDA-only), so they are what pins the oracle.  Files: ref_sh.npz, ref_camera.npz.
+
+Part B (oracle-generated regression vectors, NOT reference-derived -- "parity unpinned"):
+small scenes run through oracle/gs_oracle.c; they catch regressions in either the oracle or the
+HIP path and travel to the GPU box.  Files: oracle_<scene>.npz.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def part_a():
+    sh_utils = _load(os.path.join(REF, "lib/utils/sh_utils.py"), "ref_sh_utils")
+    gu = _load(os.path.join(REF, "lib/utils/graphics_utils.py"), "ref_graphics_utils")
+    g = torch.Generator().manual_seed(1234)
+    N = 96
+    means = torch.randn(N, 3, generator=g) * 3.0
+    means[:, 2] = means[:, 2].abs() + 1.0          # in front of an identity camera
+    campos = torch.tensor([0.3, -0.2, -0.5])
+    shs = torch.randn(N, 16, 3, generator=g) * 0.6
+    dirs = means - campos[None]
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    out = {}
+    for deg in range(4):
+        M = (deg + 1) ** 2
+        # reference layout: sh [..., C, (deg+1)^2]  (street_gaussian_renderer.py:183-185)
+        res = sh_utils.eval_sh(deg, shs[:, :M, :].transpose(1, 2), dirs)
+        out["eval_sh_deg%d" % deg] = res.numpy().astype(np.float32)
+    np.savez(os.path.join(HERE, "ref_sh.npz"), means3D=means.numpy(), campos=campos.numpy(),
+             shs=shs.numpy(), dirs=dirs.numpy(), **out)
+
+    rng = np.random.RandomState(7)
+    cams = {}
+    for i in range(4):
+        A = rng.randn(3, 3)
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        T = rng.randn(3) * 2.0
+        cams["R%d" % i] = Q
+        cams["T%d" % i] = T
+        cams["w2v%d" % i] = gu.getWorld2View2(Q, T)
+    K = np.array([[2083.09, 0.0, 960.0], [0.0, 2083.09, 640.0], [0.0, 0.0, 1.0]])
+    cams["K"] = K
+    cams["projK_1920x1280"] = gu.getProjectionMatrixK(K, 1280, 1920, 0.001, 1000.0).numpy()
+    K2 = np.array([[700.0, 0.0, 300.5], [0.0, 650.0, 170.25], [0.0, 0.0, 1.0]])
+    cams["K2"] = K2
+    cams["projK_640x360"] = gu.getProjectionMatrixK(K2, 360, 640, 0.001, 1000.0).numpy()
+    cams["proj_fov"] = gu.getProjectionMatrix(0.01, 100.0, 1.416, 0.506).numpy()
+    cams["fov2focal"] = np.array([gu.fov2focal(1.416, 1242), gu.fov2focal(0.506, 375)])
+    cams["focal2fov"] = np.array([gu.focal2fov(2083.09, 1920), gu.focal2fov(2083.09, 1280)])
+    np.savez(os.path.join(HERE, "ref_camera.npz"), **cams)
+    print("part A written (reference-derived)")
+
+
+def scenes():
+    """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
+    from gaussianrpg_amd import harness as hz
+    g = torch.Generator().manual_seed(99)
+    out = []
+    out.append(("toy_deg1", hz.toy_scene(1500, seed=1, sh_degree=1),
+                hz.trajectory_camera(0, W=96, H=64), dict(bg=[0.0, 0.0, 0.0])))
+    out.append(("toy_deg3_sem", hz.toy_scene(1200, seed=2, sh_degree=3),
+                hz.trajectory_camera(0, W=80, H=50), dict(bg=[0.2, 0.4, 0.6], S=3)))
+    out.append(("smoke_deg0", hz.smoke_scene(600, seed=0), hz.smoke_camera(64, 48),
+                dict(bg=[0.0, 0.0, 0.0])))
+    out.append(("street_small", hz.street_scene(6000, seed=5), hz.trajectory_camera(2, W=160, H=112),
+                dict(bg=[1.0, 1.0, 1.0])))
+    return out, g
+
+
+def part_b():
+    sys.path.insert(0, ROOT)
+    import oracle
+    from gaussianrpg_amd import harness as hz
+    sc_list, g = scenes()
+    for name, sc, cam, extra in sc_list:
+        P = sc.means3D.shape[0]
+        S = extra.get("S", 0)
+        sem = torch.rand(P, S, generator=g) if S else None
+        bg = torch.tensor(extra["bg"], dtype=torch.float32)
+        kw = {k: v for k, v in hz.settings_kwargs(cam, sc.sh_degree, bg=bg).items()
+              if k not in ("prefiltered", "debug")}
+        o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales,
+                           rotations=sc.rotations, semantics=sem, **kw)
+        H, W = cam.image_height, cam.image_width
+        gc = torch.randn(3, H, W, generator=g).numpy()
+        gd = (0.1 * torch.randn(1, H, W, generator=g)).numpy()
+        ga = torch.randn(1, H, W, generator=g).numpy()
+        gs = torch.randn(S, H, W, generator=g).numpy()
+        gr = oracle.backward(o, gc, gd, ga, gs)
+        np.savez_compressed(
+            os.path.join(HERE, "oracle_%s.npz" % name),
+            means3D=sc.means3D.numpy(), opacity=sc.opacity.numpy(), scales=sc.scales.numpy(),
+            rotations=sc.rotations.numpy(), shs=sc.shs.numpy(),
+            semantics=(sem.numpy() if S else np.zeros((P, 0), np.float32)),
+            sh_degree=sc.sh_degree, bg=bg.numpy(), H=H, W=W, tanfovx=cam.tanfovx,
+            tanfovy=cam.tanfovy, viewmatrix=cam.viewmatrix.numpy(),
+            projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(),
+            radii=o["radii"], num_rendered=o["num_rendered"], keys_sorted=o["keys_sorted"],
+            point_list=o["point_list"], ranges=o["ranges"], n_contrib=o["n_contrib"],
+            fragile=o["fragile"], color=o["color"], depth=o["depth"], alpha=o["alpha"],
+            semantic=o["semantic"], means2D=o["means2D"], depths=o["depths"],
+            conic_opacity=o["conic_opacity"], rgb=o["rgb"],
+            grad_color=gc, grad_depth=gd, grad_alpha=ga, grad_semantic=gs,
+            **{k: v for k, v in gr.items()})
+        print("wrote oracle_%s.npz  P=%d V=%d R=%d" % (name, P, int((o["radii"] > 0).sum()),
+                                                      o["num_rendered"]))
+
+
+if __name__ == "__main__":
+    if os.path.isdir(REF):
+        part_a()
+    else:
+        print("no /root/reference here: skipping part A (reference-derived vectors)")
+    part_b()

@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (tests/ may use oracle/; the product may not)."""
+import os
+
+import numpy as np
+import torch
+
+from gaussianrpg_amd import harness as hz
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Tolerance north_star states for floating point outputs: "forward RGB/depth within 1e-4 fp32".
+ATOL = 1e-4
+RTOL = 1e-4
+# A pixel the oracle flags "fragile" had an accept/reject decision within a few ulp of its
+# threshold (alpha~1/255, T~1e-4, power~0): an implementation whose exp() differs in the last
+# bits may take the other branch; one flipped contribution is worth at most ~alpha*T.
+FRAGILE_ATOL = 5e-2
+
+
+def oracle_kwargs(cam, sh_degree, bg=None, scale_modifier=1.0):
+    kw = hz.settings_kwargs(cam, sh_degree, bg=bg, scale_modifier=scale_modifier)
+    kw.pop("prefiltered")
+    kw.pop("debug")
+    return kw
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, "oracle_%s.npz" % name))
+    return {k: z[k] for k in z.files}
+
+
+def fixture_oracle_inputs(fx):
+    return dict(image_height=int(fx["H"]), image_width=int(fx["W"]), tanfovx=float(fx["tanfovx"]),
+                tanfovy=float(fx["tanfovy"]), bg=fx["bg"], scale_modifier=1.0,
+                viewmatrix=fx["viewmatrix"], projmatrix=fx["projmatrix"],
+                sh_degree=int(fx["sh_degree"]), campos=fx["campos"])
+
+
+def assert_image_close(name, got, ref, fragile=None, atol=ATOL, rtol=RTOL, max_fragile_frac=0.1):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    if fragile is None:
+        bad = err > tol
+        assert not bad.any(), "%s: %d px beyond tol, max err %.3e" % (name, bad.sum(), err.max())
+        return
+    frag = np.broadcast_to(np.asarray(fragile, dtype=bool), ref.shape[-2:])
+    bad = (err > tol) & ~frag[None]
+    assert not bad.any(), "%s: %d non-fragile px beyond tol, max err %.3e" % (
+        name, bad.sum(), (err * ~frag[None]).max())
+    assert frag.mean() <= max_fragile_frac, "%s: fragile fraction %.4f" % (name, frag.mean())
+    scale = 1.0 + np.abs(ref)
+    assert ((err / scale) * frag[None]).max() <= FRAGILE_ATOL, "%s: fragile px err %.3e" % (
+        name, ((err / scale) * frag[None]).max())
