@@ -1,0 +1,121 @@
+"""In-tree build of the native pieces (no JIT cache: the .so files must travel with the repo).
+
+* ``libgrpg_rasterizer.so`` -- hand-written HIP for gfx950 + the C ABI (include/grpg_rasterizer.h),
+  compiled with ``hipcc --offload-arch=gfx950``; no torch dependency.
+* ``_C.<abi>.so`` -- the PyTorch-ROCm extension module (csrc/torch_binding.cpp) that exposes the
+  reference's operator surface on top of the C ABI; compiled with g++ against torch's headers.
+
+Both land next to this file.  ``python -m gaussianrpg_amd.build`` builds everything.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
+LIB_NAME = "libgrpg_rasterizer.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+EXT_PATH = os.path.join(HERE, "_C" + sysconfig.get_config_var("EXT_SUFFIX"))
+ARCH = "gfx950"
+
+# translation unit -> extra flags
+HIP_UNITS = {
+    # bit-exact integer outputs need the oracle's arithmetic: no FMA contraction
+    "preprocess.hip": ["-ffp-contract=off"],
+    "preprocess_bwd.hip": ["-ffp-contract=off"],
+    "sort.hip": [],
+    "binning.hip": [],
+    "render_fwd.hip": [],
+    # hardware global_atomic_add_f32 instead of a CAS loop
+    "render_bwd.hip": ["-munsafe-fp-atomics"],
+    "api.hip": [],
+}
+HEADERS = ["common.h", "gaussian_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (needed to build the gfx950 kernels)")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), p.stdout))
+    return p.stdout
+
+
+def build_native(force=False, verbose=False):
+    """hipcc -> libgrpg_rasterizer.so (gfx950 only)."""
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    objs = []
+    for unit, extra in HIP_UNITS.items():
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+                         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] + extra +
+                        ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if force or jobs or _newer(LIB_PATH, objs):
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs +
+             ["-Wl,--enable-new-dtags", "-Wl,-rpath,/opt/rocm/lib"])
+    return LIB_PATH
+
+
+def build_binding(force=False, verbose=False):
+    """g++ -> _C extension module linking libgrpg_rasterizer.so and torch."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    hdr = os.path.join(ROOT, "include", "grpg_rasterizer.h")
+    if not (force or _newer(EXT_PATH, [src, hdr, os.path.abspath(__file__)])):
+        return EXT_PATH
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-variable",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_C",
+           "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for inc in ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(rocm, "include")]:
+        cmd += ["-isystem", inc]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd += [src, "-o", EXT_PATH, "-L" + HERE, "-l:" + LIB_NAME, "-L" + torch_lib, "-ltorch",
+            "-ltorch_cpu", "-ltorch_python", "-lc10", "-lc10_hip", "-ltorch_hip",
+            "-Wl,--enable-new-dtags", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib]
+    out = _run(cmd)
+    if verbose and out.strip():
+        print(out)
+    return EXT_PATH
+
+
+def build_all(force=False, verbose=False):
+    build_native(force=force, verbose=verbose)
+    build_binding(force=force, verbose=verbose)
+    return LIB_PATH, EXT_PATH
+
+
+if __name__ == "__main__":
+    paths = build_all(force="--force" in sys.argv, verbose=True)
+    print("built:", *paths, sep="\n  ")

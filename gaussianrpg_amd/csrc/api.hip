@@ -1,0 +1,398 @@
+// C ABI of libgrpg_rasterizer.so (include/grpg_rasterizer.h): host orchestration of the HIP
+// pipeline.  Mirrors CudaRasterizer::Rasterizer::{forward,backward,markVisible,visible_filter}
+// (cuda_rasterizer/rasterizer_impl.cu:197-343, :396-505, :141-153, :345-392).
+//
+// Forward schedule on the caller's stream:
+//   preprocess -> depth sort of P (key,id) pairs, 4 x 8-bit passes -> exclusive scan of the
+//   per-Gaussian tile counts in depth order -> [one 4-byte D2H + stream sync: num_rendered] ->
+//   binning blob alloc -> instance emit -> stable tile partition (ceil(log2 T) bits, <= 2 passes)
+//   -> tile ranges -> render (-> semantic render).
+// There is no CPU fallback: without a usable HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/grpg_rasterizer.h"
+#include "common.h"
+
+using namespace grpg;
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local bool g_timing_enabled = false;
+thread_local bool g_timing_valid = false;
+thread_local float g_stage_ms[GRPG_NUM_STAGES];
+thread_local uint32_t* g_pinned_u32 = nullptr;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(GRPG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+// debug=true: synchronise and check after every stage, like CHECK_CUDA (auxiliary.h:166-173).
+#define STAGE_CHECK(name)                                                                    \
+  do {                                                                                       \
+    hipError_t e_ = hipGetLastError();                                                       \
+    if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(stream);                        \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(GRPG_ERR_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(GRPG_ERR_NO_DEVICE,
+                "no usable HIP device (libgrpg_rasterizer has no CPU fallback by design)");
+  return GRPG_OK;
+}
+
+int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit in b bits
+  int b = 0;
+  while ((1ull << b) < (unsigned long long)T) b++;
+  return b;
+}
+
+struct StageTimer {
+  hipStream_t s;
+  bool on;
+  hipEvent_t ev[GRPG_NUM_STAGES + 1];
+  int n = 0;
+  int stage_of[GRPG_NUM_STAGES + 1];
+  StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
+    if (on) for (auto& e : ev) (void)hipEventCreate(&e);
+  }
+  void mark(int next_stage) {
+    if (!on || n > GRPG_NUM_STAGES) return;
+    (void)hipEventRecord(ev[n], s);
+    stage_of[n] = next_stage;
+    n++;
+  }
+  void finish() {
+    if (!on) return;
+    (void)hipEventSynchronize(ev[n - 1]);
+    for (int i = 0; i < GRPG_NUM_STAGES; i++) g_stage_ms[i] = 0.f;
+    for (int i = 0; i + 1 < n; i++) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      if (stage_of[i] >= 0 && stage_of[i] < GRPG_NUM_STAGES) g_stage_ms[stage_of[i]] += ms;
+    }
+    g_timing_valid = true;
+  }
+  ~StageTimer() {
+    if (on) for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+CameraArgs make_camera(const float* view, const float* proj, const float* campos, int W, int H,
+                       float tan_fovx, float tan_fovy) {
+  CameraArgs c;
+  c.view = view; c.proj = proj; c.campos = campos;
+  c.W = W; c.H = H;
+  c.gx = (W + TILE - 1) / TILE;
+  c.gy = (H + TILE - 1) / TILE;
+  c.tan_fovx = tan_fovx; c.tan_fovy = tan_fovy;
+  c.focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:225-226
+  c.focal_x = W / (2.0f * tan_fovx);
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grpg_abi_version(void) { return GRPG_ABI_VERSION; }
+const char* grpg_last_error(void) { return g_last_error.c_str(); }
+
+int grpg_set_stage_timing(int enabled) {
+  g_timing_enabled = enabled != 0;
+  g_timing_valid = false;
+  return GRPG_OK;
+}
+int grpg_get_stage_timing(float* stage_ms) {
+  if (!stage_ms || !g_timing_valid) return fail(GRPG_ERR_INVALID_ARGUMENT, "stage timing not available");
+  std::memcpy(stage_ms, g_stage_ms, sizeof(g_stage_ms));
+  return GRPG_OK;
+}
+
+int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                 void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D,
+                 int M, int S, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* semantics, const float* opacities, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                 float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
+                 void* hip_stream) {
+  (void)prefiltered;  // reference: __trap() on a culled point when set; always False in practice
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "negative size");
+  if (!geometry_alloc || !binning_alloc || !image_alloc)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "buffer allocators must not be NULL");
+  if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth || !out_alpha)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL camera/background/output pointer");
+  if (P > 0) {
+    if (!means3D || !opacities) return fail(GRPG_ERR_INVALID_ARGUMENT, "means3D/opacities NULL");
+    if (!cov3D_precomp && (!scales || !rotations))
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "need scales+rotations or cov3D_precomp");
+    if (!colors_precomp && (!shs || M <= 0))
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "need shs (M>0) or colors_precomp");
+    if (!colors_precomp && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M, D <= 3");
+    if (S > 0 && (!semantics || !out_semantic))
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "semantics/out_semantic NULL with S>0");
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const CameraArgs cam = make_camera(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+  const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
+  const size_t N = (size_t)width * height;
+
+  const GeomLayout GL = geom_layout((size_t)P);
+  const ImgLayout IL = img_layout(T, N);
+  char* geom = geometry_alloc(GL.total, geometry_user);
+  char* img = image_alloc(IL.total, image_user);
+  if (!geom || !img) return fail(GRPG_ERR_ALLOC, "geometry/image buffer allocation failed");
+
+  float4* rec = (float4*)(geom + GL.rec);
+  uint32_t* key_a = (uint32_t*)(geom + GL.key_a);
+  uint32_t* key_b = (uint32_t*)(geom + GL.key_b);
+  uint32_t* val_a = (uint32_t*)(geom + GL.val_a);
+  uint32_t* val_b = (uint32_t*)(geom + GL.val_b);
+  uint32_t* tiles = (uint32_t*)(geom + GL.tiles);
+  uint32_t* offsets = (uint32_t*)(geom + GL.offsets);
+  int* radii_int = radii ? radii : (int*)(geom + GL.radii);
+  uint32_t* table = (uint32_t*)(geom + GL.table);
+  uint32_t* totals = (uint32_t*)(geom + GL.totals);
+  uint32_t* block_sums = (uint32_t*)(geom + GL.block_sums);
+  BlobHeader* gh = (BlobHeader*)geom;
+  uint2* ranges = (uint2*)(img + IL.ranges);
+  uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
+
+  BlobHeader hh;
+  std::memset(&hh, 0, sizeof(hh));
+  hh.magic = GEOM_MAGIC; hh.P = (uint32_t)P; hh.R = 0; hh.W = (uint32_t)width; hh.H = (uint32_t)height; hh.S = (uint32_t)S;
+  HIP_TRY(hipMemcpyAsync(gh, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
+  hh.magic = IMG_MAGIC;
+  HIP_TRY(hipMemcpyAsync(img, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
+
+  StageTimer tm(stream, g_timing_enabled);
+  g_timing_valid = false;
+  uint32_t R = 0;
+
+  if (P > 0) {
+    tm.mark(0);
+    launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                      cov3D_precomp, colors_precomp, cam, radii_int, rec, key_a, tiles);
+    STAGE_CHECK("preprocess");
+    tm.mark(1);
+    // (depth_bits, id) order: stable sort of ids by the 32-bit depth key; culled keys sort last.
+    const bool in_b = radix_sort_pairs(stream, (uint32_t)P, key_a, val_a, key_b, val_b, true, 0, 32,
+                                       table, totals, GL.nchunks_sort);
+    const uint32_t* sorted_gid = in_b ? val_b : val_a;  // 4 passes -> back in "a"
+    STAGE_CHECK("depth sort");
+    tm.mark(2);
+    launch_offsets_scan(stream, (uint32_t)P, sorted_gid, tiles, offsets, block_sums,
+                        GL.nblocks_scan, &gh->R);
+    STAGE_CHECK("offsets scan");
+    // The one host round trip per frame (reference: rasterizer_impl.cu:284).
+    if (!g_pinned_u32) HIP_TRY(hipHostMalloc((void**)&g_pinned_u32, 64, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(g_pinned_u32, &gh->R, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    R = *g_pinned_u32;
+    if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+
+    const BinLayout BL = bin_layout((size_t)R);
+    char* bin = binning_alloc(BL.total, binning_user);
+    if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
+    hh.magic = BIN_MAGIC; hh.R = R;
+    HIP_TRY(hipMemcpyAsync(bin, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
+    uint32_t* bkey_a = (uint32_t*)(bin + BL.key_a);
+    uint32_t* bkey_b = (uint32_t*)(bin + BL.key_b);
+    uint32_t* bval_a = (uint32_t*)(bin + BL.val_a);
+    uint32_t* bval_b = (uint32_t*)(bin + BL.val_b);
+    uint32_t* btable = (uint32_t*)(bin + BL.table);
+    uint32_t* btotals = (uint32_t*)(bin + BL.totals);
+
+    tm.mark(3);
+    const int tbits = bits_for(T);
+    const int passes = radix_sort_num_passes(0, tbits);
+    // emit into whichever pair makes the LAST pass land in "a" (point_list lives in val_a)
+    const bool start_in_b = (passes & 1) != 0;
+    launch_emit(stream, (uint32_t)P, sorted_gid, offsets, tiles, rec, cam.gx, cam.gy,
+                start_in_b ? bkey_b : bkey_a, start_in_b ? bval_b : bval_a);
+    STAGE_CHECK("emit");
+    tm.mark(4);
+    if (passes > 0) {
+      bool res_b;
+      if (start_in_b)
+        res_b = !radix_sort_pairs(stream, R, bkey_b, bval_b, bkey_a, bval_a, false, 0, tbits,
+                                  btable, btotals, BL.nchunks_sort);
+      else
+        res_b = radix_sort_pairs(stream, R, bkey_a, bval_a, bkey_b, bval_b, false, 0, tbits,
+                                 btable, btotals, BL.nchunks_sort);
+      if (res_b && R > 0) return fail(GRPG_ERR_HIP, "internal: tile sort landed in the wrong buffer");
+    }
+    STAGE_CHECK("tile sort");
+    tm.mark(5);
+    launch_tile_ranges(stream, R, bkey_a, ranges, T);
+    STAGE_CHECK("tile ranges");
+    tm.mark(6);
+    launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
+                          out_color, out_depth, out_alpha, n_contrib);
+    STAGE_CHECK("render");
+    tm.mark(7);
+    if (S > 0) {
+      launch_render_semantic(stream, ranges, bval_a, rec, semantics, S, width, height, cam.gx,
+                             cam.gy, out_semantic);
+      STAGE_CHECK("semantic render");
+    }
+    tm.mark(-1);
+    tm.finish();
+  } else {
+    // P == 0: the reference launches nothing and its pre-zeroed planes stay zero
+    // (rasterize_points.cu:85-86,123); write the zeros explicitly.
+    HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * 4, stream));
+    HIP_TRY(hipMemsetAsync(out_depth, 0, N * 4, stream));
+    HIP_TRY(hipMemsetAsync(out_alpha, 0, N * 4, stream));
+    if (S > 0 && out_semantic) HIP_TRY(hipMemsetAsync(out_semantic, 0, (size_t)S * N * 4, stream));
+    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)T * 8, stream));
+    HIP_TRY(hipMemsetAsync(n_contrib, 0, N * 4, stream));
+    char* bin = binning_alloc(bin_layout(0).total, binning_user);
+    if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
+    hh.magic = BIN_MAGIC; hh.R = 0;
+    HIP_TRY(hipMemcpyAsync(bin, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
+  }
+  return (int)R;
+}
+
+int grpg_backward(int P, int D, int M, int R, int S, const float* background, int width,
+                  int height, const float* means3D, const float* shs, const float* colors_precomp,
+                  const float* semantics, const float* alphas, const float* scales,
+                  float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* campos,
+                  float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
+                  char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                  const float* dL_dpix_depth, const float* dL_dalphas,
+                  const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dconic,
+                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                  float* dL_dsemantic, int debug, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P <= 0) return GRPG_OK;
+  if (!geom_buffer || !binning_buffer || !image_buffer)
+    return fail(GRPG_ERR_BAD_BUFFER, "NULL state buffer");
+  if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dconic ||
+      !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
+  if (S > 0 && (!semantics || !dL_dpix_semantic || !dL_dsemantic))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL semantic pointer with S>0");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const CameraArgs cam = make_camera(viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy);
+  const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
+  const GeomLayout GL = geom_layout((size_t)P);
+  const BinLayout BL = bin_layout((size_t)R);
+  const ImgLayout IL = img_layout(T, (size_t)width * height);
+  if (debug) {  // validate the blobs (costs a sync; only in debug mode, like the reference's checks)
+    BlobHeader h[3];
+    HIP_TRY(hipMemcpyAsync(&h[0], geom_buffer, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&h[1], binning_buffer, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&h[2], image_buffer, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (h[0].magic != GEOM_MAGIC || h[1].magic != BIN_MAGIC || h[2].magic != IMG_MAGIC ||
+        h[0].P != (uint32_t)P || h[1].R != (uint32_t)R || h[2].W != (uint32_t)width ||
+        h[2].H != (uint32_t)height)
+      return fail(GRPG_ERR_BAD_BUFFER, "state buffers do not match this call (P/R/W/H or magic)");
+  }
+  const float4* rec = (const float4*)(geom_buffer + GL.rec);
+  const int* radii_int = radii ? radii : (const int*)(geom_buffer + GL.radii);
+  const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.val_a);
+  const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
+  const uint32_t* n_contrib = (const uint32_t*)(image_buffer + IL.n_contrib);
+
+  launch_render_backward(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
+                         cam.gy, background, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas,
+                         dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                         dL_ddepth, dL_dsemantic);
+  STAGE_CHECK("render backward");
+  launch_preprocess_backward(stream, P, D, M, means3D, radii_int, colors_precomp ? nullptr : shs,
+                             rec, cov3D_precomp ? nullptr : scales, rotations, scale_modifier,
+                             cov3D_precomp, cam, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor,
+                             dL_ddepth, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+  STAGE_CHECK("preprocess backward");
+  return GRPG_OK;
+}
+
+int grpg_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, unsigned char* present, void* hip_stream) {
+  (void)projmatrix;
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present)))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "bad argument");
+  launch_mark_visible((hipStream_t)hip_stream, P, means3D, viewmatrix, present);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
+int grpg_visible_filter(int P, int M, int width, int height, const float* means3D,
+                        const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix,
+                        const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered,
+                        int* radii, float* means2D, int debug, void* hip_stream) {
+  (void)M; (void)prefiltered;
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P < 0 || width <= 0 || height <= 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "bad size");
+  if (P == 0) return GRPG_OK;
+  if (!means3D || !viewmatrix || !projmatrix || !radii || !means2D ||
+      (!cov3D_precomp && (!scales || !rotations)))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL pointer");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const CameraArgs cam = make_camera(viewmatrix, projmatrix, nullptr, width, height, tan_fovx, tan_fovy);
+  launch_visible_filter(stream, P, means3D, scales, scale_modifier, rotations, cov3D_precomp, cam,
+                        radii, means2D);
+  STAGE_CHECK("visible filter");
+  return GRPG_OK;
+}
+
+int grpg_debug_export(int P, int R, int width, int height, const char* geom_buffer,
+                      const char* binning_buffer, const char* image_buffer, uint64_t* keys_sorted,
+                      uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib, float* means2D,
+                      float* depths, float* conic_opacity, float* rgb, uint32_t* tiles_touched,
+                      void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P < 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "bad argument");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+  const GeomLayout GL = geom_layout((size_t)P);
+  const BinLayout BL = bin_layout((size_t)R);
+  const ImgLayout IL = img_layout((size_t)gx * gy, (size_t)width * height);
+  launch_debug_export(stream, P, (uint32_t)R, width, height, gx, gy,
+                      (const float4*)(geom_buffer + GL.rec),
+                      (const uint32_t*)(geom_buffer + GL.tiles),
+                      (const uint32_t*)(binning_buffer + BL.key_a),
+                      (const uint32_t*)(binning_buffer + BL.val_a),
+                      (const uint2*)(image_buffer + IL.ranges),
+                      (const uint32_t*)(image_buffer + IL.n_contrib), keys_sorted, point_list,
+                      ranges, n_contrib, means2D, depths, conic_opacity, rgb, tiles_touched);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
+}  // extern "C"

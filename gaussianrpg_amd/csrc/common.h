@@ -1,0 +1,202 @@
+// Internal declarations shared by the HIP translation units of libgrpg_rasterizer.so.
+// Target: gfx950 (MI355X, CDNA4, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace grpg {
+
+constexpr int TILE = 16;            // cuda_rasterizer/config.h:17-18
+constexpr int WAVE = 64;            // gfx950 wavefront
+constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;  // depth key of a culled Gaussian (sorts last)
+
+// ---------------------------------------------------------------------------------------
+// Per-Gaussian record written by preprocess and gathered by render: 3 x float4 = 48 B.
+//   r0 = { px, py, depth(view z), opacity }
+//   r1 = { conic.x, conic.y, conic.z, R }
+//   r2 = { G, B, bits(clamped mask: bit0 R,bit1 G,bit2 B), bits(radius as int32) }
+// The reference keeps the same data in six arrays (GeometryState, rasterizer_impl.h:30-44);
+// one 48-byte record means a tile instance costs one contiguous gather instead of four.
+// ---------------------------------------------------------------------------------------
+constexpr int REC_F4 = 3;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+constexpr uint32_t GEOM_MAGIC = 0x47504730u;  // "GPG0"
+constexpr uint32_t BIN_MAGIC = 0x47504231u;
+constexpr uint32_t IMG_MAGIC = 0x47504932u;
+
+struct BlobHeader {      // first 256 bytes of every blob
+  uint32_t magic;
+  uint32_t P;
+  uint32_t R;            // num_rendered (device-written in the geometry blob)
+  uint32_t W, H;
+  uint32_t S;
+  uint32_t reserved[58];
+};
+static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
+
+// radix sort geometry
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_MAX_BITS = 8;
+constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
+
+// scan geometry
+constexpr int SC_THREADS = 256;
+constexpr int SC_ITEMS = 8;
+constexpr int SC_CHUNK = SC_THREADS * SC_ITEMS;  // 2048 per workgroup
+
+struct GeomLayout {
+  size_t total;
+  size_t rec, key_a, key_b, val_a, val_b, tiles, offsets, radii, table, totals, block_sums;
+  uint32_t nchunks_sort, nblocks_scan;
+};
+struct BinLayout {
+  size_t total;
+  size_t key_a, key_b, val_a, val_b, table, totals;
+  uint32_t nchunks_sort;
+};
+struct ImgLayout {
+  size_t total;
+  size_t ranges, n_contrib;
+};
+
+inline GeomLayout geom_layout(size_t P) {
+  GeomLayout L{};
+  size_t o = sizeof(BlobHeader);
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  L.nchunks_sort = (uint32_t)((P + RS_CHUNK - 1) / RS_CHUNK);
+  L.nblocks_scan = (uint32_t)((P + SC_CHUNK - 1) / SC_CHUNK);
+  L.rec = take(P * REC_F4 * 16);
+  L.key_a = take(P * 4);
+  L.key_b = take(P * 4);
+  L.val_a = take(P * 4);
+  L.val_b = take(P * 4);
+  L.tiles = take(P * 4);
+  L.offsets = take(P * 4);
+  L.radii = take(P * 4);
+  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 4);
+  L.totals = take(RS_MAX_RADIX * 4);
+  L.block_sums = take(((size_t)L.nblocks_scan + 1) * 4);
+  L.total = o;
+  return L;
+}
+inline BinLayout bin_layout(size_t R) {
+  BinLayout L{};
+  size_t o = sizeof(BlobHeader);
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  L.nchunks_sort = (uint32_t)((R + RS_CHUNK - 1) / RS_CHUNK);
+  L.val_a = take(R * 4);   // == point_list after the tile sort
+  L.key_a = take(R * 4);   // == sorted tile ids
+  L.key_b = take(R * 4);
+  L.val_b = take(R * 4);
+  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 4);
+  L.totals = take(RS_MAX_RADIX * 4);
+  L.total = o;
+  return L;
+}
+inline ImgLayout img_layout(size_t T, size_t N) {
+  ImgLayout L{};
+  size_t o = sizeof(BlobHeader);
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  L.ranges = take(T * 8);
+  L.n_contrib = take(N * 4);
+  L.total = o;
+  return L;
+}
+
+// ------------------------------- launchers (one per .hip TU) ---------------------------
+struct CameraArgs {
+  const float* view;    // device [16]
+  const float* proj;    // device [16]
+  const float* campos;  // device [3]
+  int W, H, gx, gy;
+  float tan_fovx, tan_fovy, focal_x, focal_y;
+};
+
+void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
+                       const float* scales, float scale_modifier, const float* rotations,
+                       const float* opacities, const float* shs, const float* cov3D_precomp,
+                       const float* colors_precomp, const CameraArgs& cam, int* radii,
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles);
+void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
+                           float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const CameraArgs& cam, int* radii,
+                           float* means2D);
+void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view,
+                         unsigned char* present);
+
+// Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), in
+// passes of <= 8 bits.  (key_a,val_a) holds the input (val_a ignored when vals_iota: value i = i),
+// (key_b,val_b) is scratch.  Returns true if the result is in the "b" pair, false if in "a".
+bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
+                      uint32_t* val_b, bool vals_iota, int begin_bit, int end_bit, uint32_t* table,
+                      uint32_t* totals, uint32_t nchunks);
+int radix_sort_num_passes(int begin_bit, int end_bit);
+
+// offsets[i] = exclusive prefix sum over tiles[gid[i]]; *total (device) = sum.
+void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* gid, const uint32_t* tiles,
+                         uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
+                         uint32_t* total_out);
+
+void launch_emit(hipStream_t s, uint32_t P, const uint32_t* sorted_gid, const uint32_t* offsets,
+                 const uint32_t* tiles, const float4* rec, int gx, int gy, uint32_t* tile_keys,
+                 uint32_t* vals);
+void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
+                        uint32_t T);
+
+void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+                           const float4* rec, int W, int H, int gx, int gy, const float* bg,
+                           float* out_color, float* out_depth, float* out_alpha,
+                           uint32_t* n_contrib);
+void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+                            const float4* rec, const float* semantics, int S, int W, int H, int gx,
+                            int gy, float* out_semantic);
+
+void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+                            const float4* rec, const float* semantics, int S, int W, int H, int gx,
+                            int gy, const float* bg, const float* alphas,
+                            const uint32_t* n_contrib, const float* dL_dpix,
+                            const float* dL_dpix_depth, const float* dL_dalphas,
+                            const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dconic,
+                            float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                            float* dL_dsemantic);
+void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,
+                                const int* radii, const float* shs, const float4* rec,
+                                const float* scales, const float* rotations, float scale_modifier,
+                                const float* cov3D_precomp, const CameraArgs& cam,
+                                const float* dL_dmean2D, const float* dL_dconic,
+                                float* dL_dmean3D, const float* dL_dcolor, const float* dL_ddepth,
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
+
+void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
+                         const float4* rec, const uint32_t* tiles, const uint32_t* tile_keys,
+                         const uint32_t* point_list, const uint2* ranges,
+                         const uint32_t* n_contrib_in, uint64_t* keys_sorted,
+                         uint32_t* point_list_out, uint32_t* ranges_out, uint32_t* n_contrib_out,
+                         float* means2D, float* depths, float* conic_opacity, float* rgb,
+                         uint32_t* tiles_out);
+
+// ------------------------------- device helpers ---------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// float -> int, truncating & saturating (v_cvt_i32_f32), identical to oracle f2i_rz_sat.
+__device__ __forceinline__ int f2i_rz(float x) { return (int)x; }
+
+// Tile rectangle of a splat: cuda_rasterizer/auxiliary.h:46-56.
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy,
+                                         int& minx, int& miny, int& maxx, int& maxy) {
+  const float r = (float)max_radius;
+  minx = min(gx, max(0, f2i_rz((px - r) / 16.0f)));
+  miny = min(gy, max(0, f2i_rz((py - r) / 16.0f)));
+  maxx = min(gx, max(0, f2i_rz((px + r + 15.0f) / 16.0f)));
+  maxy = min(gy, max(0, f2i_rz((py + r + 15.0f) / 16.0f)));
+}
+#endif
+
+}  // namespace grpg

@@ -1,0 +1,217 @@
+// Per-Gaussian preprocess for gfx950: near cull, projection, Sigma = R S^2 R^T, EWA 2x2
+// covariance (+0.3 low-pass), conic, radius, tile rectangle, SH -> RGB.
+//
+// Replaces preprocessCUDA / filter_preprocessCUDA / checkFrustum of the reference
+// (cuda_rasterizer/forward.cu:155-256, :259-334; rasterizer_impl.cu:54-66) and the device
+// helpers they call (forward.cu:20-152, auxiliary.h:41-164).
+//
+// ARITHMETIC CONTRACT: this translation unit is compiled with -ffp-contract=off and every
+// expression below is written in the evaluation order of the reference source (glm 0.9.9.9
+// matrix products term by term), so that radii, tile rectangles, tiles_touched and the depth
+// sort keys are BIT-EXACT against oracle/gs_oracle.c.  Division and sqrt are IEEE-correct in
+// HIP by default (-fhip-fp32-correctly-rounded-divide-sqrt).  Do not "simplify" anything here.
+//
+// Memory: one thread per Gaussian, 256-thread workgroups.  Inputs arrive AoS ([P,3], [P,4],
+// [P,M,3]) straight from the caller's torch.cat; a wave's 64 lanes read 64 consecutive
+// records, so every cache line fetched is fully used.  Output is one 48-byte record per
+// visible Gaussian (common.h) + radii + depth key + tiles_touched.  The kernel is HBM-bound:
+// algorithmic bytes = P*(44+12M) read + 12 B (+48 B if visible) written per Gaussian.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+#include "gaussian_math.h"
+
+namespace grpg {
+
+// Everything up to the tile rectangle.  Returns false if the Gaussian is culled
+// (near plane, det==0, empty rectangle) -- forward.cu:192-237.
+__device__ __forceinline__ bool project_and_bound(const int idx, const float* __restrict__ means3D,
+                                                  const float* __restrict__ scales,
+                                                  const float scale_modifier,
+                                                  const float* __restrict__ rotations,
+                                                  const float* __restrict__ cov3D_precomp,
+                                                  const float* __restrict__ view,
+                                                  const float* __restrict__ proj, const int W,
+                                                  const int H, const int gx, const int gy,
+                                                  const float tan_fovx, const float tan_fovy,
+                                                  const float focal_x, const float focal_y,
+                                                  Projected& o) {
+  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+  // in_frustum, auxiliary.h:139-164
+  const float hx = proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12];
+  const float hy = proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13];
+  const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+  const float p_w = 1.0f / (hw + 0.0000001f);
+  const float projx = hx * p_w, projy = hy * p_w;
+  const float vz = view[2] * mx + view[6] * my + view[10] * mz + view[14];
+  if (vz <= 0.2f) return false;
+  if (cov3D_precomp != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) o.cov3d[i] = cov3D_precomp[6 * idx + i];
+  } else {
+    const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+    cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2],
+                         scale_modifier, q, o.cov3d);
+  }
+  Cov2D cv;
+  cov2d_project(mx, my, mz, view, focal_x, focal_y, tan_fovx, tan_fovy, o.cov3d, cv);
+  const float cov_x = cv.a + 0.3f, cov_y = cv.b, cov_z = cv.c + 0.3f;
+  const float det = (cov_x * cov_z - cov_y * cov_y);
+  if (det == 0.0f) return false;
+  const float det_inv = 1.f / det;
+  o.conic[0] = cov_z * det_inv;
+  o.conic[1] = -cov_y * det_inv;
+  o.conic[2] = cov_x * det_inv;
+  const float mid = 0.5f * (cov_x + cov_z);
+  const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+  o.px = ndc2pix(projx, W);
+  o.py = ndc2pix(projy, H);
+  o.radius = f2i_rz(my_radius);
+  get_rect(o.px, o.py, o.radius, gx, gy, o.minx, o.miny, o.maxx, o.maxy);
+  if ((uint32_t)(o.maxx - o.minx) * (uint32_t)(o.maxy - o.miny) == 0) return false;
+  o.depth = vz;
+  return true;
+}
+
+// SH -> RGB, forward.cu:20-71.  `sh` points at this Gaussian's M coefficients (x3 channels).
+__device__ __forceinline__ void sh_to_rgb(const int deg, const float* __restrict__ sh,
+                                          const float dx, const float dy, const float dz,
+                                          float* rgb, uint32_t& clamped) {
+  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float x = dx / len, y = dy / len, z = dz / len;
+  clamped = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+#define SH(k) sh[3 * (k) + c]
+    float result = SH_C0 * SH(0);
+    if (deg > 0) {
+      result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) +
+                 SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) + SH_C2[3] * xz * SH(7) +
+                 SH_C2[4] * (xx - yy) * SH(8);
+        if (deg > 2) {
+          result = result + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                   SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                   SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                   SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) +
+                   SH_C3[5] * z * (xx - yy) * SH(14) + SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+        }
+      }
+    }
+#undef SH
+    result += 0.5f;
+    if (result < 0) clamped |= (1u << c);
+    rgb[c] = fmaxf(result, 0.0f);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_kernel(const int P, const int D, const int M, const float* __restrict__ means3D,
+                  const float* __restrict__ scales, const float scale_modifier,
+                  const float* __restrict__ rotations, const float* __restrict__ opacities,
+                  const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ view,
+                  const float* __restrict__ proj, const float* __restrict__ campos, const int W,
+                  const int H, const int gx, const int gy, const float tan_fovx,
+                  const float tan_fovy, const float focal_x, const float focal_y,
+                  int* __restrict__ radii, float4* __restrict__ rec,
+                  uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  Projected o;
+  const bool vis = project_and_bound(idx, means3D, scales, scale_modifier, rotations,
+                                     cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
+                                     focal_x, focal_y, o);
+  if (!vis) {
+    radii[idx] = 0;
+    tiles[idx] = 0;
+    depth_key[idx] = CULLED_KEY;
+    return;
+  }
+  float rgb[3];
+  uint32_t clamped = 0;
+  if (colors_precomp == nullptr) {
+    const float dx = means3D[3 * idx] - campos[0];
+    const float dy = means3D[3 * idx + 1] - campos[1];
+    const float dz = means3D[3 * idx + 2] - campos[2];
+    sh_to_rgb(D, shs + (size_t)idx * M * 3, dx, dy, dz, rgb, clamped);
+  } else {
+    rgb[0] = colors_precomp[3 * idx];
+    rgb[1] = colors_precomp[3 * idx + 1];
+    rgb[2] = colors_precomp[3 * idx + 2];
+  }
+  radii[idx] = o.radius;
+  tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
+  depth_key[idx] = __float_as_uint(o.depth);
+  rec[3 * idx + 0] = make_float4(o.px, o.py, o.depth, opacities[idx]);
+  rec[3 * idx + 1] = make_float4(o.conic[0], o.conic[1], o.conic[2], rgb[0]);
+  rec[3 * idx + 2] = make_float4(rgb[1], rgb[2], __uint_as_float(clamped), __int_as_float(o.radius));
+}
+
+__global__ void __launch_bounds__(256)
+visible_filter_kernel(const int P, const float* __restrict__ means3D,
+                      const float* __restrict__ scales, const float scale_modifier,
+                      const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+                      const float* __restrict__ proj, const int W, const int H, const int gx,
+                      const int gy, const float tan_fovx, const float tan_fovy,
+                      const float focal_x, const float focal_y, int* __restrict__ radii,
+                      float* __restrict__ means2D) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  Projected o;
+  const bool vis = project_and_bound(idx, means3D, scales, scale_modifier, rotations,
+                                     cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
+                                     focal_x, focal_y, o);
+  radii[idx] = vis ? o.radius : 0;
+  if (vis) {  // forward.cu:331-333: only visible Gaussians get a screen position
+    means2D[2 * idx] = o.px;
+    means2D[2 * idx + 1] = o.py;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(const int P, const float* __restrict__ means3D,
+                    const float* __restrict__ view, unsigned char* __restrict__ present) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+  const float vz = view[2] * mx + view[6] * my + view[10] * mz + view[14];
+  present[idx] = (vz <= 0.2f) ? 0 : 1;
+}
+
+void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
+                       const float* scales, float scale_modifier, const float* rotations,
+                       const float* opacities, const float* shs, const float* cov3D_precomp,
+                       const float* colors_precomp, const CameraArgs& cam, int* radii,
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles) {
+  if (P <= 0) return;
+  preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+      P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+      colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
+      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles);
+}
+
+void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
+                           float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const CameraArgs& cam, int* radii,
+                           float* means2D) {
+  if (P <= 0) return;
+  visible_filter_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+      P, means3D, scales, scale_modifier, rotations, cov3D_precomp, cam.view, cam.proj, cam.W,
+      cam.H, cam.gx, cam.gy, cam.tan_fovx, cam.tan_fovy, cam.focal_x, cam.focal_y, radii, means2D);
+}
+
+void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view,
+                         unsigned char* present) {
+  if (P <= 0) return;
+  mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, view, present);
+}
+
+}  // namespace grpg

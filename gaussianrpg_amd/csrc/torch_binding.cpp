@@ -1,0 +1,300 @@
+// PyTorch-ROCm extension module `_C`: the operator surface the reference's Python wrapper binds
+// (submodules/diff-gaussian-rasterization/ext.cpp:15-20), implemented on top of the C ABI in
+// include/grpg_rasterizer.h.  Same four functions, same argument order and return tuples as
+// rasterize_points.h:18-88 / rasterize_points.cu:35-306:
+//   rasterize_gaussians, rasterize_gaussians_backward, mark_visible, rasterize_gaussians_filter.
+// This file is plumbing only (tensor allocation, pointer extraction, stream/device selection);
+// it contains no rasterizer arithmetic and has no CPU path: CPU means3D -> error.
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <torch/extension.h>
+
+#include <stdexcept>
+#include <string>
+#include <tuple>
+
+#include "../../include/grpg_rasterizer.h"
+
+namespace {
+
+// Optional inputs arrive as EMPTY (usually CPU) tensors, diff_gaussian_rasterization/__init__.py:
+// 207-217; the reference turns them into null data pointers.  Everything else must be fp32 on
+// the same HIP device as means3D.
+const float* fptr(const torch::Tensor& t, const torch::Tensor& like, const char* name,
+                  torch::Tensor& keep) {
+  if (!t.defined() || t.numel() == 0) return nullptr;
+  TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32");
+  TORCH_CHECK(t.device() == like.device(), name, " must be on ", like.device(), " (got ",
+              t.device(), ")");
+  keep = t.contiguous();
+  return keep.data_ptr<float>();
+}
+
+char* resize_blob(size_t bytes, void* user) {   // replaces resizeFunctional, rasterize_points.cu:27-33
+  auto* t = static_cast<torch::Tensor*>(user);
+  t->resize_({static_cast<long long>(bytes)});
+  return reinterpret_cast<char*>(t->data_ptr());
+}
+
+void require_device(const torch::Tensor& means3D) {
+  TORCH_CHECK(means3D.is_cuda(),
+              "gaussianrpg_amd: means3D must live on a ROCm/HIP device (torch device 'cuda'); "
+              "this rasterizer is MI355X-native and has no CPU path");
+}
+
+[[noreturn]] void raise_abi_error(const char* what, int rc) {
+  throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) +
+                           "): " + grpg_last_error());
+}
+
+}  // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D,
+                   const torch::Tensor& colors, const torch::Tensor& semantics,
+                   const torch::Tensor& opacity, const torch::Tensor& scales,
+                   const torch::Tensor& rotations, const float scale_modifier,
+                   const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                   const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                   const int image_height, const int image_width, const torch::Tensor& sh,
+                   const int degree, const torch::Tensor& campos, const bool prefiltered,
+                   const bool debug) {
+  if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
+    AT_ERROR("means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:58-60
+  }
+  require_device(means3D);
+  TORCH_CHECK(means3D.scalar_type() == torch::kFloat32, "means3D must be float32");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+  const int P = means3D.size(0);
+  const int H = image_height, W = image_width;
+  TORCH_CHECK(semantics.dim() == 2, "semantics must be [P,S]");
+  const int S = semantics.size(1);
+
+  auto float_opts = means3D.options().dtype(torch::kFloat32);
+  // every element of these planes is written by the library: no zero-fill pass needed
+  torch::Tensor out_color = torch::empty({GRPG_NUM_CHANNELS, H, W}, float_opts);
+  torch::Tensor out_depth = torch::empty({1, H, W}, float_opts);
+  torch::Tensor out_alpha = torch::empty({1, H, W}, float_opts);
+  torch::Tensor out_semantic = torch::empty({S, H, W}, float_opts);
+  torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
+  auto byte_opts = means3D.options().dtype(torch::kByte);
+  torch::Tensor geomBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor binningBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+
+  int M = 0;
+  if (sh.size(0) != 0) M = sh.size(1);   // rasterize_points.cu:88-92
+
+  torch::Tensor k_bg, k_means, k_sh, k_col, k_sem, k_op, k_sc, k_rot, k_cov, k_view, k_proj, k_cam;
+  const float* p_bg = fptr(background, means3D, "background", k_bg);
+  const float* p_means = fptr(means3D, means3D, "means3D", k_means);
+  const float* p_sh = fptr(sh, means3D, "sh", k_sh);
+  const float* p_col = fptr(colors, means3D, "colors_precomp", k_col);
+  const float* p_sem = fptr(semantics, means3D, "semantics", k_sem);
+  const float* p_op = fptr(opacity, means3D, "opacities", k_op);
+  const float* p_sc = fptr(scales, means3D, "scales", k_sc);
+  const float* p_rot = fptr(rotations, means3D, "rotations", k_rot);
+  const float* p_cov = fptr(cov3D_precomp, means3D, "cov3D_precomp", k_cov);
+  const float* p_view = fptr(viewmatrix, means3D, "viewmatrix", k_view);
+  const float* p_proj = fptr(projmatrix, means3D, "projmatrix", k_proj);
+  const float* p_cam = fptr(campos, means3D, "campos", k_cam);
+  TORCH_CHECK(p_bg && p_view && p_proj && p_cam, "bg/viewmatrix/projmatrix/campos must be non-empty");
+
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rendered = grpg_forward(
+      resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree, M,
+      S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov, p_view,
+      p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, out_color.data_ptr<float>(),
+      out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
+      S > 0 ? out_semantic.data_ptr<float>() : nullptr, P > 0 ? radii.data_ptr<int>() : nullptr,
+      debug ? 1 : 0, (void*)stream);
+  if (rendered < 0) raise_abi_error("grpg_forward", rendered);
+  return std::make_tuple(rendered, out_color, out_depth, out_alpha, out_semantic, radii,
+                         geomBuffer, binningBuffer, imgBuffer);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor& means3D,
+                           const torch::Tensor& radii, const torch::Tensor& colors,
+                           const torch::Tensor& scales, const torch::Tensor& rotations,
+                           const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                           const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+                           const float tan_fovx, const float tan_fovy,
+                           const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_depth,
+                           const torch::Tensor& dL_dout_alpha,
+                           const torch::Tensor& dL_dout_semantic, const torch::Tensor& sh,
+                           const int degree, const torch::Tensor& campos,
+                           const torch::Tensor& geomBuffer, const int R,
+                           const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+                           const torch::Tensor& alphas, const torch::Tensor& semantics,
+                           const bool debug) {
+  require_device(means3D);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+  const int P = means3D.size(0);
+  const int H = dL_dout_color.size(1);   // rasterize_points.cu:156-158
+  const int W = dL_dout_color.size(2);
+  const int S = dL_dout_semantic.size(0);
+  int M = 0;
+  if (sh.size(0) != 0) M = sh.size(1);
+
+  auto o = means3D.options();
+  torch::Tensor dL_dmeans3D = torch::zeros({P, 3}, o);
+  torch::Tensor dL_dmeans2D = torch::zeros({P, 3}, o);
+  torch::Tensor dL_dcolors = torch::zeros({P, GRPG_NUM_CHANNELS}, o);
+  torch::Tensor dL_ddepths = torch::zeros({P, 1}, o);
+  torch::Tensor dL_dconic = torch::zeros({P, 2, 2}, o);
+  torch::Tensor dL_dopacity = torch::zeros({P, 1}, o);
+  torch::Tensor dL_dcov3D = torch::zeros({P, 6}, o);
+  torch::Tensor dL_dsh = torch::zeros({P, M, 3}, o);
+  torch::Tensor dL_dscales = torch::zeros({P, 3}, o);
+  torch::Tensor dL_drotations = torch::zeros({P, 4}, o);
+  torch::Tensor dL_dsemantic = torch::zeros({P, S}, o);
+
+  if (P != 0) {
+    torch::Tensor k[16];
+    const float* p_bg = fptr(background, means3D, "background", k[0]);
+    const float* p_means = fptr(means3D, means3D, "means3D", k[1]);
+    const float* p_sh = fptr(sh, means3D, "sh", k[2]);
+    const float* p_col = fptr(colors, means3D, "colors_precomp", k[3]);
+    const float* p_sem = fptr(semantics, means3D, "semantics", k[4]);
+    const float* p_alpha = fptr(alphas, means3D, "alphas", k[5]);
+    const float* p_sc = fptr(scales, means3D, "scales", k[6]);
+    const float* p_rot = fptr(rotations, means3D, "rotations", k[7]);
+    const float* p_cov = fptr(cov3D_precomp, means3D, "cov3D_precomp", k[8]);
+    const float* p_view = fptr(viewmatrix, means3D, "viewmatrix", k[9]);
+    const float* p_proj = fptr(projmatrix, means3D, "projmatrix", k[10]);
+    const float* p_cam = fptr(campos, means3D, "campos", k[11]);
+    const float* g_col = fptr(dL_dout_color, means3D, "dL_dout_color", k[12]);
+    const float* g_dep = fptr(dL_dout_depth, means3D, "dL_dout_depth", k[13]);
+    const float* g_alp = fptr(dL_dout_alpha, means3D, "dL_dout_alpha", k[14]);
+    const float* g_sem = fptr(dL_dout_semantic, means3D, "dL_dout_semantic", k[15]);
+    TORCH_CHECK(radii.scalar_type() == torch::kInt32 && radii.device() == means3D.device(),
+                "radii must be int32 on the device");
+    torch::Tensor radii_c = radii.contiguous();
+    torch::Tensor gb = geomBuffer.contiguous(), bb = binningBuffer.contiguous(),
+                  ib = imageBuffer.contiguous();
+    hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    const int rc = grpg_backward(
+        P, degree, M, R, S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_alpha, p_sc, scale_modifier,
+        p_rot, p_cov, p_view, p_proj, p_cam, tan_fovx, tan_fovy, radii_c.data_ptr<int>(),
+        reinterpret_cast<char*>(gb.data_ptr()), reinterpret_cast<char*>(bb.data_ptr()),
+        reinterpret_cast<char*>(ib.data_ptr()), g_col, g_dep, g_alp, g_sem,
+        dL_dmeans2D.data_ptr<float>(), dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
+        dL_dcolors.data_ptr<float>(), dL_ddepths.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
+        dL_dcov3D.data_ptr<float>(), M > 0 ? dL_dsh.data_ptr<float>() : nullptr,
+        dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(),
+        S > 0 ? dL_dsemantic.data_ptr<float>() : nullptr, debug ? 1 : 0, (void*)stream);
+    if (rc != GRPG_OK) raise_abi_error("grpg_backward", rc);
+  }
+  return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                         dL_dscales, dL_drotations, dL_dsemantic);
+}
+
+torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix,
+                          torch::Tensor& projmatrix) {
+  require_device(means3D);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+  const int P = means3D.size(0);
+  torch::Tensor present = torch::full({P}, false, means3D.options().dtype(at::kBool));
+  if (P != 0) {
+    torch::Tensor k[3];
+    const float* p_means = fptr(means3D, means3D, "means3D", k[0]);
+    const float* p_view = fptr(viewmatrix, means3D, "viewmatrix", k[1]);
+    const float* p_proj = fptr(projmatrix, means3D, "projmatrix", k[2]);
+    hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    const int rc = grpg_mark_visible(P, p_means, p_view, p_proj,
+                                     reinterpret_cast<unsigned char*>(present.data_ptr<bool>()),
+                                     (void*)stream);
+    if (rc != GRPG_OK) raise_abi_error("grpg_mark_visible", rc);
+  }
+  return present;
+}
+
+std::tuple<torch::Tensor, torch::Tensor> RasterizeGaussiansFilter(
+    const torch::Tensor& means3D, const torch::Tensor& scales, const torch::Tensor& rotations,
+    const float scale_modifier, const torch::Tensor& cov3D_precomp,
+    const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+    const float tan_fovy, const int image_height, const int image_width, const bool prefiltered,
+    const bool debug) {
+  if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
+    AT_ERROR("means3D must have dimensions (num_points, 3)");
+  }
+  require_device(means3D);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+  const int P = means3D.size(0);
+  torch::Tensor radii = torch::full({P}, 0, means3D.options().dtype(torch::kInt32));
+  torch::Tensor means2D = torch::full({P, 2}, 0, means3D.options());
+  if (P != 0) {
+    torch::Tensor k[6];
+    const float* p_means = fptr(means3D, means3D, "means3D", k[0]);
+    const float* p_sc = fptr(scales, means3D, "scales", k[1]);
+    const float* p_rot = fptr(rotations, means3D, "rotations", k[2]);
+    const float* p_cov = fptr(cov3D_precomp, means3D, "cov3D_precomp", k[3]);
+    const float* p_view = fptr(viewmatrix, means3D, "viewmatrix", k[4]);
+    const float* p_proj = fptr(projmatrix, means3D, "projmatrix", k[5]);
+    hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    const int rc = grpg_visible_filter(P, 0, image_width, image_height, p_means, p_sc,
+                                       scale_modifier, p_rot, p_cov, p_view, p_proj, tan_fovx,
+                                       tan_fovy, prefiltered ? 1 : 0, radii.data_ptr<int>(),
+                                       means2D.data_ptr<float>(), debug ? 1 : 0, (void*)stream);
+    if (rc != GRPG_OK) raise_abi_error("grpg_visible_filter", rc);
+  }
+  return std::make_tuple(radii, means2D);
+}
+
+// Parity/debug accessor (no reference counterpart): decode the private blobs of a
+// forward call into the reference's intermediate arrays.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+DebugExport(const torch::Tensor& geomBuffer, const torch::Tensor& binningBuffer,
+            const torch::Tensor& imgBuffer, const int P, const int R, const int image_height,
+            const int image_width) {
+  TORCH_CHECK(geomBuffer.is_cuda(), "buffers must be device tensors");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(geomBuffer.device());
+  const int gx = (image_width + GRPG_TILE_X - 1) / GRPG_TILE_X;
+  const int gy = (image_height + GRPG_TILE_Y - 1) / GRPG_TILE_Y;
+  auto o = geomBuffer.options();
+  torch::Tensor keys = torch::zeros({R}, o.dtype(torch::kInt64));
+  torch::Tensor plist = torch::zeros({R}, o.dtype(torch::kInt32));
+  torch::Tensor ranges = torch::zeros({gx * gy, 2}, o.dtype(torch::kInt32));
+  torch::Tensor ncontrib = torch::zeros({image_height, image_width}, o.dtype(torch::kInt32));
+  torch::Tensor means2D = torch::zeros({P, 2}, o.dtype(torch::kFloat32));
+  torch::Tensor depths = torch::zeros({P}, o.dtype(torch::kFloat32));
+  torch::Tensor conic = torch::zeros({P, 4}, o.dtype(torch::kFloat32));
+  torch::Tensor rgb = torch::zeros({P, 3}, o.dtype(torch::kFloat32));
+  torch::Tensor tiles = torch::zeros({P}, o.dtype(torch::kInt32));
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_debug_export(
+      P, R, image_width, image_height, reinterpret_cast<const char*>(geomBuffer.data_ptr()),
+      reinterpret_cast<const char*>(binningBuffer.data_ptr()),
+      reinterpret_cast<const char*>(imgBuffer.data_ptr()),
+      reinterpret_cast<uint64_t*>(keys.data_ptr<int64_t>()),
+      reinterpret_cast<uint32_t*>(plist.data_ptr<int>()),
+      reinterpret_cast<uint32_t*>(ranges.data_ptr<int>()),
+      reinterpret_cast<uint32_t*>(ncontrib.data_ptr<int>()), means2D.data_ptr<float>(),
+      depths.data_ptr<float>(), conic.data_ptr<float>(), rgb.data_ptr<float>(),
+      reinterpret_cast<uint32_t*>(tiles.data_ptr<int>()), (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_debug_export", rc);
+  return std::make_tuple(keys, plist, ranges, ncontrib, means2D, depths, conic, rgb, tiles);
+}
+
+std::vector<float> StageTiming() {
+  std::vector<float> ms(GRPG_NUM_STAGES, 0.f);
+  const int rc = grpg_get_stage_timing(ms.data());
+  if (rc != GRPG_OK) raise_abi_error("grpg_get_stage_timing", rc);
+  return ms;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("rasterize_gaussians", &RasterizeGaussians);
+  m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
+  m.def("mark_visible", &markVisible);
+  m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);
+  // additions (not in the reference module)
+  m.def("debug_export", &DebugExport);
+  m.def("set_stage_timing", [](bool on) { grpg_set_stage_timing(on ? 1 : 0); });
+  m.def("stage_timing", &StageTiming);
+  m.def("abi_version", []() { return grpg_abi_version(); });
+}

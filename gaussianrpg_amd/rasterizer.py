@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's Python operator interface.
+
+Same public names, argument order, return values and error messages as
+submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py of the reference
+(:21-44 rasterize_gaussians, :46-165 _RasterizeGaussians, :167-179 GaussianRasterizationSettings,
+:181-260 GaussianRasterizer), so lib/utils/camera_utils.py:make_rasterizer and
+lib/models/street_gaussian_renderer.py:render_kernel call it unchanged.  The arithmetic lives in
+the HIP library behind ``_C``; nothing here falls back to PyTorch.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+try:
+    from . import _C
+except ImportError as exc:  # fail loudly: no CPU / eager fallback exists by design
+    raise ImportError(
+        "gaussianrpg_amd._C (the HIP extension for gfx950) is not built or failed to load: %s.\n"
+        "Build it in-tree with `python -m gaussianrpg_amd.build` (needs hipcc); there is no "
+        "CPU or PyTorch fallback for the rasterizer." % (exc,)) from exc
+
+
+def _snapshot(args):
+    """CPU deep copy of an argument tuple, taken before the call can corrupt it (debug mode)."""
+    return tuple(a.cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """autograd bridge: forward -> _C.rasterize_gaussians (20 args, reference order
+    __init__.py:63-84), backward -> _C.rasterize_gaussians_backward (26 args, :113-138)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        call = (rs.bg, means3D, colors_precomp, semantics, opacities, scales, rotations,
+                rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+                rs.prefiltered, rs.debug)
+        if rs.debug:
+            saved = _snapshot(call)
+            try:
+                out = _C.rasterize_gaussians(*call)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians(*call)
+        num_rendered, color, depth, alpha, semantic, radii, geom, binning, img = out
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              geom, binning, img, alpha, semantics)
+        return color, radii, depth, alpha, semantic
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha, grad_semantic):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
+         alpha, semantics) = ctx.saved_tensors
+        call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier,
+                cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color,
+                grad_depth, grad_alpha, grad_semantic, sh, rs.sh_degree, rs.campos, geom,
+                ctx.num_rendered, binning, img, alpha, semantics, rs.debug)
+        if rs.debug:
+            saved = _snapshot(call)
+            try:
+                grads = _C.rasterize_gaussians_backward(*call)
+            except Exception:
+                torch.save(saved, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            grads = _C.rasterize_gaussians_backward(*call)
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations,
+         g_semantics) = grads
+        # one gradient per forward input, in forward-argument order (reference :152-163)
+        return (g_means3D, g_means2D, g_sh, g_colors, g_semantics, g_opacities, g_scales,
+                g_rotations, g_cov3D, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opacities, scales,
+                        rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities,
+                                     scales, rotations, cov3Ds_precomp, raster_settings)
+
+
+def _empty():
+    # the reference passes torch.Tensor([]) (an empty CPU tensor) for absent optionals (:207-217)
+    return torch.Tensor([])
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: view-space z > 0.2 (reference :186-195 -> rasterizer_impl.cu:54-66)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None, semantics=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        shs = _empty() if shs is None else shs
+        colors_precomp = _empty() if colors_precomp is None else colors_precomp
+        scales = _empty() if scales is None else scales
+        rotations = _empty() if rotations is None else rotations
+        cov3D_precomp = _empty() if cov3D_precomp is None else cov3D_precomp
+        if semantics is None:
+            semantics = torch.zeros(means3D.shape[0], 0, dtype=torch.float32, device=means3D.device)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, semantics, opacities,
+                                   scales, rotations, cov3D_precomp, rs)
+
+    def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+        """(radii int32[P], means2D [P,2]) without colour/conic (reference :235-259)."""
+        rs = self.raster_settings
+        scales = _empty() if scales is None else scales
+        rotations = _empty() if rotations is None else rotations
+        cov3D_precomp = _empty() if cov3D_precomp is None else cov3D_precomp
+        with torch.no_grad():
+            return _C.rasterize_gaussians_filter(
+                means3D, scales, rotations, rs.scale_modifier, cov3D_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
+                rs.prefiltered, rs.debug)
+
+
+def debug_export(geom, binning, img, P, R, image_height, image_width):
+    """Decode the private blobs of a forward call into the reference's intermediate arrays:
+    dict(keys_sorted i64[R], point_list i32[R], ranges i32[T,2], n_contrib i32[H,W],
+    means2D, depths, conic_opacity, rgb, tiles_touched).  Parity tooling, not in the reference."""
+    names = ("keys_sorted", "point_list", "ranges", "n_contrib", "means2D", "depths",
+             "conic_opacity", "rgb", "tiles_touched")
+    return dict(zip(names, _C.debug_export(geom, binning, img, int(P), int(R), int(image_height),
+                                           int(image_width))))

@@ -1,0 +1,168 @@
+/*
+ * grpg_rasterizer.h -- C ABI of the MI355X-native 3D-Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of GimpelZhang/GaussianRPG: it replaces the
+ * static methods of CudaRasterizer::Rasterizer declared in
+ *   submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:22-114
+ * one for one (forward :32-58, backward :60-96, markVisible :25-30, visible_filter :98-114),
+ * with the same argument meaning and order.  The only changes are the ones a C ABI forces:
+ *   - std::function<char*(size_t)> buffer resizers  ->  (grpg_alloc_fn, void* user) pairs;
+ *   - bool -> int;  thrown std::runtime_error -> negative return + grpg_last_error();
+ *   - an explicit hipStream_t (the reference launches on the legacy default stream).
+ * All pointers are DEVICE pointers to fp32/int32 data unless stated otherwise; "optional"
+ * pointers may be NULL exactly where the reference accepts nullptr.  No torch types appear.
+ *
+ * The library (libgrpg_rasterizer.so) is pure HIP for gfx950; there is no CPU fallback: every
+ * entry point fails (GRPG_ERR_NO_DEVICE) if no HIP device is usable.
+ *
+ * The three "buffers" (geometry / binning / image) are opaque blobs with a layout private to
+ * this library (documented in DESIGN.md §4); they only have to survive from grpg_forward to the
+ * matching grpg_backward, exactly like the reference's geomBuffer/binningBuffer/imgBuffer
+ * (rasterize_points.cu:76-83, diff_gaussian_rasterization/__init__.py:101).
+ */
+#ifndef GRPG_RASTERIZER_H_INCLUDED
+#define GRPG_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRPG_ABI_VERSION 1
+
+/* Exported symbol (the library is built with -fvisibility=hidden). */
+#if defined(__GNUC__)
+#define GRPG_API __attribute__((visibility("default")))
+#else
+#define GRPG_API
+#endif
+
+/* Tile size: cuda_rasterizer/config.h:17-18 (BLOCK_X, BLOCK_Y). */
+#define GRPG_TILE_X 16
+#define GRPG_TILE_Y 16
+/* RGB only: cuda_rasterizer/config.h:15 (NUM_CHANNELS). */
+#define GRPG_NUM_CHANNELS 3
+
+enum {
+  GRPG_OK = 0,
+  GRPG_ERR_INVALID_ARGUMENT = -1,
+  GRPG_ERR_NO_DEVICE = -2,
+  GRPG_ERR_HIP = -3,        /* a HIP call or kernel failed; see grpg_last_error() */
+  GRPG_ERR_ALLOC = -4,      /* a grpg_alloc_fn returned NULL */
+  GRPG_ERR_BAD_BUFFER = -5  /* a blob handed to grpg_backward was not produced by grpg_forward */
+};
+
+/* Replaces std::function<char*(size_t N)> (rasterizer.h:33-35, rasterize_points.cu:27-33):
+ * must return a device pointer to at least `bytes` bytes that stays valid until the blob is
+ * released by the caller; called at most once per blob per grpg_forward. */
+typedef char* (*grpg_alloc_fn)(size_t bytes, void* user);
+
+/* ABI version of the loaded library (== GRPG_ABI_VERSION of the header it was built from). */
+GRPG_API int grpg_abi_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+GRPG_API const char* grpg_last_error(void);
+
+/*
+ * Rasterizer::forward  (rasterizer.h:32-58, rasterizer_impl.cu:197-343).
+ * P Gaussians, SH degree D with M coefficients per Gaussian, S semantic channels.
+ *   background[3]; means3D[P,3]; shs[P,M,3] or NULL; colors_precomp[P,3] or NULL;
+ *   semantics[P,S] (ignored when S==0); opacities[P]; scales[P,3] / rotations[P,4] or NULL with
+ *   cov3D_precomp[P,6]; viewmatrix[16], projmatrix[16] (row-major storage of the TRANSPOSED
+ *   math matrices, as lib/utils/camera_utils.py:50-58 builds them); cam_pos[3].
+ * Outputs (caller-allocated, like rasterize_points.cu:70-74): out_color[3,H,W], out_depth[H,W],
+ *   out_alpha[H,W], out_semantic[S,H,W], radii[P] (may be NULL).  Every pixel of every output
+ *   plane is written (the reference relies on pre-zeroed planes; this library does not).
+ * Returns num_rendered (>= 0, the number of Gaussian/tile instances) or a negative GRPG_ERR_*.
+ * Synchronises `stream` once (to size the binning blob), as the reference does
+ * (rasterizer_impl.cu:284).
+ */
+GRPG_API int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 int P, int D, int M, int S,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* semantics, const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, int prefiltered,
+                 float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
+                 int* radii, int debug, void* hip_stream);
+
+/*
+ * Rasterizer::backward  (rasterizer.h:60-96, rasterizer_impl.cu:396-505).
+ * R is the value grpg_forward returned.  geom/binning/image buffers are the blobs it filled.
+ * Gradient outputs must arrive ZERO-FILLED (as rasterize_points.cu:166-176 allocates them):
+ *   dL_dmean2D[P,3] (.z = sum |d/dx|+|d/dy|, backward.cu:627-628), dL_dconic[P,4] (.x .y .w),
+ *   dL_dopacity[P], dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3], dL_dcov3D[P,6],
+ *   dL_dsh[P,M,3], dL_dscale[P,3], dL_drot[P,4], dL_dsemantic[P,S].
+ * Returns GRPG_OK or a negative GRPG_ERR_*.
+ */
+GRPG_API int grpg_backward(int P, int D, int M, int R, int S,
+                  const float* background, int width, int height,
+                  const float* means3D, const float* shs, const float* colors_precomp,
+                  const float* semantics, const float* alphas,
+                  const float* scales, float scale_modifier, const float* rotations,
+                  const float* cov3D_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* campos,
+                  float tan_fovx, float tan_fovy, const int* radii,
+                  char* geom_buffer, char* binning_buffer, char* image_buffer,
+                  const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                  const float* dL_dpix_semantic,
+                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                  float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                  float* dL_dscale, float* dL_drot, float* dL_dsemantic,
+                  int debug, void* hip_stream);
+
+/* Rasterizer::markVisible (rasterizer.h:25-30, rasterizer_impl.cu:54-66,141-153):
+ * present[P] (1 byte each, 0/1) = view-space z > 0.2. */
+GRPG_API int grpg_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, unsigned char* present, void* hip_stream);
+
+/* Rasterizer::visible_filter (rasterizer.h:98-114, rasterizer_impl.cu:345-392,
+ * forward.cu:259-334): radii[P] and means2D[P,2] only (both must arrive zero-filled for
+ * culled Gaussians to read 0, as rasterize_points.cu:277-278 allocates them). */
+GRPG_API int grpg_visible_filter(int P, int M, int width, int height,
+                        const float* means3D, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix,
+                        float tan_fovx, float tan_fovy, int prefiltered,
+                        int* radii, float* means2D, int debug, void* hip_stream);
+
+/*
+ * Debug / parity accessor (no reference counterpart; SURVEY.md §8(b) "Ownership"): decodes the
+ * private blobs of the last grpg_forward into the reference's own intermediate arrays so tests
+ * can check them bit-exactly.  Any output pointer may be NULL.  All outputs are DEVICE pointers.
+ *   keys_sorted[R]  u64  (tile << 32 | depth bits)   == BinningState::point_list_keys
+ *   point_list[R]   u32                              == BinningState::point_list
+ *   ranges[T,2]     u32                              == ImageState::ranges (first T entries)
+ *   n_contrib[H*W]  u32                              == ImageState::n_contrib
+ *   means2D[P,2] depths[P] conic_opacity[P,4] rgb[P,3] tiles_touched[P]  == GeometryState fields
+ *     (entries of culled Gaussians are written as 0)
+ */
+GRPG_API int grpg_debug_export(int P, int R, int width, int height,
+                      const char* geom_buffer, const char* binning_buffer,
+                      const char* image_buffer,
+                      uint64_t* keys_sorted, uint32_t* point_list, uint32_t* ranges,
+                      uint32_t* n_contrib, float* means2D, float* depths, float* conic_opacity,
+                      float* rgb, uint32_t* tiles_touched, void* hip_stream);
+
+/*
+ * Per-stage device timing of the most recent grpg_forward on this thread, measured with HIP
+ * events on the op's stream when enabled.  stage_ms must hold GRPG_NUM_STAGES floats.
+ * Stages: 0 preprocess, 1 depth sort, 2 offsets scan, 3 instance emit, 4 tile sort,
+ * 5 tile ranges, 6 render, 7 semantic render.  Returns GRPG_OK, or GRPG_ERR_INVALID_ARGUMENT
+ * if timing was not enabled for that call.
+ */
+#define GRPG_NUM_STAGES 8
+GRPG_API int grpg_set_stage_timing(int enabled);
+GRPG_API int grpg_get_stage_timing(float* stage_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRPG_RASTERIZER_H_INCLUDED */

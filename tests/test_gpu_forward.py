@@ -1,0 +1,256 @@
+"""GPU parity tests (-m gpu): HIP path, called through the drop-in Python API -> _C -> C ABI,
+against the oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): radii / num_rendered / sorted keys / point list / tile ranges
+bit-exact; RGB / depth / alpha / semantic within 1e-4 (abs + rel) on every pixel the oracle does
+not flag threshold-fragile; n_contrib exact on those pixels.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gaussianrpg_amd import harness as hz
+from helpers import (assert_image_close, fixture_oracle_inputs, load_fixture, oracle_kwargs)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _rasterize(dev, sc, cam, bg=None, semantics=None, colors_precomp=None, cov3D_precomp=None,
+               scale_modifier=1.0, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianrpg_amd.rasterizer import _C, debug_export
+    camd = hz.CameraTensors(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy,
+                            cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.campos.to(dev))
+    bgd = torch.zeros(3, device=dev) if bg is None else torch.as_tensor(bg, dtype=torch.float32).to(dev)
+    kw = hz.settings_kwargs(camd, sc.sh_degree, bg=bgd, scale_modifier=scale_modifier, debug=debug)
+    rs = GaussianRasterizationSettings(**kw)
+    d = sc.to(dev)
+    P = d.means3D.shape[0]
+    e = torch.Tensor([])
+    sem = torch.zeros(P, 0, device=dev) if semantics is None else semantics.to(dev)
+    use_cov = cov3D_precomp is not None
+    args = (rs.bg, d.means3D, e if colors_precomp is None else colors_precomp.to(dev), sem,
+            d.opacity, e if use_cov else d.scales, e if use_cov else d.rotations, rs.scale_modifier,
+            cov3D_precomp.to(dev) if use_cov else e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, rs.image_height, rs.image_width, d.shs if colors_precomp is None else e,
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+    R, color, depth, alpha, semantic, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+    dbg = debug_export(geom, binning, img, P, R, rs.image_height, rs.image_width)
+    torch.cuda.synchronize()
+    # and the same call through the nn.Module front end must agree exactly
+    out2 = GaussianRasterizer(rs)(
+        means3D=d.means3D, means2D=None, opacities=d.opacity,
+        shs=d.shs if colors_precomp is None else None,
+        colors_precomp=None if colors_precomp is None else colors_precomp.to(dev),
+        scales=None if use_cov else d.scales, rotations=None if use_cov else d.rotations,
+        cov3D_precomp=cov3D_precomp.to(dev) if use_cov else None,
+        semantics=None if semantics is None else semantics.to(dev))
+    assert torch.equal(out2[0], color) and torch.equal(out2[1], radii)
+    return dict(R=R, color=color.cpu().numpy(), depth=depth.cpu().numpy(), alpha=alpha.cpu().numpy(),
+                semantic=semantic.cpu().numpy(), radii=radii.cpu().numpy(),
+                **{k: v.cpu().numpy() for k, v in dbg.items()})
+
+
+def _check(got, o, max_fragile_frac=0.1):
+    assert got["R"] == o["num_rendered"]
+    np.testing.assert_array_equal(got["radii"], o["radii"])
+    np.testing.assert_array_equal(got["tiles_touched"].view(np.uint32), o["tiles_touched"])
+    np.testing.assert_array_equal(got["keys_sorted"].view(np.uint64), o["keys_sorted"])
+    np.testing.assert_array_equal(got["point_list"].view(np.uint32), o["point_list"])
+    np.testing.assert_array_equal(got["ranges"].view(np.uint32), o["ranges"])
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(got["means2D"][vis], o["means2D"][vis])
+    np.testing.assert_array_equal(got["depths"][vis], o["depths"][vis])
+    np.testing.assert_array_equal(got["conic_opacity"][vis], o["conic_opacity"][vis])
+    np.testing.assert_array_equal(got["rgb"][vis], o["features"][vis])
+    frag = o["fragile"]
+    for k in ("color", "depth", "alpha", "semantic"):
+        if o[k].size:
+            assert_image_close(k, got[k], o[k], frag, max_fragile_frac=max_fragile_frac)
+    nf = frag == 0
+    np.testing.assert_array_equal(got["n_contrib"].view(np.uint32)[nf], o["n_contrib"][nf])
+
+
+CASES = {
+    "toy_deg1": lambda: (hz.toy_scene(3000, seed=4, sh_degree=1), hz.trajectory_camera(0, W=200, H=136)),
+    "toy_deg3_odd_size": lambda: (hz.toy_scene(2500, seed=7, sh_degree=3), hz.trajectory_camera(0, W=203, H=121)),
+    "toy_deg0": lambda: (hz.toy_scene(1500, seed=9, sh_degree=0), hz.trajectory_camera(0, W=64, H=48)),
+    "toy_deg2": lambda: (hz.toy_scene(1500, seed=10, sh_degree=2), hz.trajectory_camera(0, W=96, H=96)),
+    "smoke_overdraw": lambda: (hz.smoke_scene(1500, seed=3), hz.smoke_camera(128, 96)),
+    "street_20k": lambda: (hz.street_scene(20000, seed=3), hz.trajectory_camera(3, W=480, H=320)),
+    "street_200k": lambda: (hz.street_scene(200000, seed=8), hz.trajectory_camera(10, W=960, H=640)),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward_matches_oracle(dev, case):
+    sc, cam = CASES[case]()
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, sc.sh_degree, bg=bg))
+    got = _rasterize(dev, sc, cam, bg=bg)
+    _check(got, o, max_fragile_frac=0.2 if case == "smoke_overdraw" else 0.05)
+
+
+@pytest.mark.parametrize("name", ["toy_deg1", "toy_deg3_sem", "smoke_deg0", "street_small"])
+def test_forward_matches_committed_golden(dev, name):
+    fx = load_fixture(name)
+    S = fx["semantics"].shape[1]
+    sc = hz.Scene(torch.tensor(fx["means3D"]), torch.tensor(fx["opacity"]), torch.tensor(fx["scales"]),
+                  torch.tensor(fx["rotations"]), torch.tensor(fx["shs"]), int(fx["sh_degree"]))
+    cam = hz.CameraTensors(int(fx["H"]), int(fx["W"]), float(fx["tanfovx"]), float(fx["tanfovy"]),
+                           torch.tensor(fx["viewmatrix"]), torch.tensor(fx["projmatrix"]),
+                           torch.tensor(fx["campos"]))
+    got = _rasterize(dev, sc, cam, bg=fx["bg"], semantics=torch.tensor(fx["semantics"]) if S else None)
+    assert got["R"] == int(fx["num_rendered"])
+    for k in ("radii", "point_list", "ranges", "keys_sorted"):
+        np.testing.assert_array_equal(got[k].astype(np.int64), fx[k].astype(np.int64), err_msg=k)
+    for k in ("color", "depth", "alpha", "semantic"):
+        if fx[k].size:
+            assert_image_close(k, got[k], fx[k], fx["fragile"])
+
+
+@pytest.mark.parametrize("S", [3, 15])
+def test_semantic_channels(dev, S):
+    # script/test_gaussian_rasterization.py:73-87 runs S=15
+    sc, cam = hz.toy_scene(2000, seed=12, sh_degree=1), hz.trajectory_camera(0, W=160, H=96)
+    sem = torch.rand(2000, S, generator=torch.Generator().manual_seed(S))
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       semantics=sem, **oracle_kwargs(cam, sc.sh_degree))
+    got = _rasterize(dev, sc, cam, semantics=sem)
+    assert got["semantic"].shape == (S, 96, 160)
+    _check(got, o)
+
+
+def test_colors_precomp_and_cov3d_precomp(dev):
+    sc, cam = hz.toy_scene(2000, seed=13, sh_degree=1), hz.trajectory_camera(0, W=160, H=96)
+    g = torch.Generator().manual_seed(2)
+    colors = torch.rand(2000, 3, generator=g)
+    o0 = oracle.forward(sc.means3D, sc.opacity, colors_precomp=colors, scales=sc.scales,
+                        rotations=sc.rotations, **oracle_kwargs(cam, 0))
+    cov = torch.tensor(o0["cov3D"])       # reference layout [xx,xy,xz,yy,yz,zz]
+    o = oracle.forward(sc.means3D, sc.opacity, colors_precomp=colors, cov3D_precomp=cov,
+                       **oracle_kwargs(cam, 0))
+    got = _rasterize(dev, sc, cam, colors_precomp=colors, cov3D_precomp=cov)
+    _check(got, o)
+    np.testing.assert_array_equal(o["radii"], o0["radii"])
+
+
+def test_scale_modifier_and_white_bg(dev):
+    sc, cam = hz.toy_scene(1500, seed=14, sh_degree=1), hz.trajectory_camera(0, W=128, H=80)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, 1, bg=torch.ones(3), scale_modifier=0.6))
+    got = _rasterize(dev, sc, cam, bg=[1.0, 1.0, 1.0], scale_modifier=0.6)
+    _check(got, o)
+
+
+def test_degenerate_inputs(dev):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = hz.trajectory_camera(0, W=70, H=50, device=dev)
+    bg = torch.tensor([0.5, 0.25, 0.125], device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 0, bg=bg)))
+    # P == 0: zero outputs (black, NOT background), rasterize_points.cu:85-86,123
+    z = torch.zeros
+    c, r, d, a, s = rast(means3D=z(0, 3, device=dev), means2D=None, opacities=z(0, 1, device=dev),
+                         colors_precomp=z(0, 3, device=dev), scales=z(0, 3, device=dev),
+                         rotations=z(0, 4, device=dev))
+    assert float(c.abs().max()) == 0.0 and r.numel() == 0 and float(a.abs().max()) == 0.0
+    # nothing visible: behind the camera / too close -> colour == bg, alpha = depth = 0
+    m = torch.tensor([[0, 0, -5.0], [0.1, 0.1, 0.1]], device=dev)
+    c, r, d, a, s = rast(means3D=m, means2D=None, opacities=torch.ones(2, 1, device=dev),
+                         colors_precomp=torch.ones(2, 3, device=dev),
+                         scales=torch.full((2, 3), 0.1, device=dev),
+                         rotations=torch.tensor([[1.0, 0, 0, 0]] * 2, device=dev))
+    assert int(r.abs().max()) == 0 and float(a.max()) == 0.0 and float(d.max()) == 0.0
+    assert torch.allclose(c[:, 7, 9], bg)
+    # shape error message of the reference (rasterize_points.cu:58-60)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        rast(means3D=z(4, 2, device=dev), means2D=None, opacities=z(4, 1, device=dev),
+             colors_precomp=z(4, 3, device=dev), scales=z(4, 3, device=dev), rotations=z(4, 4, device=dev))
+
+
+def test_giant_splat_and_single_tile(dev):
+    """A splat covering every tile (cooperative emit path) and an image smaller than one tile."""
+    g = torch.Generator().manual_seed(5)
+    sc = hz.toy_scene(800, seed=15, sh_degree=1)
+    big = hz.Scene(torch.cat([torch.tensor([[0.0, 0.0, 1.0], [0.3, -0.2, 0.6]]), sc.means3D]),
+                   torch.cat([torch.tensor([[0.3], [0.05]]), sc.opacity]),
+                   torch.cat([torch.tensor([[3.0, 2.0, 0.5], [5.0, 5.0, 5.0]]), sc.scales]),
+                   torch.cat([torch.tensor([[1.0, 0, 0, 0], [0.9, 0.1, 0.3, 0.2]]), sc.rotations]),
+                   torch.cat([torch.rand(2, 4, 3, generator=g), sc.shs]), 1)
+    cam = hz.trajectory_camera(0, W=400, H=240)
+    o = oracle.forward(big.means3D, big.opacity, shs=big.shs, scales=big.scales,
+                       rotations=big.rotations, **oracle_kwargs(cam, 1))
+    assert o["tiles_touched"].max() == 25 * 15
+    _check(_rasterize(dev, big, cam), o)
+    cam1 = hz.trajectory_camera(0, W=12, H=9)
+    o1 = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                        **oracle_kwargs(cam1, 1))
+    _check(_rasterize(dev, sc, cam1), o1, max_fragile_frac=0.5)
+
+
+def test_equal_depth_ties_keep_id_order(dev):
+    """Duplicated Gaussians have identical depth keys: order must be ascending id (stable sort)."""
+    sc = hz.toy_scene(500, seed=16, sh_degree=1)
+    dup = hz.Scene(*(torch.cat([t, t, t]) for t in sc[:5]), 1)
+    cam = hz.trajectory_camera(0, W=96, H=64)
+    o = oracle.forward(dup.means3D, dup.opacity, shs=dup.shs, scales=dup.scales,
+                       rotations=dup.rotations, **oracle_kwargs(cam, 1))
+    _check(_rasterize(dev, dup, cam), o, max_fragile_frac=0.2)
+
+
+def test_mark_visible_and_filter(dev):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc, cam = hz.street_scene(30000, seed=21), hz.trajectory_camera(4, W=480, H=320)
+    camd = hz.trajectory_camera(4, W=480, H=320, device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 1)))
+    d = sc.to(dev)
+    vis = rast.markVisible(d.means3D)
+    np.testing.assert_array_equal(vis.cpu().numpy(), oracle.mark_visible(sc.means3D, cam.viewmatrix, cam.projmatrix))
+    radii, m2d = rast.visible_filter(d.means3D, d.scales, d.rotations)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       render=False, **oracle_kwargs(cam, 1))
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    np.testing.assert_array_equal(m2d.cpu().numpy(), o["means2D"])
+
+
+def test_debug_mode_and_noncontiguous_inputs(dev):
+    sc, cam = hz.toy_scene(1200, seed=17, sh_degree=1), hz.trajectory_camera(0, W=96, H=64)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, 1))
+    # non-contiguous means3D view (the reference calls .contiguous() on every input)
+    wide = torch.zeros(1200, 6)
+    wide[:, ::2] = sc.means3D
+    sc2 = hz.Scene(wide[:, ::2], sc.opacity, sc.scales, sc.rotations, sc.shs, 1)
+    assert not sc2.means3D.is_contiguous()
+    _check(_rasterize(dev, sc2, cam, debug=True), o)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 size (1920x1280, P=1M): size-independent invariants + exact integer
+    parity with the oracle's preprocess/binning (the oracle's blend is checked on a crop-sized
+    scene elsewhere; here the blend is checked through conservation laws)."""
+    sc, cam = hz.street_scene(1_000_000, seed=149), hz.trajectory_camera(0)
+    got = _rasterize(dev, sc, cam, bg=[0.0, 0.0, 0.0])
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       render=False, **oracle_kwargs(cam, 1))
+    assert got["R"] == o["num_rendered"] == int(o["tiles_touched"].sum())
+    np.testing.assert_array_equal(got["radii"], o["radii"])
+    np.testing.assert_array_equal(got["keys_sorted"].view(np.uint64), o["keys_sorted"])
+    np.testing.assert_array_equal(got["point_list"].view(np.uint32), o["point_list"])
+    np.testing.assert_array_equal(got["ranges"].view(np.uint32), o["ranges"])
+    keys = got["keys_sorted"].view(np.uint64)
+    assert (keys[1:] >= keys[:-1]).all()                       # sortedness
+    rg = got["ranges"].view(np.uint32).astype(np.int64)
+    assert ((rg[:, 1] - rg[:, 0]).sum()) == got["R"]           # ranges partition the list
+    a = got["alpha"]
+    assert a.min() >= 0.0 and a.max() <= 1.0 + 1e-5            # alpha = 1 - T in [0,1]
+    assert (got["n_contrib"].reshape(-1) <= np.repeat((rg[:, 1] - rg[:, 0]).reshape(80, 120), 16, 0).repeat(16, 1).reshape(-1)).all()
+    assert np.isfinite(got["color"]).all() and np.isfinite(got["depth"]).all()
