@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""Headline benchmark of the hot path: frames/s of the rasterizer forward at 1920x1280 on a
+~2 M-Gaussian street scene (BASELINE.json `metric`, configs[2]), 1..8 MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: one call of the drop-in operator (GaussianRasterizer -> _C -> C ABI -> HIP)
+on synthetic inputs already resident in HBM, followed by the eval-mode clamp + uint8 pack of the
+trajectory mode.  With N GPUs the frames of the synthetic 200-pose drive are sharded round-robin
+(frame i -> rank i mod N, gaussianrpg_amd/trajectory.py), every rank renders K frames (weak
+scaling) and the ONLY collective is the final RCCL gather of the uint8 frames to rank 0, inside
+the timed region.  Rank 0 prints one JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel (render_forward_kernel): algorithmic bytes per launch
+                (44*R + 8*T + 20*N, SURVEY.md §8(d) / DESIGN.md §6) / its average duration measured
+                with HIP events on the op's own stream during the timed region, vs 8 TB/s.
+  frame_roofline  whole-frame B_alg / ms_per_step (the figure BASELINE.json asks for).
+  stages_ms     per-stage average device time from the same HIP events.
+  cpu_baseline  pure-PyTorch CPU splat (oracle/torch_splat.py) timed on the host cores on a
+                bounded sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from gaussianrpg_amd import harness as hz  # noqa: E402
+from gaussianrpg_amd import trajectory as tj  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+NUM_FRAMES = 200               # poses of the synthetic drive (BASELINE config 4)
+P_GAUSS = 2_000_000            # "Waymo scene 002 full Street-Gaussians (~2M)" stand-in
+SCENE_SEED = 2
+W, H = hz.WAYMO_W, hz.WAYMO_H
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=P_GAUSS, help="override P (debugging only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def effective_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's cores even inside a quota-limited container, and an
+    over-subscribed OpenMP pool makes small torch ops hundreds of times slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def _cpu_baseline_worker(threads):
+    """Runs in a child process (hard wall-clock limit enforced by the parent): pure-PyTorch CPU
+    splat on every 2nd Gaussian of the bench scene at 960x640.  Prints one JSON line."""
+    from oracle import torch_splat as ts
+    torch.set_num_threads(threads)
+    scene = hz.street_scene(P_GAUSS, seed=SCENE_SEED, sh_degree=1)
+    sub = hz.Scene(*(t[::2].contiguous() if isinstance(t, torch.Tensor) else t for t in scene))
+    cam = hz.trajectory_camera(0, W=960, H=640)
+    kw = hz.settings_kwargs(cam, scene.sh_degree)
+    kw.pop("prefiltered"), kw.pop("debug")
+    with torch.no_grad():
+        t0 = time.time()
+        r = ts.rasterize(sub.means3D, sub.opacity, shs=sub.shs, scales=sub.scales,
+                         rotations=sub.rotations, **kw)
+        dt = time.time() - t0
+    print(json.dumps({"seconds": dt, "R_sample": int(r["num_rendered"]),
+                      "P_sample": int(sub.means3D.shape[0]), "threads": torch.get_num_threads()}))
+
+
+def cpu_baseline(R_full, limit_s=240):
+    """cpu_baseline leg (rank 0, N=1): the oracle's pure-PyTorch CPU splat, timed on the host
+    cores on a bounded sample of the same workload, scaled to whole frames of the full workload
+    by the ratio of tile instances (the blend's work is proportional to R)."""
+    import subprocess
+    cores = effective_cores()
+    threads = min(cores, 32)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+                            str(threads)], capture_output=True, text=True, timeout=limit_s)
+        res = json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": "cpu baseline did not finish within %d s: %r" % (limit_s, exc)}
+    dt, R_s = res["seconds"], max(res["R_sample"], 1)
+    est = (1.0 / dt) * (R_s / max(R_full, 1))
+    return {"value": est, "unit": "frames/s", "cores": res["threads"], "kind": "port",
+            "host_cpu_count": os.cpu_count(), "usable_cores": cores,
+            "sample": "oracle/torch_splat.py (pure-PyTorch CPU splat), frame 0, every 2nd Gaussian "
+                      "(P=%d) at 960x640: %.2f s for R=%d tile instances on %d threads; value = 1/t "
+                      "scaled by R_sample/R_full (R_full=%d) to whole 1920x1280 frames" % (
+                          res["P_sample"], dt, R_s, res["threads"], R_full),
+            "sample_seconds": dt}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        _cpu_baseline_worker(args.cpu_baseline_worker)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs ROCm devices (no CPU fallback exists)"
+    torch.set_num_threads(max(1, min(effective_cores() // max(world, 1), 16)))   # host-side scene synthesis
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank,
+                                device_id=dev)
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianrpg_amd.rasterizer import _C
+
+    scene_cpu = hz.street_scene(args.gaussians, seed=SCENE_SEED, sh_degree=1)
+    sc = scene_cpu.to(dev)
+    P = sc.means3D.shape[0]
+    M = sc.shs.shape[1]
+    bg = torch.zeros(3, device=dev)
+    tape = tj.make_tape(NUM_FRAMES)
+    rasterizers = []
+    for e in tape:
+        cam = tj.camera_from_tape(e, W=W, H=H, device=dev)
+        rasterizers.append(GaussianRasterizer(GaussianRasterizationSettings(
+            **hz.settings_kwargs(cam, sc.sh_degree, bg=bg))))
+
+    def render_frame(i):
+        # argument pattern of render_kernel in eval mode (street_gaussian_renderer.py:224-237)
+        color, radii, depth, alpha, sem = rasterizers[i % NUM_FRAMES](
+            means3D=sc.means3D, means2D=None, opacities=sc.opacity, shs=sc.shs, scales=sc.scales,
+            rotations=sc.rotations, cov3D_precomp=None, semantics=None)
+        return color
+
+    K, Wm = args.steps, args.warmup
+    frames_of = lambda s: (s * world + rank)          # noqa: E731  round-robin frame ownership
+    local = torch.empty((K, 3, H, W), dtype=torch.uint8, device=dev)
+
+    with torch.no_grad():
+        for s in range(Wm):
+            tj.pack_u8(render_frame(frames_of(s)))
+        gather_bufs = None
+        if world > 1:
+            import torch.distributed as dist
+            if rank == 0:
+                gather_bufs = [torch.empty_like(local) for _ in range(world)]
+            # warm the communicator outside the timed region
+            tiny = torch.zeros(1, device=dev)
+            dist.all_reduce(tiny)
+        torch.cuda.synchronize()
+
+        stage_timing = not args.no_stage_timing
+        _C.set_stage_timing(stage_timing)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(K):
+            local[s] = tj.pack_u8(render_frame(frames_of(s)))
+        if world > 1:
+            dist.gather(local, gather_list=gather_bufs, dst=0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        stage_sum, ncalls = _C.stage_timing() if stage_timing else ([0.0] * 8, 0)
+        _C.set_stage_timing(False)
+
+        elapsed = t1 - t0
+        if world > 1:
+            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+
+        # untimed statistics pass: V and R of the frames this rank rendered
+        Vs, Rs = [], []
+        e = torch.Tensor([])
+        sem0 = torch.zeros(P, 0, device=dev)
+        for s in range(min(K, 50)):
+            rs = rasterizers[frames_of(s) % NUM_FRAMES].raster_settings
+            out = _C.rasterize_gaussians(rs.bg, sc.means3D, e, sem0, sc.opacity, sc.scales,
+                                         sc.rotations, rs.scale_modifier, e, rs.viewmatrix,
+                                         rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                         rs.image_width, sc.shs, rs.sh_degree, rs.campos, False, False)
+            Rs.append(int(out[0]))
+            Vs.append(int((out[5] > 0).sum()))
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        N = W * H
+        R_avg = sum(Rs) / len(Rs)
+        V_avg = sum(Vs) / len(Vs)
+        fps = world * K / elapsed
+        ms_per_step = 1000.0 * elapsed / K
+        names = ["preprocess", "depth_sort", "offsets_scan_and_readback", "emit", "tile_sort",
+                 "tile_ranges", "render", "semantic_render"]
+        stages = {n: (stage_sum[i] / ncalls if ncalls else None) for i, n in enumerate(names)}
+        render_ms = stages["render"]
+        b_render = 44.0 * R_avg + 8.0 * T_tiles + 20.0 * N
+        b_frame = P * (48 + 12 * M) + 40.0 * V_avg + 88.0 * R_avg + 16.0 * T_tiles + 20.0 * N
+        roof = None
+        if render_ms:
+            ach = b_render / (render_ms * 1e-3) / 1e9
+            roof = {"kernel": "render_forward_kernel", "bound": "hbm", "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": b_render,
+                    "avg_launch_ms": render_ms,
+                    "note": "render is VALU-bound (about 25 flop per pixel-splat pair), see DESIGN.md §6"}
+        ach_f = b_frame / (ms_per_step * 1e-3) / 1e9
+        line = {
+            "metric": "frames/sec @1920x1280, ~2M Gaussians; achieved HBM GB/s vs peak",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: scene-002-like synthetic street scene (seed %d), "
+                                   "forward op + clamp + uint8 pack per frame, %d-pose drive, "
+                                   "frames sharded round-robin over ranks" % (SCENE_SEED, NUM_FRAMES),
+                       "P": P, "V_avg": V_avg, "R_avg": R_avg, "T": T_tiles, "width": W,
+                       "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
+                       "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
+            "roofline": roof,
+            "frame_roofline": {"bound": "hbm", "achieved": ach_f, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": ach_f / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_frame": b_frame},
+            "stages_ms": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(int(R_avg))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/grpg_rasterizer.h"
 #include "common.h"
@@ -23,8 +24,6 @@ namespace {
 
 thread_local std::string g_last_error;
 thread_local bool g_timing_enabled = false;
-thread_local bool g_timing_valid = false;
-thread_local float g_stage_ms[GRPG_NUM_STAGES];
 thread_local uint32_t* g_pinned_u32 = nullptr;
 
 int fail(int code, const std::string& msg) {
@@ -63,34 +62,37 @@ int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit 
   return b;
 }
 
+// Per-stage device timing with HIP events recorded on the op's stream.  Nothing is synchronised
+// while frames are in flight: every grpg_forward appends one record of events to a thread-local
+// list; grpg_get_stage_timing() waits for them, sums per stage and clears the list.
+struct TimingRecord {
+  hipEvent_t ev[GRPG_NUM_STAGES + 1];
+  int stage_of[GRPG_NUM_STAGES + 1];
+  int n = 0;
+};
+thread_local std::vector<TimingRecord*> g_pending;
+thread_local std::vector<TimingRecord*> g_free;
+
 struct StageTimer {
   hipStream_t s;
-  bool on;
-  hipEvent_t ev[GRPG_NUM_STAGES + 1];
-  int n = 0;
-  int stage_of[GRPG_NUM_STAGES + 1];
-  StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
-    if (on) for (auto& e : ev) (void)hipEventCreate(&e);
+  TimingRecord* r = nullptr;
+  StageTimer(hipStream_t s_, bool on) : s(s_) {
+    if (!on) return;
+    if (!g_free.empty()) { r = g_free.back(); g_free.pop_back(); }
+    else { r = new TimingRecord(); for (auto& e : r->ev) (void)hipEventCreate(&e); }
+    r->n = 0;
   }
   void mark(int next_stage) {
-    if (!on || n > GRPG_NUM_STAGES) return;
-    (void)hipEventRecord(ev[n], s);
-    stage_of[n] = next_stage;
-    n++;
+    if (!r || r->n > GRPG_NUM_STAGES) return;
+    (void)hipEventRecord(r->ev[r->n], s);
+    r->stage_of[r->n] = next_stage;
+    r->n++;
   }
   void finish() {
-    if (!on) return;
-    (void)hipEventSynchronize(ev[n - 1]);
-    for (int i = 0; i < GRPG_NUM_STAGES; i++) g_stage_ms[i] = 0.f;
-    for (int i = 0; i + 1 < n; i++) {
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-      if (stage_of[i] >= 0 && stage_of[i] < GRPG_NUM_STAGES) g_stage_ms[stage_of[i]] += ms;
-    }
-    g_timing_valid = true;
+    if (r) { g_pending.push_back(r); r = nullptr; }
   }
   ~StageTimer() {
-    if (on) for (auto& e : ev) (void)hipEventDestroy(e);
+    if (r) g_free.push_back(r);   // call failed before finish(): recycle
   }
 };
 
@@ -116,12 +118,27 @@ const char* grpg_last_error(void) { return g_last_error.c_str(); }
 
 int grpg_set_stage_timing(int enabled) {
   g_timing_enabled = enabled != 0;
-  g_timing_valid = false;
+  for (auto* r : g_pending) g_free.push_back(r);
+  g_pending.clear();
   return GRPG_OK;
 }
-int grpg_get_stage_timing(float* stage_ms) {
-  if (!stage_ms || !g_timing_valid) return fail(GRPG_ERR_INVALID_ARGUMENT, "stage timing not available");
-  std::memcpy(stage_ms, g_stage_ms, sizeof(g_stage_ms));
+int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls) {
+  if (!stage_ms_sum || !num_calls) return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL output");
+  for (int i = 0; i < GRPG_NUM_STAGES; i++) stage_ms_sum[i] = 0.f;
+  *num_calls = 0;
+  for (auto* r : g_pending) {
+    if (r->n < 2) { g_free.push_back(r); continue; }
+    hipError_t e = hipEventSynchronize(r->ev[r->n - 1]);
+    if (e != hipSuccess) return fail(GRPG_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    for (int i = 0; i + 1 < r->n; i++) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, r->ev[i], r->ev[i + 1]);
+      if (r->stage_of[i] >= 0 && r->stage_of[i] < GRPG_NUM_STAGES) stage_ms_sum[r->stage_of[i]] += ms;
+    }
+    (*num_calls)++;
+    g_free.push_back(r);
+  }
+  g_pending.clear();
   return GRPG_OK;
 }
 
@@ -189,7 +206,6 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   HIP_TRY(hipMemcpyAsync(img, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
 
   StageTimer tm(stream, g_timing_enabled);
-  g_timing_valid = false;
   uint32_t R = 0;
 
   if (P > 0) {

@@ -280,11 +280,12 @@ DebugExport(const torch::Tensor& geomBuffer, const torch::Tensor& binningBuffer,
   return std::make_tuple(keys, plist, ranges, ncontrib, means2D, depths, conic, rgb, tiles);
 }
 
-std::vector<float> StageTiming() {
+std::tuple<std::vector<float>, int> StageTiming() {
   std::vector<float> ms(GRPG_NUM_STAGES, 0.f);
-  const int rc = grpg_get_stage_timing(ms.data());
+  int calls = 0;
+  const int rc = grpg_get_stage_timing(ms.data(), &calls);
   if (rc != GRPG_OK) raise_abi_error("grpg_get_stage_timing", rc);
-  return ms;
+  return std::make_tuple(ms, calls);
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {

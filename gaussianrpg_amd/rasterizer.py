@@ -91,9 +91,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             grads = _C.rasterize_gaussians_backward(*call)
         (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations,
          g_semantics) = grads
-        # one gradient per forward input, in forward-argument order (reference :152-163)
-        return (g_means3D, g_means2D, g_sh, g_colors, g_semantics, g_opacities, g_scales,
-                g_rotations, g_cov3D, None)
+        # one gradient per forward input, in forward-argument order (reference :152-163).
+        # Inputs that are not tensors requiring grad (means2D=None in eval mode, the empty
+        # placeholders of absent optionals) get None: the reference returns a tensor there and
+        # autograd rejects it ("...the corresponding forward input was not a Variable").
+        grads = (g_means3D, g_means2D, g_sh, g_colors, g_semantics, g_opacities, g_scales,
+                 g_rotations, g_cov3D)
+        return tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad)) + (None,)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opacities, scales,

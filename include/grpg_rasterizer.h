@@ -152,15 +152,18 @@ GRPG_API int grpg_debug_export(int P, int R, int width, int height,
                       float* rgb, uint32_t* tiles_touched, void* hip_stream);
 
 /*
- * Per-stage device timing of the most recent grpg_forward on this thread, measured with HIP
- * events on the op's stream when enabled.  stage_ms must hold GRPG_NUM_STAGES floats.
- * Stages: 0 preprocess, 1 depth sort, 2 offsets scan, 3 instance emit, 4 tile sort,
- * 5 tile ranges, 6 render, 7 semantic render.  Returns GRPG_OK, or GRPG_ERR_INVALID_ARGUMENT
- * if timing was not enabled for that call.
+ * Per-stage device timing, measured with HIP events recorded on the op's own stream (so it sees
+ * the real kernel durations whatever stream torch calls "current").  While enabled, every
+ * grpg_forward on this thread records GRPG_NUM_STAGES+1 events and returns without waiting;
+ * grpg_get_stage_timing() waits for the recorded calls, writes the per-stage SUM of milliseconds
+ * over those calls into stage_ms_sum[GRPG_NUM_STAGES] and their count into *num_calls, then
+ * forgets them.  Stages: 0 preprocess, 1 depth sort, 2 offsets scan (+ the num_rendered read-back
+ * and binning-blob allocation), 3 instance emit, 4 tile sort, 5 tile ranges, 6 render,
+ * 7 semantic render.
  */
 #define GRPG_NUM_STAGES 8
 GRPG_API int grpg_set_stage_timing(int enabled);
-GRPG_API int grpg_get_stage_timing(float* stage_ms);
+GRPG_API int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls);
 
 #ifdef __cplusplus
 }
