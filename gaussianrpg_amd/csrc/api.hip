@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,16 @@ int ensure_device() {
     return fail(GRPG_ERR_NO_DEVICE,
                 "no usable HIP device (libgrpg_rasterizer has no CPU fallback by design)");
   return GRPG_OK;
+}
+
+// Tiles whose list holds at least this many splats are rendered as four 16x4 sub-tiles
+// (render_fwd.hip).  Tunable for experiments through GRPG_HEAVY_MIN.
+uint32_t heavy_tile_min() {
+  static const uint32_t v = [] {
+    const char* e = getenv("GRPG_HEAVY_MIN");
+    return e ? (uint32_t)strtoul(e, nullptr, 10) : 1024u;
+  }();
+  return v;
 }
 
 int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit in b bits
@@ -267,7 +278,8 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     STAGE_CHECK("tile ranges");
     tm.mark(6);
     launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
-                          out_color, out_depth, out_alpha, n_contrib);
+                          out_color, out_depth, out_alpha, n_contrib,
+                          (uint32_t*)(img + IL.work), heavy_tile_min());
     STAGE_CHECK("render");
     tm.mark(7);
     if (S > 0) {

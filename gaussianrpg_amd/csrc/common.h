@@ -61,7 +61,7 @@ struct BinLayout {
 };
 struct ImgLayout {
   size_t total;
-  size_t ranges, n_contrib;
+  size_t ranges, n_contrib, work;
 };
 
 inline GeomLayout geom_layout(size_t P) {
@@ -104,6 +104,7 @@ inline ImgLayout img_layout(size_t T, size_t N) {
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   L.ranges = take(T * 8);
   L.n_contrib = take(N * 4);
+  L.work = take((2 + 2 * T) * 4);   // render work lists: counts[2], heavy[T], light[T]
   L.total = o;
   return L;
 }
@@ -151,7 +152,8 @@ void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, ui
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const float4* rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
-                           uint32_t* n_contrib);
+                           uint32_t* n_contrib, uint32_t* work /* [2 + 2T] u32 scratch */,
+                           uint32_t heavy_min);
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const float4* rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, float* out_semantic);

@@ -13,6 +13,7 @@
 // 256x fewer atomics than the reference.  Summation order differs from the reference's
 // (unspecified) atomic order, so gradients agree to rounding, not bitwise -- exactly as two runs of
 // the reference differ from each other.
+#include "blend_math.h"
 #include "common.h"
 
 namespace grpg {
@@ -124,6 +125,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
       const uint32_t gid = myid[j];
       const uint32_t pos = lo + (uint32_t)j;   // 0-based position == reference's `contributor`
       const float dx = a.x - pxf;
+      const SplatTerms st = splat_terms(dx, b.x, b.y, b.z);
       float g_mx = 0.f, g_my = 0.f, g_mabs = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f;
       float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
       float g_s[SM];
@@ -133,10 +135,8 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const float dy = a.y - (float)(py0 + k);
-        const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(0.99f, a.w * G);
-        const bool valid = (pos < lastc[k]) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        float G, alpha;   // identical arithmetic to the forward (blend_math.h)
+        const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]);
         if (valid) {
           any = true;
           T[k] = T[k] / (1.f - alpha);

@@ -7,91 +7,160 @@
 //   out_color = C + T bg, out_alpha = W, out_depth = D, n_contrib = index of last blended splat.
 //
 // CDNA4 mapping (NOT the reference's 256-thread / one-pixel-per-thread / LDS-broadcast layout):
-//   * one wave64 owns one 16x16 tile, 4 vertically adjacent pixels per lane.  Broadcasting a
-//     splat's 40 bytes from LDS costs the same ~10 LDS cycles per wave whether a lane shades 1
-//     pixel or 4, so 4 px/lane cuts LDS traffic per pixel-pair 4x, shares dx and the
-//     a*dx^2 / b*dx terms across the 4 pixels, and gives 4 independent exp chains per lane.
-//   * no __syncthreads anywhere: a workgroup is 4 independent waves (4 tiles); each wave stages
-//     batches of 64 splat records (one coalesced-ish 48-byte gather per lane) into its private
-//     3 KB LDS slice and then walks them with uniform (broadcast) ds_read_b128.
-//   * wave-uniform early exit via ballot when all 256 pixels of the tile are saturated.
-// The kernel is VALU-bound (about 20 flop-equivalents per pixel-splat pair), not HBM-bound;
-// its compulsory HBM traffic is 4 B (id) + 48 B (record) per tile instance + 24 B per pixel.
+//   * A wave64 is the unit of work and never synchronises with another wave (no __syncthreads).
+//     LIGHT tiles (short lists): one wave owns the whole 16x16 tile, 4 vertically adjacent pixels
+//     per lane -- a splat's 48-byte record is broadcast from LDS once per wave whether a lane
+//     shades 1 pixel or 4, so LDS traffic per pixel-pair drops 4x and the dx-only terms of the
+//     quadratic are shared.  HEAVY tiles (a street scene's horizon tiles hold up to ~35 k splats
+//     and would serialise the whole frame behind one wave): the tile is split into four 16x4
+//     sub-tiles, one wave each at 1 pixel per lane, 4 splats per iteration for ILP.
+//   * A tile-classification pre-pass builds the two work lists; heavy tiles are dispatched first
+//     (longest-processing-time-first) from the same launch.
+//   * Each wave stages batches of 64 splat records (one 48-byte gather per lane) into its private
+//     3 KB LDS slice.  While staging, every lane runs a CONSERVATIVE rectangle cull for "its"
+//     splat (exact minimum of the conic's quadratic over the wave's pixel rectangle,
+//     blend_math.h); a 64-bit ballot of the survivors drives the inner loop, so splats that
+//     cannot reach any pixel of the (sub-)tile cost ~1/64 of a lane-op instead of a full
+//     evaluation.  The reference bins by the 3-sigma bounding SQUARE, so a large share of the
+//     list never touches the tile.
+//   * The blend part of an iteration is skipped wave-uniformly when no lane accepted the splat.
+//   * Wave-uniform early exit via ballot when every pixel of the wave is saturated.
+// The kernel is VALU-bound (about 25 flop-equivalents per surviving pixel-splat pair), not
+// HBM-bound; its compulsory HBM traffic is 4 B (id) + 40 B (record fields) per tile instance
+// + 20 B per pixel.
+#include "blend_math.h"
 #include "common.h"
 
 namespace grpg {
 
-constexpr int RW_WAVES = 4;  // tiles per workgroup
+constexpr int RW_WAVES = 4;
 
-struct PixelState {
-  float T, Cr, Cg, Cb, D, Wt;
-  uint32_t last;
-  bool done;
-};
-
-template <bool WRITE_AUX>
+// ------------------------------------------------------------------------------------------
+// Tile classification: heavy / light work lists (order inside a list is irrelevant to results).
+// counts[0] = #heavy, counts[1] = #light (pre-zeroed by the launcher).
+// ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const float4* __restrict__ rec, const int W, const int H, const int gx,
-                      const int ntiles, const float* __restrict__ bg,
-                      float* __restrict__ out_color, float* __restrict__ out_depth,
-                      float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * RW_WAVES + wave;
-  if (tile >= ntiles) return;  // whole wave exits together; no workgroup barriers are used
-  const int ty = tile / gx, tx = tile - ty * gx;
-  const int px = tx * TILE + (lane & 15);
-  const int py0 = ty * TILE + (lane >> 4) * 4;
+classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
+                      const uint32_t heavy_min, uint32_t* __restrict__ counts,
+                      uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ light_list) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const uint2 r = ranges[t];
+  if (r.y - r.x >= heavy_min)
+    heavy_list[atomicAdd(&counts[0], 1u)] = t;
+  else
+    light_list[atomicAdd(&counts[1], 1u)] = t;
+}
+
+// Per-wave blend of one pixel rectangle: 16 columns x (4*PX... see below) rows.
+//   PX = 4: rows y0 + (lane>>4)*4 + k, k<4   -> 16x16 pixels (a whole tile)
+//   PX = 1: rows y0 + (lane>>4)               -> 16x4 pixels (a quarter tile)
+// GPI splats are evaluated per inner iteration (independent alpha chains), then blended in order.
+template <int PX, int GPI, bool WRITE_AUX>
+__device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int lane,
+                                           const uint32_t r_begin, const uint32_t r_end,
+                                           const int x0, const int y0, const int W, const int H,
+                                           const uint32_t* __restrict__ point_list,
+                                           const float4* __restrict__ rec,
+                                           const float* __restrict__ bg,
+                                           float* __restrict__ out_color,
+                                           float* __restrict__ out_depth,
+                                           float* __restrict__ out_alpha,
+                                           uint32_t* __restrict__ n_contrib) {
+  const int px = x0 + (lane & 15);
+  const int py0 = y0 + (lane >> 4) * PX;
   const float pxf = (float)px;
-  const uint2 range = ranges[tile];
+  // pixel rectangle of this wave (for the cull), clipped rows/cols do not matter (superset)
+  const float rx0 = (float)x0, rx1 = (float)(x0 + 15);
+  const float ry0 = (float)y0, ry1 = (float)(y0 + 4 * PX - 1);
 
-  PixelState p[4];
+  float T[PX], Cr[PX], Cg[PX], Cb[PX], D[PX], Wt[PX];
+  uint32_t last[PX];
+  bool done[PX];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    p[k].T = 1.0f; p[k].Cr = p[k].Cg = p[k].Cb = 0.f; p[k].D = 0.f; p[k].Wt = 0.f;
-    p[k].last = 0;
-    p[k].done = !(px < W && (py0 + k) < H);
+  for (int k = 0; k < PX; k++) {
+    T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = 0.f; D[k] = 0.f; Wt[k] = 0.f;
+    last[k] = 0;
+    done[k] = !(px < W && (py0 + k) < H);
   }
-  float4* my = s_rec[wave];
 
-  for (uint32_t base = range.x; base < range.y; base += WAVE) {
-    const bool alldone = p[0].done && p[1].done && p[2].done && p[3].done;
+  for (uint32_t base = r_begin; base < r_end; base += WAVE) {
+    bool alldone = true;
+#pragma unroll
+    for (int k = 0; k < PX; k++) alldone = alldone && done[k];
     if (__ballot(!alldone) == 0ull) break;
-    const uint32_t n = min((uint32_t)WAVE, range.y - base);
+    const uint32_t n = min((uint32_t)WAVE, r_end - base);
+    bool keep = false;
     if ((uint32_t)lane < n) {
       const uint32_t id = point_list[base + lane];
       const float4* r = rec + (size_t)id * REC_F4;
       const float4 a = r[0], b = r[1], c = r[2];
-      my[lane * REC_F4 + 0] = a;
-      my[lane * REC_F4 + 1] = b;
-      my[lane * REC_F4 + 2] = c;
+      keep = !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
+      if (keep) {
+        my[lane * REC_F4 + 0] = a;
+        my[lane * REC_F4 + 1] = b;
+        my[lane * REC_F4 + 2] = c;
+      }
     }
+    uint64_t mask = __ballot(keep);
     __builtin_amdgcn_wave_barrier();
-    const uint32_t idx0 = base - range.x + 1;  // 1-based position in the tile's list
-    for (uint32_t j = 0; j < n; j++) {
-      const float4 a = my[j * REC_F4 + 0];   // px, py, depth, opacity
-      const float4 b = my[j * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
-      const float4 c = my[j * REC_F4 + 2];   // G, B, -, -
-      const float dx = a.x - pxf;
+    const uint32_t idx0 = base - r_begin + 1;   // 1-based list position of entry 0 of the batch
+    while (mask) {
+      int jj[GPI];
+      bool has[GPI];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float dy = a.y - (float)(py0 + k);
-        const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-        const float alpha = fminf(0.99f, a.w * __expf(power));
-        bool valid = !p[k].done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        const float test_T = p[k].T * (1.0f - alpha);
-        const bool term = valid && (test_T < 0.0001f);
-        p[k].done = p[k].done || term;
-        valid = valid && !term;
-        const float w = valid ? alpha * p[k].T : 0.0f;
-        p[k].Cr += b.w * w;
-        p[k].Cg += c.x * w;
-        p[k].Cb += c.y * w;
-        p[k].D += a.z * w;
-        p[k].Wt += w;
-        p[k].T = valid ? test_T : p[k].T;
-        p[k].last = valid ? (idx0 + j) : p[k].last;
+      for (int g = 0; g < GPI; g++) {
+        has[g] = mask != 0ull;
+        jj[g] = has[g] ? (int)__builtin_ctzll(mask) : 0;
+        mask &= mask - 1ull;   // (0 & anything) stays 0
+      }
+      float4 ra[GPI], rb[GPI], rc[GPI];
+#pragma unroll
+      for (int g = 0; g < GPI; g++) {
+        ra[g] = my[jj[g] * REC_F4 + 0];   // px, py, depth, opacity
+        rb[g] = my[jj[g] * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
+        rc[g] = my[jj[g] * REC_F4 + 2];   // G, B, -, -
+      }
+      float alpha[GPI][PX];
+      bool ok[GPI][PX];
+      bool any = false;
+#pragma unroll
+      for (int g = 0; g < GPI; g++) {
+        if (!has[g]) {   // wave-uniform: fewer than GPI survivors were left in this batch
+#pragma unroll
+          for (int k = 0; k < PX; k++) { ok[g][k] = false; alpha[g][k] = 0.f; }
+          continue;
+        }
+        const SplatTerms st = splat_terms(ra[g].x - pxf, rb[g].x, rb[g].y, rb[g].z);
+#pragma unroll
+        for (int k = 0; k < PX; k++) {
+          const float dy = ra[g].y - (float)(py0 + k);
+          float G;
+          ok[g][k] = pair_alpha(pair_power(st, dy), ra[g].w, G, alpha[g][k]);
+          any = any || (ok[g][k] && !done[k]);
+        }
+      }
+      if (__ballot(any) == 0ull) continue;   // nobody in the wave blends any of these splats
+#pragma unroll
+      for (int g = 0; g < GPI; g++) {
+        // never touch the (stale) record of an absent slot: 0 * NaN would poison the sums
+        if (!has[g]) continue;
+#pragma unroll
+        for (int k = 0; k < PX; k++) {
+          bool valid = ok[g][k] && !done[k];
+          const float test_T = T[k] * (1.0f - alpha[g][k]);
+          const bool term = valid && (test_T < 0.0001f);
+          done[k] = done[k] || term;
+          valid = valid && !term;
+          const float w = valid ? alpha[g][k] * T[k] : 0.0f;
+          Cr[k] = fmaf(rb[g].w, w, Cr[k]);
+          Cg[k] = fmaf(rc[g].x, w, Cg[k]);
+          Cb[k] = fmaf(rc[g].y, w, Cb[k]);
+          D[k] = fmaf(ra[g].z, w, D[k]);
+          Wt[k] += w;
+          T[k] = valid ? test_T : T[k];
+          last[k] = valid ? (idx0 + (uint32_t)jj[g]) : last[k];
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -100,22 +169,59 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t HW = (size_t)H * W;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < PX; k++) {
     const int py = py0 + k;
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      out_color[pix] = p[k].Cr + p[k].T * bg0;
-      out_color[HW + pix] = p[k].Cg + p[k].T * bg1;
-      out_color[2 * HW + pix] = p[k].Cb + p[k].T * bg2;
-      out_alpha[pix] = p[k].Wt;
-      out_depth[pix] = p[k].D;
-      if (WRITE_AUX) n_contrib[pix] = p[k].last;
+      out_color[pix] = Cr[k] + T[k] * bg0;
+      out_color[HW + pix] = Cg[k] + T[k] * bg1;
+      out_color[2 * HW + pix] = Cb[k] + T[k] * bg2;
+      out_alpha[pix] = Wt[k];
+      out_depth[pix] = D[k];
+      if (WRITE_AUX) n_contrib[pix] = last[k];
     }
   }
 }
 
-// N-channel "semantic" planes (forward.cu:442-444): same traversal, NCH channels per launch
-// accumulated in registers instead of the reference's per-contribution global read-modify-write.
+template <bool WRITE_AUX>
+__global__ void __launch_bounds__(256)
+render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const float4* __restrict__ rec, const int W, const int H, const int gx,
+                      const uint32_t* __restrict__ counts,
+                      const uint32_t* __restrict__ heavy_list,
+                      const uint32_t* __restrict__ light_list, const float* __restrict__ bg,
+                      float* __restrict__ out_color, float* __restrict__ out_depth,
+                      float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
+  __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t nheavy = counts[0], nlight = counts[1];
+  const uint32_t b = blockIdx.x;
+  if (b < nheavy) {
+    // heavy tile: four independent 16x4 sub-tiles, 1 pixel per lane, 4 splats per iteration
+    const uint32_t tile = heavy_list[b];
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+    const uint2 range = ranges[tile];
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    blend_rect<1, 4, WRITE_AUX>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE + wave * 4, W, H,
+                                point_list, rec, bg, out_color, out_depth, out_alpha, n_contrib);
+  } else {
+    const uint32_t li = (b - nheavy) * RW_WAVES + (uint32_t)wave;
+    if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
+    const uint32_t tile = light_list[li];
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+    const uint2 range = ranges[tile];
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    blend_rect<4, 1, WRITE_AUX>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE, W, H, point_list,
+                                rec, bg, out_color, out_depth, out_alpha, n_contrib);
+  }
+}
+
+// N-channel "semantic" planes (forward.cu:442-444): same traversal and the same accept/reject
+// arithmetic (blend_math.h), NCH channels per launch accumulated in registers instead of the
+// reference's per-contribution global read-modify-write.  Non-default path (use_semantic=False
+// in every shipped config), kept simple: one wave per tile, 4 pixels per lane.
 template <int NCH>
 __global__ void __launch_bounds__(256)
 render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -163,20 +269,19 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
       float sv[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) sv[c] = mysem[j * NCH + c];
-      const float dx = a.x - pxf;
+      const SplatTerms st = splat_terms(a.x - pxf, b.x, b.y, b.z);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const float dy = a.y - (float)(py0 + k);
-        const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-        const float alpha = fminf(0.99f, a.w * __expf(power));
-        bool valid = !done[k] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        float G, alpha;
+        bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && !done[k];
         const float test_T = T[k] * (1.0f - alpha);
         const bool term = valid && (test_T < 0.0001f);
         done[k] = done[k] || term;
         valid = valid && !term;
         const float w = valid ? alpha * T[k] : 0.0f;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) acc[k][c] += sv[c] * w;
+        for (int c = 0; c < NCH; c++) acc[k][c] = fmaf(sv[c], w, acc[k][c]);
         T[k] = valid ? test_T : T[k];
       }
     }
@@ -198,13 +303,20 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const float4* rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
-                           uint32_t* n_contrib) {
+                           uint32_t* n_contrib, uint32_t* work /* [2 + 2T] scratch */,
+                           uint32_t heavy_min) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
-  const int blocks = (ntiles + RW_WAVES - 1) / RW_WAVES;
-  render_forward_kernel<true><<<blocks, 256, 0, s>>>(ranges, point_list, rec, W, H, gx, ntiles,
-                                                     bg, out_color, out_depth, out_alpha,
-                                                     n_contrib);
+  uint32_t* counts = work;
+  uint32_t* heavy_list = work + 2;
+  uint32_t* light_list = work + 2 + ntiles;
+  (void)hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s);
+  classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
+                                                            counts, heavy_list, light_list);
+  // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
+  render_forward_kernel<true><<<ntiles, 256, 0, s>>>(ranges, point_list, rec, W, H, gx, counts,
+                                                     heavy_list, light_list, bg, out_color,
+                                                     out_depth, out_alpha, n_contrib);
 }
 
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
