@@ -209,12 +209,6 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   uint2* ranges = (uint2*)(img + IL.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
 
-  BlobHeader hh;
-  std::memset(&hh, 0, sizeof(hh));
-  hh.magic = GEOM_MAGIC; hh.P = (uint32_t)P; hh.R = 0; hh.W = (uint32_t)width; hh.H = (uint32_t)height; hh.S = (uint32_t)S;
-  HIP_TRY(hipMemcpyAsync(gh, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
-  hh.magic = IMG_MAGIC;
-  HIP_TRY(hipMemcpyAsync(img, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
 
   StageTimer tm(stream, g_timing_enabled);
   uint32_t R = 0;
@@ -244,8 +238,8 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     const BinLayout BL = bin_layout((size_t)R);
     char* bin = binning_alloc(BL.total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
-    hh.magic = BIN_MAGIC; hh.R = R;
-    HIP_TRY(hipMemcpyAsync(bin, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
+    launch_write_headers(stream, geom, bin, img, (uint32_t)P, R, (uint32_t)width, (uint32_t)height,
+                         (uint32_t)S);
     uint32_t* bkey_a = (uint32_t*)(bin + BL.key_a);
     uint32_t* bkey_b = (uint32_t*)(bin + BL.key_b);
     uint32_t* bval_a = (uint32_t*)(bin + BL.val_a);
@@ -258,7 +252,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     const int passes = radix_sort_num_passes(0, tbits);
     // emit into whichever pair makes the LAST pass land in "a" (point_list lives in val_a)
     const bool start_in_b = (passes & 1) != 0;
-    launch_emit(stream, (uint32_t)P, sorted_gid, offsets, tiles, rec, cam.gx, cam.gy,
+    launch_emit(stream, (uint32_t)P, R, sorted_gid, offsets, rec, cam.gx, cam.gy,
                 start_in_b ? bkey_b : bkey_a, start_in_b ? bval_b : bval_a);
     STAGE_CHECK("emit");
     tm.mark(4);
@@ -300,8 +294,8 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipMemsetAsync(n_contrib, 0, N * 4, stream));
     char* bin = binning_alloc(bin_layout(0).total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
-    hh.magic = BIN_MAGIC; hh.R = 0;
-    HIP_TRY(hipMemcpyAsync(bin, &hh, sizeof(hh), hipMemcpyHostToDevice, stream));
+    launch_write_headers(stream, geom, bin, img, 0u, 0u, (uint32_t)width, (uint32_t)height,
+                         (uint32_t)S);
   }
   return (int)R;
 }
@@ -394,6 +388,17 @@ int grpg_visible_filter(int P, int M, int width, int height, const float* means3
   launch_visible_filter(stream, P, means3D, scales, scale_modifier, rotations, cov3D_precomp, cam,
                         radii, means2D);
   STAGE_CHECK("visible filter");
+  return GRPG_OK;
+}
+
+int grpg_pack_rgb_u8(const float* src, unsigned char* dst, size_t n, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (n > 0 && (!src || !dst)) return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 3))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "src must be 16-byte and dst 4-byte aligned");
+  launch_pack_u8((hipStream_t)hip_stream, src, dst, n);
+  HIP_TRY(hipGetLastError());
   return GRPG_OK;
 }
 

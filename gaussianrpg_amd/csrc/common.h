@@ -104,7 +104,7 @@ inline ImgLayout img_layout(size_t T, size_t N) {
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   L.ranges = take(T * 8);
   L.n_contrib = take(N * 4);
-  L.work = take((2 + 2 * T) * 4);   // render work lists: counts[2], heavy[T], light[T]
+  L.work = take((4 + 4 * T) * 4);   // render work lists: counts[4], lists[4][T]
   L.total = o;
   return L;
 }
@@ -143,8 +143,8 @@ void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* gid, const u
                          uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
                          uint32_t* total_out);
 
-void launch_emit(hipStream_t s, uint32_t P, const uint32_t* sorted_gid, const uint32_t* offsets,
-                 const uint32_t* tiles, const float4* rec, int gx, int gy, uint32_t* tile_keys,
+void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_gid,
+                 const uint32_t* offsets, const float4* rec, int gx, int gy, uint32_t* tile_keys,
                  uint32_t* vals);
 void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
                         uint32_t T);
@@ -152,7 +152,7 @@ void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, ui
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const float4* rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
-                           uint32_t* n_contrib, uint32_t* work /* [2 + 2T] u32 scratch */,
+                           uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
                            uint32_t heavy_min);
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const float4* rec, const float* semantics, int S, int W, int H, int gx,
@@ -173,6 +173,10 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 const float* dL_dmean2D, const float* dL_dconic,
                                 float* dL_dmean3D, const float* dL_dcolor, const float* dL_ddepth,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
+
+void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t R,
+                          uint32_t W, uint32_t H, uint32_t S);
+void launch_pack_u8(hipStream_t s, const float* src, unsigned char* dst, size_t n);
 
 void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
                          const float4* rec, const uint32_t* tiles, const uint32_t* tile_keys,

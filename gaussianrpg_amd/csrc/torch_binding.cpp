@@ -280,6 +280,18 @@ DebugExport(const torch::Tensor& geomBuffer, const torch::Tensor& binningBuffer,
   return std::make_tuple(keys, plist, ranges, ncontrib, means2D, depths, conic, rgb, tiles);
 }
 
+torch::Tensor PackU8(const torch::Tensor& color) {
+  TORCH_CHECK(color.is_cuda() && color.scalar_type() == torch::kFloat32, "pack_u8: float32 device tensor");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(color.device());
+  torch::Tensor src = color.contiguous();
+  torch::Tensor out = torch::empty(src.sizes(), src.options().dtype(torch::kUInt8));
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_pack_rgb_u8(src.data_ptr<float>(), out.data_ptr<uint8_t>(), (size_t)src.numel(),
+                                  (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_pack_rgb_u8", rc);
+  return out;
+}
+
 std::tuple<std::vector<float>, int> StageTiming() {
   std::vector<float> ms(GRPG_NUM_STAGES, 0.f);
   int calls = 0;
@@ -295,6 +307,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);
   // additions (not in the reference module)
   m.def("debug_export", &DebugExport);
+  m.def("pack_u8", &PackU8);
   m.def("set_stage_timing", [](bool on) { grpg_set_stage_timing(on ? 1 : 0); });
   m.def("stage_timing", &StageTiming);
   m.def("abi_version", []() { return grpg_abi_version(); });

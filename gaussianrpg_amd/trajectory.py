@@ -56,7 +56,10 @@ def shard_frames(num_frames: int, rank: int, world: int) -> List[int]:
 def pack_u8(color: torch.Tensor) -> torch.Tensor:
     """float [3,H,W] -> uint8 [3,H,W] (eval-mode clamp of render_kernel,
     street_gaussian_renderer.py:236-237, then the x255 of the image writers)."""
-    return (color.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8)
+    if color.is_cuda:
+        from .rasterizer import _C          # one fused HIP launch instead of four torch kernels
+        return _C.pack_u8(color)
+    return (color.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8)   # host-side logic tests only
 
 
 def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int, rank: int,

@@ -152,6 +152,15 @@ GRPG_API int grpg_debug_export(int P, int R, int width, int height,
                       float* rgb, uint32_t* tiles_touched, void* hip_stream);
 
 /*
+ * Frame delivery helper for trajectory mode (no reference counterpart in the extension; it fuses
+ * what the reference does in PyTorch after the op: the eval-mode clamp of
+ * lib/models/street_gaussian_renderer.py:236-237 and the x255 -> uint8 conversion of the image
+ * writers): dst[i] = (uint8)(clamp(src[i], 0, 1) * 255 + 0.5) for n floats (device pointers,
+ * src 16-byte aligned).
+ */
+GRPG_API int grpg_pack_rgb_u8(const float* src, unsigned char* dst, size_t n, void* hip_stream);
+
+/*
  * Per-stage device timing, measured with HIP events recorded on the op's own stream (so it sees
  * the real kernel durations whatever stream torch calls "current").  While enabled, every
  * grpg_forward on this thread records GRPG_NUM_STAGES+1 events and returns without waiting;

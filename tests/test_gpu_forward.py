@@ -254,3 +254,13 @@ def test_full_size_properties(dev):
     assert a.min() >= 0.0 and a.max() <= 1.0 + 1e-5            # alpha = 1 - T in [0,1]
     assert (got["n_contrib"].reshape(-1) <= np.repeat((rg[:, 1] - rg[:, 0]).reshape(80, 120), 16, 0).repeat(16, 1).reshape(-1)).all()
     assert np.isfinite(got["color"]).all() and np.isfinite(got["depth"]).all()
+
+
+def test_pack_u8(dev):
+    from gaussianrpg_amd import trajectory as tj
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(3, 37, 53, generator=g) * 1.6 - 0.3)
+    got = tj.pack_u8(x.to(dev)).cpu()
+    ref = tj.pack_u8(x)
+    assert got.dtype == torch.uint8 and got.shape == ref.shape
+    assert int((got.int() - ref.int()).abs().max()) == 0
