@@ -50,26 +50,31 @@ __device__ __forceinline__ bool splat_misses_rect(const float gx, const float gy
                                                   const float b, const float c,
                                                   const float opacity, const float x0,
                                                   const float x1, const float y0, const float y1) {
-  if (!(opacity == opacity)) return false;
-  // alpha <= opacity * exp(power <= 0) <= opacity, so a splat below 1/255 never passes anywhere
-  if (opacity < (1.0f / 255.0f) * 0.999f) return true;
-  if (!(a > 0.0f) || !(c > 0.0f)) return false;
+  // Branch-free on purpose (predicates only): this runs once per list entry per wave.
   const float dxl = gx - x1, dxh = gx - x0, dyl = gy - y1, dyh = gy - y0;
-  if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) return false;   // centre inside
-  const float ia = 1.0f / a, ic = 1.0f / c;
-  float qmin = 3.0e38f;
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    const float ex = e ? dxh : dxl;
-    const float dy = fminf(dyh, fmaxf(dyl, -b * ex * ic));
-    qmin = fminf(qmin, a * ex * ex + 2.0f * b * ex * dy + c * dy * dy);
-    const float fy = e ? dyh : dyl;
-    const float dx = fminf(dxh, fmaxf(dxl, -b * fy * ia));
-    qmin = fminf(qmin, a * dx * dx + 2.0f * b * dx * fy + c * fy * fy);
+  const bool centre_inside = dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f;
+  // 1 ulp reciprocals are fine: the 1-D minimiser only has to be accurate to the safety margin
+  const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);
+  const float nb = -b;
+  float qmin;
+  {
+    const float dy0 = fminf(dyh, fmaxf(dyl, nb * dxl * ic));
+    const float dy1 = fminf(dyh, fmaxf(dyl, nb * dxh * ic));
+    const float dx0 = fminf(dxh, fmaxf(dxl, nb * dyl * ia));
+    const float dx1 = fminf(dxh, fmaxf(dxl, nb * dyh * ia));
+    const float q0 = a * dxl * dxl + (2.0f * b * dxl + c * dy0) * dy0;
+    const float q1 = a * dxh * dxh + (2.0f * b * dxh + c * dy1) * dy1;
+    const float q2 = c * dyl * dyl + (2.0f * b * dyl + a * dx0) * dx0;
+    const float q3 = c * dyh * dyh + (2.0f * b * dyh + a * dx1) * dx1;
+    qmin = fminf(fminf(q0, q1), fminf(q2, q3));
   }
-  if (!(qmin == qmin)) return false;
   const float thr = 2.0f * __logf(255.0f * opacity);
-  return qmin > thr + 1e-4f * fabsf(thr) + 1e-3f * (1.0f + fabsf(qmin) * 1e-3f);
+  const bool far = qmin > thr + 1e-4f * fabsf(thr) + 1e-3f * (1.0f + fabsf(qmin) * 1e-3f);
+  // alpha <= opacity * exp(power <= 0) <= opacity, so a splat below 1/255 never passes anywhere
+  const bool transparent = opacity < (1.0f / 255.0f) * 0.999f;
+  // never reject on doubt: NaNs, non-positive diagonal (degenerate conic), centre inside
+  const bool sane = (a > 0.0f) && (c > 0.0f) && (qmin == qmin) && (opacity == opacity);
+  return transparent || (sane && !centre_inside && far);
 }
 
 }  // namespace grpg

@@ -28,6 +28,10 @@
 // The kernel is VALU-bound (about 25 flop-equivalents per surviving pixel-splat pair), not
 // HBM-bound; its compulsory HBM traffic is 4 B (id) + 40 B (record fields) per tile instance
 // + 20 B per pixel.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "blend_math.h"
 #include "common.h"
 
@@ -73,7 +77,67 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
 //   PX = 4: rows y0 + (lane>>4)*4 + k, k<4   -> 16x16 pixels (a whole tile)
 //   PX = 1: rows y0 + (lane>>4)               -> 16x4 pixels (a quarter tile)
 // GPI splats are evaluated per inner iteration (independent alpha chains), then blended in order.
-template <int PX, int GPI, bool WRITE_AUX>
+template <int PX>
+struct WavePix {   // per-lane blending state of PX pixels
+  float T[PX], Cr[PX], Cg[PX], Cb[PX], D[PX], Wt[PX];
+  uint32_t last[PX];
+  bool done[PX];
+};
+
+// Evaluate G consecutive compacted survivors (LDS slots j0 .. j0+G-1, all present) for the lane's
+// PX pixels: G*PX independent power/exp/alpha chains, then the in-order blend.  Returns true if
+// the blend part ran (some lane accepted some splat).
+template <int PX, int G>
+__device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __restrict__ my,
+                                            const int j0, const uint32_t idx0, const float pxf,
+                                            const int py0) {
+  float4 ra[G], rb[G], rc[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    ra[g] = my[(j0 + g) * REC_F4 + 0];   // px, py, depth, opacity
+    rb[g] = my[(j0 + g) * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
+    rc[g] = my[(j0 + g) * REC_F4 + 2];   // G, B, position in batch, -
+  }
+  float alpha[G][PX];
+  bool ok[G][PX];
+  bool any = false;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const SplatTerms st = splat_terms(ra[g].x - pxf, rb[g].x, rb[g].y, rb[g].z);
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+      const float dy = ra[g].y - (float)(py0 + k);
+      float Gv;
+      ok[g][k] = pair_alpha(pair_power(st, dy), ra[g].w, Gv, alpha[g][k]);
+      any = any || (ok[g][k] && !s.done[k]);
+    }
+  }
+  if (__ballot(any) == 0ull) return false;   // nobody in the wave blends any of these splats
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+      bool valid = ok[g][k] && !s.done[k];
+      const float test_T = s.T[k] * (1.0f - alpha[g][k]);
+      const bool term = valid && (test_T < 0.0001f);
+      s.done[k] = s.done[k] || term;
+      valid = valid && !term;
+      const float w = valid ? alpha[g][k] * s.T[k] : 0.0f;
+      s.Cr[k] = fmaf(rb[g].w, w, s.Cr[k]);
+      s.Cg[k] = fmaf(rc[g].x, w, s.Cg[k]);
+      s.Cb[k] = fmaf(rc[g].y, w, s.Cb[k]);
+      s.D[k] = fmaf(ra[g].z, w, s.D[k]);
+      s.Wt[k] += w;
+      s.T[k] = valid ? test_T : s.T[k];
+      s.last[k] = valid ? (idx0 + (uint32_t)__float_as_int(rc[g].z)) : s.last[k];
+    }
+  }
+  return true;
+}
+
+struct WaveTrace { uint32_t batches, survivors, blends, t_stage, t_loop; };
+
+template <int PX, int GPI, bool WRITE_AUX, bool TRACE = false>
 __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int lane,
                                            const uint32_t r_begin, const uint32_t r_end,
                                            const int x0, const int y0, const int W, const int H,
@@ -83,28 +147,29 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
                                            float* __restrict__ out_color,
                                            float* __restrict__ out_depth,
                                            float* __restrict__ out_alpha,
-                                           uint32_t* __restrict__ n_contrib) {
+                                           uint32_t* __restrict__ n_contrib,
+                                           WaveTrace* tr = nullptr, const int ablate = 0) {
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
   const float pxf = (float)px;
   // pixel rectangle of this wave (for the cull), clipped rows/cols do not matter (superset)
-  const float rx0 = (float)x0, rx1 = (float)(x0 + 15);
-  const float ry0 = (float)y0, ry1 = (float)(y0 + 4 * PX - 1);
+  float rx0 = (float)x0, rx1 = (float)(x0 + 15);
+  float ry0 = (float)y0, ry1 = (float)(y0 + 4 * PX - 1);
+  uint64_t prev_alive = ~0ull;
 
-  float T[PX], Cr[PX], Cg[PX], Cb[PX], D[PX], Wt[PX];
-  uint32_t last[PX];
-  bool done[PX];
+  WavePix<PX> st;
 #pragma unroll
   for (int k = 0; k < PX; k++) {
-    T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = 0.f; D[k] = 0.f; Wt[k] = 0.f;
-    last[k] = 0;
-    done[k] = !(px < W && (py0 + k) < H);
+    st.T[k] = 1.0f; st.Cr[k] = st.Cg[k] = st.Cb[k] = 0.f; st.D[k] = 0.f; st.Wt[k] = 0.f;
+    st.last[k] = 0;
+    st.done[k] = !(px < W && (py0 + k) < H);
   }
 
   // Software pipeline over batches of 64 list entries: while batch i is blended, the records of
-  // batch i+1 and the ids of batch i+2 are already in flight (the id -> record gather is a
-  // dependent pair of ~1 us L2/HBM round trips that would otherwise sit on the critical path of
-  // the longest tile).
+  // batch i+1 and the ids of batch i+2 are in flight (the id -> record gather is a dependent pair
+  // of L2 / Infinity-Cache round trips).  Deeper register queues were tried (3 batches, loop
+  // unrolled over fixed slots): hipcc still waits vmcnt(0) at the top of every batch, so they only
+  // cost registers (occupancy 4 -> 3) -- kept at one batch.
   uint32_t id_n2 = 0;
   float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
   if (r_begin + (uint32_t)lane < r_end) {
@@ -117,8 +182,34 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   for (uint32_t base = r_begin; base < r_end; base += WAVE) {
     bool alldone = true;
 #pragma unroll
-    for (int k = 0; k < PX; k++) alldone = alldone && done[k];
-    if (__ballot(!alldone) == 0ull) break;
+    for (int k = 0; k < PX; k++) alldone = alldone && st.done[k];
+    const uint64_t alive = __ballot(!alldone);
+    if (alive == 0ull) break;
+    if (alive != prev_alive) {
+      // Shrink the cull rectangle to the bounding box of the pixels that are still live.  Exact:
+      // a splat is only dropped if no LIVE pixel can accept it.  In the long tail of a heavy
+      // sub-tile only a handful of unsaturated pixels keep scanning tens of thousands of entries;
+      // with the tight box almost nothing survives the cull and a batch costs little more than
+      // its staging.
+      prev_alive = alive;
+      float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+#pragma unroll
+      for (int k = 0; k < PX; k++) {
+        if (!st.done[k]) {
+          bx0 = pxf; bx1 = pxf;
+          by0 = fminf(by0, (float)(py0 + k));
+          by1 = fmaxf(by1, (float)(py0 + k));
+        }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+        by0 = fminf(by0, __shfl_xor(by0, d, 64));
+        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+      }
+      rx0 = bx0; rx1 = bx1; ry0 = by0; ry1 = by1;
+    }
     const uint32_t n = min((uint32_t)WAVE, r_end - base);
     const float4 a = a_n, b = b_n, c = c_n;
     if (base + WAVE + (uint32_t)lane < r_end) {        // records of the next batch
@@ -127,76 +218,38 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     }
     if (base + 2 * WAVE + (uint32_t)lane < r_end)      // ids of the batch after that
       id_n2 = point_list[base + 2 * WAVE + lane];
-    bool keep = false;
-    if ((uint32_t)lane < n) {
-      keep = !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
-      if (keep) {
-        my[lane * REC_F4 + 0] = a;
-        my[lane * REC_F4 + 1] = b;
-        my[lane * REC_F4 + 2] = c;
-      }
+    const uint64_t tc0 = TRACE ? __builtin_readcyclecounter() : 0;
+    const bool keep = ((uint32_t)lane < n) &&
+                      !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
+    const uint64_t mask = __ballot(keep);
+    const int cnt = (int)__popcll(mask);
+    if (keep) {
+      const int slot = (int)__popcll(mask & lanemask_lt());
+      my[slot * REC_F4 + 0] = a;
+      my[slot * REC_F4 + 1] = b;
+      my[slot * REC_F4 + 2] = make_float4(c.x, c.y, __int_as_float(lane), 0.f);   // .z = position in batch
     }
-    uint64_t mask = __ballot(keep);
+    if (TRACE) { tr->batches++; tr->survivors += (uint32_t)cnt; }
     __builtin_amdgcn_wave_barrier();
     const uint32_t idx0 = base - r_begin + 1;   // 1-based list position of entry 0 of the batch
-    while (mask) {
-      int jj[GPI];
-      bool has[GPI];
-#pragma unroll
-      for (int g = 0; g < GPI; g++) {
-        has[g] = mask != 0ull;
-        jj[g] = has[g] ? (int)__builtin_ctzll(mask) : 0;
-        mask &= mask - 1ull;   // (0 & anything) stays 0
+
+    const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
+    if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
+    {
+      // full groups of GPI survivors, then the remainder one by one: no dummy slots are evaluated
+      int j0 = (TRACE && (ablate & 1)) ? cnt : 0;
+      for (; j0 + GPI <= cnt; j0 += GPI) {
+        const bool blended = blend_group<PX, GPI>(st, my, j0, idx0, pxf, py0);
+        if (TRACE && blended) tr->blends++;
       }
-      float4 ra[GPI], rb[GPI], rc[GPI];
-#pragma unroll
-      for (int g = 0; g < GPI; g++) {
-        ra[g] = my[jj[g] * REC_F4 + 0];   // px, py, depth, opacity
-        rb[g] = my[jj[g] * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
-        rc[g] = my[jj[g] * REC_F4 + 2];   // G, B, -, -
-      }
-      float alpha[GPI][PX];
-      bool ok[GPI][PX];
-      bool any = false;
-#pragma unroll
-      for (int g = 0; g < GPI; g++) {
-        if (!has[g]) {   // wave-uniform: fewer than GPI survivors were left in this batch
-#pragma unroll
-          for (int k = 0; k < PX; k++) { ok[g][k] = false; alpha[g][k] = 0.f; }
-          continue;
-        }
-        const SplatTerms st = splat_terms(ra[g].x - pxf, rb[g].x, rb[g].y, rb[g].z);
-#pragma unroll
-        for (int k = 0; k < PX; k++) {
-          const float dy = ra[g].y - (float)(py0 + k);
-          float G;
-          ok[g][k] = pair_alpha(pair_power(st, dy), ra[g].w, G, alpha[g][k]);
-          any = any || (ok[g][k] && !done[k]);
-        }
-      }
-      if (__ballot(any) == 0ull) continue;   // nobody in the wave blends any of these splats
-#pragma unroll
-      for (int g = 0; g < GPI; g++) {
-        // never touch the (stale) record of an absent slot: 0 * NaN would poison the sums
-        if (!has[g]) continue;
-#pragma unroll
-        for (int k = 0; k < PX; k++) {
-          bool valid = ok[g][k] && !done[k];
-          const float test_T = T[k] * (1.0f - alpha[g][k]);
-          const bool term = valid && (test_T < 0.0001f);
-          done[k] = done[k] || term;
-          valid = valid && !term;
-          const float w = valid ? alpha[g][k] * T[k] : 0.0f;
-          Cr[k] = fmaf(rb[g].w, w, Cr[k]);
-          Cg[k] = fmaf(rc[g].x, w, Cg[k]);
-          Cb[k] = fmaf(rc[g].y, w, Cb[k]);
-          D[k] = fmaf(ra[g].z, w, D[k]);
-          Wt[k] += w;
-          T[k] = valid ? test_T : T[k];
-          last[k] = valid ? (idx0 + (uint32_t)jj[g]) : last[k];
+      if (GPI > 1) {
+        for (; j0 < cnt; j0++) {
+          const bool blended = blend_group<PX, 1>(st, my, j0, idx0, pxf, py0);
+          if (TRACE && blended) tr->blends++;
         }
       }
     }
+    if (TRACE) tr->t_loop += (uint32_t)(__builtin_readcyclecounter() - tc1);
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -207,26 +260,30 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     const int py = py0 + k;
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      out_color[pix] = Cr[k] + T[k] * bg0;
-      out_color[HW + pix] = Cg[k] + T[k] * bg1;
-      out_color[2 * HW + pix] = Cb[k] + T[k] * bg2;
-      out_alpha[pix] = Wt[k];
-      out_depth[pix] = D[k];
-      if (WRITE_AUX) n_contrib[pix] = last[k];
+      out_color[pix] = st.Cr[k] + st.T[k] * bg0;
+      out_color[HW + pix] = st.Cg[k] + st.T[k] * bg1;
+      out_color[2 * HW + pix] = st.Cb[k] + st.T[k] * bg2;
+      out_alpha[pix] = st.Wt[k];
+      out_depth[pix] = st.D[k];
+      if (WRITE_AUX) n_contrib[pix] = st.last[k];
     }
   }
 }
 
-template <bool WRITE_AUX>
+template <bool WRITE_AUX, int GPI_H, int GPI_L, bool TRACE = false>
 __global__ void __launch_bounds__(256)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float4* __restrict__ rec, const int W, const int H, const int gx,
                       const uint32_t T, const uint32_t* __restrict__ work,
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
-                      float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
+                      float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+                      uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WaveTrace tr = {0, 0, 0, 0, 0};
+  const uint64_t t_start = TRACE ? wall_clock64() : 0;
+  uint32_t tr_tile = 0xFFFFFFFFu, tr_len = 0;
   const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
   const uint32_t nheavy = n0 + n1 + n2;
   const uint32_t b = blockIdx.x;
@@ -239,8 +296,11 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
-    blend_rect<1, 4, WRITE_AUX>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE + wave * 4, W, H,
-                                point_list, rec, bg, out_color, out_depth, out_alpha, n_contrib);
+    tr_tile = tile; tr_len = re - rb;
+    blend_rect<1, GPI_H, WRITE_AUX, TRACE>(s_rec[wave], lane, rb, re, tx * TILE,
+                                           ty * TILE + wave * 4, W, H, point_list, rec, bg,
+                                           out_color, out_depth, out_alpha, n_contrib, &tr,
+                                           ablate);
   } else {
     const uint32_t li = (b - nheavy) * RW_WAVES + (uint32_t)wave;
     if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
@@ -249,8 +309,19 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
-    blend_rect<4, 1, WRITE_AUX>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE, W, H, point_list,
-                                rec, bg, out_color, out_depth, out_alpha, n_contrib);
+    tr_tile = tile | 0x80000000u; tr_len = re - rb;
+    blend_rect<4, GPI_L, WRITE_AUX, TRACE>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE, W, H,
+                                           point_list, rec, bg, out_color, out_depth, out_alpha,
+                                           n_contrib, &tr, ablate);
+  }
+  if (TRACE && lane == 0) {   // per-wave trace record (debug tool, GRPG_RENDER_TRACE=<file>)
+    const uint64_t t_end = wall_clock64();
+    uint32_t* o = trace + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
+    o[0] = tr_tile; o[1] = tr_len; o[2] = tr.batches; o[3] = tr.survivors; o[4] = tr.blends;
+    o[5] = (uint32_t)(t_end - t_start); o[6] = (uint32_t)(t_start & 0xFFFFFFFFu);
+    o[7] = (uint32_t)wave | ((tr.t_stage >> 8) << 4);   // stage cycles / 256 in the upper bits
+    o[2] = tr.batches | 0u; o[4] = tr.blends;
+    trace[(size_t)gridDim.x * RW_WAVES * 8 + ((size_t)blockIdx.x * RW_WAVES + wave)] = tr.t_loop;
   }
 }
 
@@ -347,9 +418,36 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
                                                             work);
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
-  render_forward_kernel<true><<<ntiles, 256, 0, s>>>(ranges, point_list, rec, W, H, gx,
-                                                     (uint32_t)ntiles, work, bg, out_color,
-                                                     out_depth, out_alpha, n_contrib);
+#define RF_LAUNCH(GH, GL)                                                                      \
+  render_forward_kernel<true, GH, GL><<<ntiles, 256, 0, s>>>(                                   \
+      ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,      \
+      out_alpha, n_contrib)
+  static const char* trace_path = getenv("GRPG_RENDER_TRACE");
+  if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
+    uint32_t* d_trace = nullptr;
+    const size_t words = (size_t)ntiles * RW_WAVES * 9;
+    if (hipMalloc((void**)&d_trace, words * 4) == hipSuccess) {
+      (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
+      render_forward_kernel<true, 4, 1, true><<<ntiles, 256, 0, s>>>(
+          ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
+          out_alpha, n_contrib, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
+      std::vector<uint32_t> h(words);
+      (void)hipMemcpyAsync(h.data(), d_trace, words * 4, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 4, words, f); fclose(f); }
+      (void)hipFree(d_trace);
+      return;
+    }
+  }
+  static const int variant = [] { const char* e = getenv("GRPG_RENDER_VARIANT"); return e ? atoi(e) : 0; }();
+  switch (variant) {   // experiment switch: splats per inner iteration (heavy, light)
+    case 1: RF_LAUNCH(8, 1); break;
+    case 2: RF_LAUNCH(8, 2); break;
+    case 3: RF_LAUNCH(4, 1); break;
+    case 4: RF_LAUNCH(6, 1); break;
+    default: RF_LAUNCH(4, 2); break;   // measured best: 0.517 ms vs 0.575 ms for (4,1)
+  }
+#undef RF_LAUNCH
 }
 
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
