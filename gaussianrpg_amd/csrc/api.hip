@@ -62,7 +62,7 @@ int ensure_device() {
 uint32_t heavy_tile_min() {
   static const uint32_t v = [] {
     const char* e = getenv("GRPG_HEAVY_MIN");
-    return e ? (uint32_t)strtoul(e, nullptr, 10) : 1024u;
+    return e ? (uint32_t)strtoul(e, nullptr, 10) : 256u;   // measured sweep: 64..1024, best 256
   }();
   return v;
 }
@@ -172,6 +172,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     return fail(GRPG_ERR_INVALID_ARGUMENT, "buffer allocators must not be NULL");
   if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth || !out_alpha)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL camera/background/output pointer");
+  if ((unsigned)P > ID_MASK) return fail(GRPG_ERR_INVALID_ARGUMENT, "P must be < 2^28");
   if (P > 0) {
     if (!means3D || !opacities) return fail(GRPG_ERR_INVALID_ARGUMENT, "means3D/opacities NULL");
     if (!cov3D_precomp && (!scales || !rotations))

@@ -8,6 +8,7 @@
 // sorted stably by depth_bits from id order -> (depth_bits, id); instances are emitted in that
 // order and then stably partitioned by tile -> (tile, depth_bits, id).  A Gaussian touches a
 // tile at most once, so there are no further ties.
+#include "blend_math.h"
 #include "common.h"
 
 namespace grpg {
@@ -65,8 +66,20 @@ emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sor
     get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
     const uint32_t w = (uint32_t)(maxx - minx);
     const uint32_t row = k / w, col = k - row * w;
-    tile_keys[s] = (uint32_t)((miny + (int)row) * gx + minx + (int)col);
-    vals[s] = g;
+    const int tx = minx + (int)col, ty = miny + (int)row;
+    tile_keys[s] = (uint32_t)(ty * gx + tx);
+    // Sub-tile mask: can this splat reach the w-th 16x4 quarter of the tile at all?  Evaluated
+    // once here (the record is in registers anyway) and carried through the sort in the spare
+    // top bits of the value, so render knows before loading a record whether it is needed.
+    const float4 r1 = rec[3 * (size_t)g + 1];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (!splat_misses_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.w, (float)(tx * TILE),
+                             (float)(tx * TILE + 15), (float)(ty * TILE + 4 * q),
+                             (float)(ty * TILE + 4 * q + 3)))
+        bits |= 1u << q;
+    vals[s] = g | (bits << SUBTILE_SHIFT);
   }
 }
 
@@ -122,7 +135,7 @@ debug_keys_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
                   uint64_t* keys_sorted, uint32_t* point_list_out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
-  const uint32_t g = point_list[i];
+  const uint32_t g = point_list[i] & ID_MASK;
   if (keys_sorted)
     keys_sorted[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec[3 * (size_t)g].z);
   if (point_list_out) point_list_out[i] = g;

@@ -11,6 +11,12 @@ constexpr int TILE = 16;            // cuda_rasterizer/config.h:17-18
 constexpr int WAVE = 64;            // gfx950 wavefront
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;  // depth key of a culled Gaussian (sorts last)
 
+// A point-list entry is  (sub-tile mask << 28) | Gaussian id.  Bit 28+w is set when the splat can
+// reach the w-th 16x4 quarter of its tile (conservative rectangle cull evaluated once at emit
+// time, binning.hip); render reads the bit before it touches the 48-byte record.  Hence P < 2^28.
+constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
+constexpr int SUBTILE_SHIFT = 28;
+
 // ---------------------------------------------------------------------------------------
 // Per-Gaussian record written by preprocess and gathered by render: 3 x float4 = 48 B.
 //   r0 = { px, py, depth(view z), opacity }

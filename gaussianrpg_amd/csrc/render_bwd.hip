@@ -110,7 +110,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     const uint32_t n = hi >= (uint32_t)WAVE ? (uint32_t)WAVE : hi;
     const uint32_t lo = hi - n;   // batch covers list positions [lo, hi)
     if ((uint32_t)lane < n) {
-      const uint32_t id = point_list[range.x + lo + lane];
+      const uint32_t id = point_list[range.x + lo + lane] & ID_MASK;
       const float4* r = rec + (size_t)id * REC_F4;
       my[lane * REC_F4 + 0] = r[0];
       my[lane * REC_F4 + 1] = r[1];

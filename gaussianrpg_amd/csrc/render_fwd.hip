@@ -170,12 +170,18 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   // of L2 / Infinity-Cache round trips).  Deeper register queues were tried (3 batches, loop
   // unrolled over fixed slots): hipcc still waits vmcnt(0) at the top of every batch, so they only
   // cost registers (occupancy 4 -> 3) -- kept at one batch.
+  // An entry whose sub-tile mask is empty cannot reach any pixel of the tile: its record is
+  // never loaded (about half of a light tile's list on the bench scene).
   uint32_t id_n2 = 0;
   float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
+  bool live_n = false;
   if (r_begin + (uint32_t)lane < r_end) {
-    const uint32_t id0 = point_list[r_begin + lane];
-    const float4* r = rec + (size_t)id0 * REC_F4;
-    a_n = r[0]; b_n = r[1]; c_n = r[2];
+    const uint32_t v0 = point_list[r_begin + lane];
+    live_n = (v0 >> SUBTILE_SHIFT) != 0u;
+    if (live_n) {
+      const float4* r = rec + (size_t)(v0 & ID_MASK) * REC_F4;
+      a_n = r[0]; b_n = r[1]; c_n = r[2];
+    }
   }
   if (r_begin + WAVE + (uint32_t)lane < r_end) id_n2 = point_list[r_begin + WAVE + lane];
 
@@ -212,14 +218,19 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     }
     const uint32_t n = min((uint32_t)WAVE, r_end - base);
     const float4 a = a_n, b = b_n, c = c_n;
+    const bool live = live_n;
+    live_n = false;
     if (base + WAVE + (uint32_t)lane < r_end) {        // records of the next batch
-      const float4* r = rec + (size_t)id_n2 * REC_F4;
-      a_n = r[0]; b_n = r[1]; c_n = r[2];
+      live_n = (id_n2 >> SUBTILE_SHIFT) != 0u;
+      if (live_n) {
+        const float4* r = rec + (size_t)(id_n2 & ID_MASK) * REC_F4;
+        a_n = r[0]; b_n = r[1]; c_n = r[2];
+      }
     }
     if (base + 2 * WAVE + (uint32_t)lane < r_end)      // ids of the batch after that
       id_n2 = point_list[base + 2 * WAVE + lane];
     const uint64_t tc0 = TRACE ? __builtin_readcyclecounter() : 0;
-    const bool keep = ((uint32_t)lane < n) &&
+    const bool keep = ((uint32_t)lane < n) && live &&
                       !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
     const uint64_t mask = __ballot(keep);
     const int cnt = (int)__popcll(mask);
@@ -270,6 +281,168 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// HEAVY path: one wave = one 16x4 quarter of a heavy tile, 1 pixel per lane.
+//
+// The list of a horizon tile holds tens of thousands of entries of which only ~1/3 can reach a
+// given quarter (and far fewer once most of its pixels are saturated).  A lone wave issues about
+// one instruction per 5-6 cycles whatever its type (tools/ubench/lone_wave.hip), so the serial
+// scan of dead entries -- not arithmetic -- was the frame's critical path.  Here the scan is
+// decoupled from the blending through a small LDS ring:
+//   FILL : read 256 list entries at a time (4 per lane, contiguous, prefetched one window ahead),
+//          test the quarter's bit of the sub-tile mask that emit stored in the entry, and append
+//          the survivors' (id, list position) to the ring (ballot + popcount prefix, no atomics);
+//   POP  : take up to 64 survivors from the ring and issue the gather of their 48-byte records;
+//   BLEND: while that gather is in flight, cull the PREVIOUS batch against the bounding box of the
+//          still-live pixels, compact it into LDS and run the blend groups.
+// Dead entries cost 1/256 of a FILL step instead of a slot of a 64-entry batch; a record is only
+// ever loaded for an entry that can reach the quarter.
+// ------------------------------------------------------------------------------------------
+constexpr int QCAP = 512;            // ring capacity in entries (>= 64 + 256), power of two
+constexpr int FILL_Q = 4;            // list entries per lane per FILL step
+
+template <bool TRACE>
+__device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
+                                            uint32_t* __restrict__ qpos, const int lane,
+                                            const int quarter, const uint32_t r_begin,
+                                            const uint32_t r_end, const int x0, const int y0,
+                                            const int W, const int H,
+                                            const uint32_t* __restrict__ point_list,
+                                            const float4* __restrict__ rec,
+                                            const float* __restrict__ bg,
+                                            float* __restrict__ out_color,
+                                            float* __restrict__ out_depth,
+                                            float* __restrict__ out_alpha,
+                                            uint32_t* __restrict__ n_contrib, WaveTrace* tr) {
+  const int px = x0 + (lane & 15);
+  const int py = y0 + (lane >> 4);
+  const float pxf = (float)px;
+  float rx0 = (float)x0, rx1 = (float)(x0 + 15), ry0 = (float)y0, ry1 = (float)(y0 + 3);
+  uint64_t prev_alive = ~0ull;
+  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
+  const uint64_t lt = lanemask_lt();
+
+  WavePix<1> st;
+  st.T[0] = 1.0f; st.Cr[0] = st.Cg[0] = st.Cb[0] = 0.f; st.D[0] = 0.f; st.Wt[0] = 0.f;
+  st.last[0] = 0;
+  st.done[0] = !(px < W && py < H);
+
+  uint32_t in_pos = r_begin;   // next unread list entry          (wave-uniform)
+  uint32_t head = 0, count = 0;   // ring state                   (wave-uniform)
+  uint32_t win[FILL_Q];        // the next FILL window's entries, in flight
+#pragma unroll
+  for (int q = 0; q < FILL_Q; q++) {
+    const uint32_t i = in_pos + q * WAVE + lane;
+    win[q] = i < r_end ? point_list[i] : 0u;
+  }
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;   // current batch (records arrived)
+  uint32_t pos = 0;
+  uint32_t ncur = 0;
+
+  for (;;) {
+    const uint64_t alive = __ballot(!st.done[0]);
+    if (alive == 0ull) break;
+    if (alive != prev_alive) {   // shrink the cull box to the live pixels (exact, see blend_rect)
+      prev_alive = alive;
+      float bx0 = st.done[0] ? 3e38f : pxf, bx1 = st.done[0] ? -3e38f : pxf;
+      float by0 = st.done[0] ? 3e38f : (float)py, by1 = st.done[0] ? -3e38f : (float)py;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+        by0 = fminf(by0, __shfl_xor(by0, d, 64));
+        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+      }
+      rx0 = bx0; rx1 = bx1; ry0 = by0; ry1 = by1;
+    }
+
+    // ---- FILL ----
+    while (count < (uint32_t)WAVE && in_pos < r_end) {
+      uint32_t v[FILL_Q];
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
+      const uint32_t nxt = in_pos + FILL_Q * WAVE;
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = nxt + q * WAVE + lane;
+        win[q] = i < r_end ? point_list[i] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = in_pos + q * WAVE + lane;
+        const bool keep = (i < r_end) && (v[q] & bit);
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
+          qid[slot] = v[q] & ID_MASK;
+          qpos[slot] = i - r_begin + 1;   // 1-based position in the tile's list
+        }
+        count += (uint32_t)__popcll(m);
+      }
+      in_pos = nxt;
+      if (TRACE) tr->batches++;
+    }
+
+    // ---- POP: next batch of up to 64 survivors, start its record gather ----
+    const uint32_t nn = min(count, (uint32_t)WAVE);
+    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
+    uint32_t pos_n = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (QCAP - 1);
+      const uint32_t id = qid[slot];
+      pos_n = qpos[slot];
+      const float4* r = rec + (size_t)id * REC_F4;
+      a_n = r[0]; b_n = r[1]; c_n = r[2];
+    }
+    head = (head + nn) & (QCAP - 1);
+    count -= nn;
+
+    // ---- BLEND the previous batch while the gather is in flight ----
+    if (ncur > 0) {
+      const uint64_t tc0 = TRACE ? __builtin_readcyclecounter() : 0;
+      const bool keep = ((uint32_t)lane < ncur) &&
+                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
+      const uint64_t mask = __ballot(keep);
+      const int cnt = (int)__popcll(mask);
+      if (keep) {
+        const int slot = (int)__popcll(mask & lt);
+        my[slot * REC_F4 + 0] = a;
+        my[slot * REC_F4 + 1] = b;
+        my[slot * REC_F4 + 2] = make_float4(c.x, c.y, __uint_as_float(pos), 0.f);
+      }
+      if (TRACE) tr->survivors += (uint32_t)cnt;
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
+      if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
+      int j0 = 0;
+      for (; j0 + 4 <= cnt; j0 += 4) {
+        const bool blended = blend_group<1, 4>(st, my, j0, 0u, pxf, py);
+        if (TRACE && blended) tr->blends++;
+      }
+      for (; j0 < cnt; j0++) {
+        const bool blended = blend_group<1, 1>(st, my, j0, 0u, pxf, py);
+        if (TRACE && blended) tr->blends++;
+      }
+      if (TRACE) tr->t_loop += (uint32_t)(__builtin_readcyclecounter() - tc1);
+      __builtin_amdgcn_wave_barrier();
+    }
+    a = a_n; b = b_n; c = c_n; pos = pos_n; ncur = nn;
+    if (ncur == 0 && in_pos >= r_end) break;   // ring empty (count == 0 here) and list exhausted
+  }
+
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const size_t HW = (size_t)H * W;
+  if (px < W && py < H) {
+    const size_t pix = (size_t)py * W + px;
+    out_color[pix] = st.Cr[0] + st.T[0] * bg0;
+    out_color[HW + pix] = st.Cg[0] + st.T[0] * bg1;
+    out_color[2 * HW + pix] = st.Cb[0] + st.T[0] * bg2;
+    out_alpha[pix] = st.Wt[0];
+    out_depth[pix] = st.D[0];
+    n_contrib[pix] = st.last[0];
+  }
+}
+
 template <bool WRITE_AUX, int GPI_H, int GPI_L, bool TRACE = false>
 __global__ void __launch_bounds__(256)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -280,6 +453,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
+  __shared__ uint32_t s_qid[RW_WAVES][QCAP];
+  __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WaveTrace tr = {0, 0, 0, 0, 0};
   const uint64_t t_start = TRACE ? wall_clock64() : 0;
@@ -297,10 +472,9 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
     tr_tile = tile; tr_len = re - rb;
-    blend_rect<1, GPI_H, WRITE_AUX, TRACE>(s_rec[wave], lane, rb, re, tx * TILE,
-                                           ty * TILE + wave * 4, W, H, point_list, rec, bg,
-                                           out_color, out_depth, out_alpha, n_contrib, &tr,
-                                           ablate);
+    blend_heavy<TRACE>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
+                       ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
+                       out_alpha, n_contrib, &tr);
   } else {
     const uint32_t li = (b - nheavy) * RW_WAVES + (uint32_t)wave;
     if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
@@ -361,7 +535,7 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     if (__ballot(!alldone) == 0ull) break;
     const uint32_t n = min((uint32_t)WAVE, range.y - base);
     if ((uint32_t)lane < n) {
-      const uint32_t id = point_list[base + lane];
+      const uint32_t id = point_list[base + lane] & ID_MASK;
       const float4* r = rec + (size_t)id * REC_F4;
       my[lane * 2 + 0] = r[0];
       my[lane * 2 + 1] = r[1];
