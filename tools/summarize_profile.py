@@ -1,0 +1,53 @@
+"""Turn the raw rocprofv3 outputs under gpurun_out/ (tools/profile_gpu.sh) into the small,
+tracked summaries under profiles/.  usage: python tools/summarize_profile.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+shutil.copy(os.path.join(OUT, "prof_stats", "stats_kernel_stats.csv"),
+            os.path.join(dst, "%s_kernel_stats.csv" % tag))
+bench = open(os.path.join(OUT, "prof_stats_bench.json")).read().strip().splitlines()[-1]
+open(os.path.join(dst, "%s_bench_under_rocprof.json" % tag), "w").write(bench + "\n")
+
+rows = list(csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_stats.csv"))))
+nf = [int(r["Calls"]) for r in rows if "render_forward" in r["Name"]][0]
+lines = ["# rocprofv3 --kernel-trace --stats of `python bench.py --steps N --warmup 3 --no-cpu-baseline`",
+         "# (%d forward calls: timed frames + warm-up + the untimed V/R statistics pass)" % nf,
+         "# per-frame = TotalDurationNs / forward calls", "",
+         "%10s %8s %10s  %s" % ("us/frame", "calls/fr", "avg us", "kernel")]
+tot = 0.0
+for r in rows:
+    per = float(r["TotalDurationNs"]) / nf / 1000
+    tot += per
+    lines.append("%10.1f %8.1f %10.1f  %s" % (per, int(r["Calls"]) / nf, float(r["AverageNs"]) / 1000,
+                                             r["Name"].split("(")[0][-70:]))
+lines.append("%10.1f  total GPU-busy us per frame" % tot)
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(OUT, "prof_pmc*", "pmc_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("grpg::", "")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k]["duration_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+lines += ["", "# PMC (separate rocprofv3 --pmc passes, mean per dispatch).",
+          "# FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide",
+          "# coalesced reads by 2x on gfx950 (reported raw here, corrected in DESIGN.md)."]
+for k in sorted(agg):
+    if not any(x in k for x in ("render_forward", "preprocess_kernel", "radix_scatter", "emit_kernel",
+                                "radix_hist", "scan_down", "tile_ranges")):
+        continue
+    lines.append("== %s" % k)
+    for c, v in sorted(agg[k].items()):
+        lines.append("   %-24s %16.1f   (n=%d)" % (c, sum(v) / len(v), len(v)))
+open(os.path.join(dst, "%s_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:30]))
