@@ -221,13 +221,14 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     STAGE_CHECK("preprocess");
     tm.mark(1);
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key; culled keys sort last.
+    uint32_t* tiles_sorted = (uint32_t*)(geom + GL.tiles_sorted);
     const bool in_b = radix_sort_pairs(stream, (uint32_t)P, key_a, val_a, key_b, val_b, true, 0, 32,
-                                       table, totals, GL.nchunks_sort);
+                                       table, totals, GL.nchunks_sort, tiles, tiles_sorted);
     const uint32_t* sorted_gid = in_b ? val_b : val_a;  // 4 passes -> back in "a"
     STAGE_CHECK("depth sort");
     tm.mark(2);
-    launch_offsets_scan(stream, (uint32_t)P, sorted_gid, tiles, offsets, block_sums,
-                        GL.nblocks_scan, &gh->R);
+    launch_offsets_scan(stream, (uint32_t)P, tiles_sorted, offsets, block_sums, GL.nblocks_scan,
+                        &gh->R);
     STAGE_CHECK("offsets scan");
     // The one host round trip per frame (reference: rasterizer_impl.cu:284).
     if (!g_pinned_u32) HIP_TRY(hipHostMalloc((void**)&g_pinned_u32, 64, hipHostMallocDefault));

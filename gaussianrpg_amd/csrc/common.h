@@ -57,7 +57,7 @@ constexpr int SC_CHUNK = SC_THREADS * SC_ITEMS;  // 2048 per workgroup
 
 struct GeomLayout {
   size_t total;
-  size_t rec, key_a, key_b, val_a, val_b, tiles, offsets, radii, table, totals, block_sums;
+  size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums;
   uint32_t nchunks_sort, nblocks_scan;
 };
 struct BinLayout {
@@ -82,6 +82,7 @@ inline GeomLayout geom_layout(size_t P) {
   L.val_a = take(P * 4);
   L.val_b = take(P * 4);
   L.tiles = take(P * 4);
+  L.tiles_sorted = take(P * 4);
   L.offsets = take(P * 4);
   L.radii = take(P * 4);
   L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 4);
@@ -141,11 +142,12 @@ void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float
 // (key_b,val_b) is scratch.  Returns true if the result is in the "b" pair, false if in "a".
 bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
                       uint32_t* val_b, bool vals_iota, int begin_bit, int end_bit, uint32_t* table,
-                      uint32_t* totals, uint32_t nchunks);
+                      uint32_t* totals, uint32_t nchunks, const uint32_t* gather_src = nullptr,
+                      uint32_t* gather_dst = nullptr);
 int radix_sort_num_passes(int begin_bit, int end_bit);
 
-// offsets[i] = exclusive prefix sum over tiles[gid[i]]; *total (device) = sum.
-void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* gid, const uint32_t* tiles,
+// offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total (device) = sum.
+void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted,
                          uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
                          uint32_t* total_out);
 

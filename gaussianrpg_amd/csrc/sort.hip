@@ -91,7 +91,8 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                      const uint32_t n, const int shift, const int bits,
                      const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
-                     const uint32_t nchunks) {
+                     const uint32_t nchunks, const uint32_t* __restrict__ gather_src,
+                     uint32_t* __restrict__ gather_dst) {
   __shared__ uint32_t s_cnt[RS_MAX_RADIX * 4];  // [digit][wave]
   __shared__ uint32_t s_gbase[RS_MAX_RADIX];    // global position of local slot 0 of each digit
   __shared__ uint32_t s_wave[4];
@@ -169,13 +170,18 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const uint32_t d = (k >> shift) & mask;
     const uint32_t g = s_gbase[d] + j;
     keys_out[g] = k;
-    vals_out[g] = s_vals[j];
+    const uint32_t v = s_vals[j];
+    vals_out[g] = v;
+    // last pass of the depth sort: also emit the per-Gaussian tile count in sorted order, so the
+    // offsets scan streams a contiguous array instead of gathering tiles[gid[i]]
+    if (gather_src) gather_dst[g] = gather_src[v];
   }
 }
 
 bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
                       uint32_t* val_b, bool vals_iota, int begin_bit, int end_bit, uint32_t* table,
-                      uint32_t* totals, uint32_t nchunks) {
+                      uint32_t* totals, uint32_t nchunks, const uint32_t* gather_src,
+                      uint32_t* gather_dst) {
   bool in_b = false;
   if (n == 0) return in_b;
   const int nbits = end_bit - begin_bit;
@@ -194,7 +200,7 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_
     radix_digit_scan_kernel<<<1u << bits, 256, 0, s>>>(table, nchunks, totals);
     radix_scatter_kernel<<<nchunks, RS_THREADS, 0, s>>>(
         kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, shift, bits, table, totals,
-        nchunks);
+        nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst);
     in_b = !in_b;
     shift += bits;
   }
@@ -207,20 +213,20 @@ int radix_sort_num_passes(int begin_bit, int end_bit) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Exclusive scan of tiles[gid[i]] (the per-Gaussian instance counts, visited in depth-sorted
-// order) -> offsets[i]; replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:280).
+// Exclusive scan of the per-Gaussian instance counts in depth-sorted order (written contiguously
+// by the last depth-sort pass) -> offsets[i]; replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:280).
 // Three launches: per-workgroup reduce, single-workgroup spine scan, per-workgroup downsweep.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SC_THREADS)
-scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ gid,
-                   const uint32_t* __restrict__ tiles, uint32_t* __restrict__ block_sums) {
+scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
+                   uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t s_wave[4];
   const uint32_t base = blockIdx.x * SC_CHUNK;
   uint32_t s = 0;
 #pragma unroll
   for (int k = 0; k < SC_ITEMS; k++) {
     const uint32_t i = base + k * SC_THREADS + threadIdx.x;
-    if (i < n) s += tiles[gid[i]];
+    if (i < n) s += tiles[i];
   }
   uint32_t tot;
   block_exclusive_scan_256(s, s_wave, &tot);
@@ -244,9 +250,8 @@ scan_spine_kernel(uint32_t* __restrict__ block_sums, const uint32_t nblocks,
 }
 
 __global__ void __launch_bounds__(SC_THREADS)
-scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ gid,
-                 const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ block_sums,
-                 uint32_t* __restrict__ offsets) {
+scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
+                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets) {
   __shared__ uint32_t s_wave[4];
   // thread t owns SC_ITEMS consecutive elements so that the scan order is the array order
   const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
@@ -254,7 +259,7 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ gid,
 #pragma unroll
   for (int k = 0; k < SC_ITEMS; k++) {
     const uint32_t i = base + k;
-    v[k] = i < n ? tiles[gid[i]] : 0;
+    v[k] = i < n ? tiles[i] : 0;
     s += v[k];
   }
   uint32_t tot;
@@ -267,13 +272,13 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ gid,
   }
 }
 
-void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* gid, const uint32_t* tiles,
+void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted,
                          uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
                          uint32_t* total_out) {
   if (n == 0) return;
-  scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, gid, tiles, block_sums);
+  scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums);
   scan_spine_kernel<<<1, 256, 0, s>>>(block_sums, nblocks, total_out);
-  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, gid, tiles, block_sums, offsets);
+  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums, offsets);
 }
 
 }  // namespace grpg

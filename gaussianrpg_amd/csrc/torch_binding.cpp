@@ -32,6 +32,14 @@ const float* fptr(const torch::Tensor& t, const torch::Tensor& like, const char*
 
 char* resize_blob(size_t bytes, void* user) {   // replaces resizeFunctional, rasterize_points.cu:27-33
   auto* t = static_cast<torch::Tensor*>(user);
+  // num_rendered changes a little from frame to frame; round the request up to 1/8-octave steps so
+  // the caching allocator keeps handing back the same blocks instead of growing its pools
+  // (a pool growth is a hipMalloc, i.e. a device-wide sync in the middle of the frame loop)
+  if (bytes > (1u << 20)) {
+    size_t step = 1;
+    while ((step << 4) <= bytes) step <<= 1;   // step = 2^floor(log2(bytes)) / 8
+    bytes = (bytes + step - 1) / step * step;
+  }
   t->resize_({static_cast<long long>(bytes)});
   return reinterpret_cast<char*>(t->data_ptr());
 }
