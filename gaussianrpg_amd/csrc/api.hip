@@ -348,7 +348,8 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   const uint32_t* n_contrib = (const uint32_t*)(image_buffer + IL.n_contrib);
 
   launch_render_backward(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
-                         cam.gy, background, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas,
+                         cam.gy, background, alphas, n_contrib,
+                         (const uint32_t*)(image_buffer + IL.work), dL_dpix, dL_dpix_depth, dL_dalphas,
                          dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                          dL_ddepth, dL_dsemantic);
   STAGE_CHECK("render backward");

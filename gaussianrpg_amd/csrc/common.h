@@ -169,7 +169,7 @@ void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* 
 void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const float4* rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, const float* bg, const float* alphas,
-                            const uint32_t* n_contrib, const float* dL_dpix,
+                            const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
                             const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dconic,
                             float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,

@@ -5,14 +5,22 @@
 // gradients w.r.t. colour / depth / semantic / accumulated alpha / background (:556-614) pushed to
 // (mean2D, conic, opacity, colour, depth, semantic) of every contributing Gaussian (:618-638).
 //
-// CDNA4 mapping: the reference issues 11+S float atomics per (pixel, Gaussian) pair.  Here one
-// wave64 owns a 16x16 tile with 4 pixels per lane (same layout as the forward); the 11+S partial
-// gradients of a splat are summed over the lane's 4 pixels in registers, reduced across the wave
-// with 6 DPP adds each (quad_perm, row_half_mirror, row_mirror, row_bcast15, row_bcast31 -- no LDS
-// traffic) and lane 63 issues ONE hardware global_atomic_add_f32 per field per (tile, Gaussian):
-// 256x fewer atomics than the reference.  Summation order differs from the reference's
-// (unspecified) atomic order, so gradients agree to rounding, not bitwise -- exactly as two runs of
-// the reference differ from each other.
+// CDNA4 mapping (same decomposition as the forward, render_fwd.hip, whose tile work lists in the
+// image blob are reused):
+//   * LIGHT tiles: one wave per tile, 4 pixels per lane.  HEAVY tiles: four 16x4 quarter-tile
+//     waves at 1 pixel per lane (a heavy tile no longer serialises behind one wave).
+//   * Per batch of 64 list entries (walked back to front, only up to the deepest contributor of
+//     the wave's pixels) a lane first looks at the sub-tile mask that emit stored in the point-list
+//     entry: the 48-byte record of a splat that cannot reach the wave's pixels is never loaded.
+//     Survivors are culled against the wave's pixel rectangle, compacted (deepest first) into the
+//     wave's LDS slice and only those are evaluated.
+//   * The reference issues 11+S float atomics per (pixel, Gaussian) pair.  Here the 11+S partial
+//     gradients of a splat are summed over the lane's pixels in registers, reduced across the wave
+//     with 6 DPP adds each (quad_perm x2, row_half_mirror, row_mirror, row_bcast15, row_bcast31 --
+//     no LDS traffic) and lane 63 issues ONE hardware global_atomic_add_f32 per field per
+//     (wave, Gaussian): 64-256x fewer atomics.  Summation order differs from the reference's
+//     (unspecified) atomic order, so gradients agree to rounding, not bitwise -- exactly as two
+//     runs of the reference differ from each other.
 #include "blend_math.h"
 #include "common.h"
 
@@ -43,41 +51,37 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
-template <int SMAX>
-__global__ void __launch_bounds__(256)
-render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                       const float4* __restrict__ rec, const float* __restrict__ semantics,
-                       const int S, const int W, const int H, const int gx, const int ntiles,
-                       const float* __restrict__ bg, const float* __restrict__ alphas,
-                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                       const float* __restrict__ dL_dpix_depth,
-                       const float* __restrict__ dL_dalphas,
-                       const float* __restrict__ dL_dpix_semantic, float* __restrict__ dL_dmean2D,
-                       float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-                       float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
-                       float* __restrict__ dL_dsemantic) {
-  __shared__ float4 s_rec[RB_WAVES][WAVE * REC_F4];
-  __shared__ uint32_t s_id[RB_WAVES][WAVE];
+// One wave, PX pixels per lane: rows y0 + (lane>>4)*PX + k.  bits_mask selects the sub-tile bits
+// of a point-list entry that concern this wave (one bit for a quarter, all four for a whole tile).
+template <int PX, int SMAX>
+__device__ __forceinline__ void backward_rect(
+    float4* __restrict__ my, const int lane, const uint32_t r_begin, const uint32_t r_end,
+    const int x0, const int y0, const uint32_t bits_mask, const int W, const int H, const int S,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    const float* __restrict__ semantics, const float* __restrict__ bg,
+    const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
+    const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpix_semantic,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
+    float* __restrict__ dL_dsemantic) {
   constexpr int SM = SMAX > 0 ? SMAX : 1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * RB_WAVES + wave;
-  if (tile >= ntiles) return;
-  const int ty = tile / gx, tx = tile - ty * gx;
-  const int px = tx * TILE + (lane & 15);
-  const int py0 = ty * TILE + (lane >> 4) * 4;
+  const int px = x0 + (lane & 15);
+  const int py0 = y0 + (lane >> 4) * PX;
   const float pxf = (float)px;
-  const uint2 range = ranges[tile];
+  const float rx0 = (float)x0, rx1 = (float)(x0 + 15);
+  const float ry0 = (float)y0, ry1 = (float)(y0 + 4 * PX - 1);
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-  float T[4], T_final[4], dLr[4], dLg[4], dLb[4], dLd[4], dLa[4], bgdot[4];
-  float acc_r[4], acc_g[4], acc_b[4], acc_d[4], acc_a[4], last_alpha[4], last_r[4], last_g[4],
-      last_b[4], last_d[4];
-  float dLs[4][SM], acc_s[4][SM], last_s[4][SM];
-  uint32_t lastc[4];
+  float T[PX], T_final[PX], dLr[PX], dLg[PX], dLb[PX], dLd[PX], dLa[PX], bgdot[PX];
+  float acc_r[PX], acc_g[PX], acc_b[PX], acc_d[PX], acc_a[PX], last_alpha[PX], last_r[PX],
+      last_g[PX], last_b[PX], last_d[PX];
+  float dLs[PX][SM], acc_s[PX][SM], last_s[PX][SM];
+  uint32_t lastc[PX];
   uint32_t maxlast = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < PX; k++) {
     const int py = py0 + k;
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)py * W + px : 0;
@@ -103,27 +107,39 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   maxlast = wave_max_u32(maxlast);   // nothing behind the tile's deepest contributor matters
   const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:501-502
 
-  float4* my = s_rec[wave];
-  uint32_t* myid = s_id[wave];
-  const uint32_t count = min(range.y - range.x, maxlast);
+  const uint64_t gt = ~(lanemask_lt() | (1ull << lane));   // lanes above this one
+  const uint32_t count = min(r_end - r_begin, maxlast);
   for (uint32_t hi = count; hi > 0;) {
     const uint32_t n = hi >= (uint32_t)WAVE ? (uint32_t)WAVE : hi;
     const uint32_t lo = hi - n;   // batch covers list positions [lo, hi)
+    bool keep = false;
+    float4 la = make_float4(0, 0, 0, 0), lb = la, lc = la;
+    uint32_t lid = 0;
     if ((uint32_t)lane < n) {
-      const uint32_t id = point_list[range.x + lo + lane] & ID_MASK;
-      const float4* r = rec + (size_t)id * REC_F4;
-      my[lane * REC_F4 + 0] = r[0];
-      my[lane * REC_F4 + 1] = r[1];
-      my[lane * REC_F4 + 2] = r[2];
-      myid[lane] = id;
+      const uint32_t v = point_list[r_begin + lo + lane];
+      if (v & bits_mask) {   // the splat can reach this wave's pixels: only now touch its record
+        lid = v & ID_MASK;
+        const float4* r = rec + (size_t)lid * REC_F4;
+        la = r[0]; lb = r[1]; lc = r[2];
+        keep = !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);
+      }
+    }
+    const uint64_t mask = __ballot(keep);
+    const int cnt = (int)__popcll(mask);
+    if (keep) {   // deepest entry (highest lane) first
+      const int slot = (int)__popcll(mask & gt);
+      my[slot * REC_F4 + 0] = la;
+      my[slot * REC_F4 + 1] = lb;
+      my[slot * REC_F4 + 2] = make_float4(lc.x, lc.y, __uint_as_float(lo + (uint32_t)lane),
+                                          __uint_as_float(lid));
     }
     __builtin_amdgcn_wave_barrier();
-    for (int j = (int)n - 1; j >= 0; j--) {
+    for (int j = 0; j < cnt; j++) {
       const float4 a = my[j * REC_F4 + 0];   // px, py, depth, opacity
       const float4 b = my[j * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
-      const float4 c = my[j * REC_F4 + 2];   // G, B
-      const uint32_t gid = myid[j];
-      const uint32_t pos = lo + (uint32_t)j;   // 0-based position == reference's `contributor`
+      const float4 c = my[j * REC_F4 + 2];   // G, B, list position, Gaussian id
+      const uint32_t pos = __float_as_uint(c.z);   // 0-based == the reference's `contributor`
+      const uint32_t gid = __float_as_uint(c.w);
       const float dx = a.x - pxf;
       const SplatTerms st = splat_terms(dx, b.x, b.y, b.z);
       float g_mx = 0.f, g_my = 0.f, g_mabs = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f;
@@ -133,7 +149,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
       for (int cc = 0; cc < SM; cc++) g_s[cc] = 0.f;
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < PX; k++) {
         const float dy = a.y - (float)(py0 + k);
         float G, alpha;   // identical arithmetic to the forward (blend_math.h)
         const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]);
@@ -230,27 +246,74 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   }
 }
 
+// Work lists: written by the forward's classify_tiles_kernel (render_fwd.hip) into the image blob:
+// counts[4] (three heavy classes, light), then four lists of T tile ids.
+constexpr int NUM_CLASSES_B = 4;
+
+template <int SMAX>
+__global__ void __launch_bounds__(256)
+render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                       const float4* __restrict__ rec, const float* __restrict__ semantics,
+                       const int S, const int W, const int H, const int gx, const uint32_t T,
+                       const uint32_t* __restrict__ work, const float* __restrict__ bg,
+                       const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
+                       const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
+                       const float* __restrict__ dL_dalphas,
+                       const float* __restrict__ dL_dpix_semantic, float* __restrict__ dL_dmean2D,
+                       float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                       float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
+                       float* __restrict__ dL_dsemantic) {
+  __shared__ float4 s_rec[RB_WAVES][WAVE * REC_F4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
+  const uint32_t nheavy = n0 + n1 + n2;
+  const uint32_t b = blockIdx.x;
+  const uint32_t* lists = work + NUM_CLASSES_B;
+  uint32_t tile;
+  if (b < nheavy) {
+    tile = b < n0 ? lists[b] : (b < n0 + n1 ? lists[T + (b - n0)] : lists[2 * T + (b - n0 - n1)]);
+  } else {
+    const uint32_t li = (b - nheavy) * RB_WAVES + (uint32_t)wave;
+    if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
+    tile = lists[3 * (size_t)T + li];
+  }
+  const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+  const uint2 range = ranges[tile];
+  const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+  const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+#define RB_CALL(PXV, YOFF, BITS)                                                                  \
+  backward_rect<PXV, SMAX>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE + (YOFF), (BITS), W, H, \
+                           S, point_list, rec, semantics, bg, alphas, n_contrib, dL_dpix,          \
+                           dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic,     \
+                           dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic)
+  if (b < nheavy)
+    RB_CALL(1, wave * 4, 1u << (SUBTILE_SHIFT + wave));
+  else
+    RB_CALL(4, 0, 0xFu << SUBTILE_SHIFT);
+#undef RB_CALL
+}
+
 void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const float4* rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, const float* bg, const float* alphas,
-                            const uint32_t* n_contrib, const float* dL_dpix,
+                            const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
                             const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dconic,
                             float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
                             float* dL_dsemantic) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
-  const int blocks = (ntiles + RB_WAVES - 1) / RB_WAVES;
-#define RB_ARGS                                                                                 \
-  ranges, point_list, rec, semantics, S, W, H, gx, ntiles, bg, alphas, n_contrib, dL_dpix,      \
-      dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity,          \
+#define RB_ARGS                                                                                  \
+  ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
+      dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity,  \
       dL_dcolor, dL_ddepth, dL_dsemantic
+  // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
   if (S <= 0)
-    render_backward_kernel<0><<<blocks, 256, 0, s>>>(RB_ARGS);
+    render_backward_kernel<0><<<ntiles, 256, 0, s>>>(RB_ARGS);
   else if (S <= 4)
-    render_backward_kernel<4><<<blocks, 256, 0, s>>>(RB_ARGS);
+    render_backward_kernel<4><<<ntiles, 256, 0, s>>>(RB_ARGS);
   else
-    render_backward_kernel<32><<<blocks, 256, 0, s>>>(RB_ARGS);   // S <= 32 (reference: 20)
+    render_backward_kernel<32><<<ntiles, 256, 0, s>>>(RB_ARGS);   // S <= 32 (reference: 20)
 #undef RB_ARGS
 }
 
