@@ -443,8 +443,11 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   }
 }
 
+#ifndef GRPG_RENDER_MIN_WAVES
+#define GRPG_RENDER_MIN_WAVES 5   // waves per SIMD the register allocator must fit (<= 96 VGPRs)
+#endif
 template <bool WRITE_AUX, int GPI_H, int GPI_L, bool TRACE = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, GRPG_RENDER_MIN_WAVES)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float4* __restrict__ rec, const int W, const int H, const int gx,
                       const uint32_t T, const uint32_t* __restrict__ work,
