@@ -85,8 +85,8 @@ inline GeomLayout geom_layout(size_t P) {
   L.tiles_sorted = take(P * 4);
   L.offsets = take(P * 4);
   L.radii = take(P * 4);
-  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 4);
-  L.totals = take(RS_MAX_RADIX * 4);
+  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);   // u32 table or u64 status words
+  L.totals = take(4 * RS_MAX_RADIX * 4);
   L.block_sums = take(((size_t)L.nblocks_scan + 1) * 4);
   L.total = o;
   return L;
@@ -100,8 +100,8 @@ inline BinLayout bin_layout(size_t R) {
   L.key_a = take(R * 4);   // == sorted tile ids
   L.key_b = take(R * 4);
   L.val_b = take(R * 4);
-  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 4);
-  L.totals = take(RS_MAX_RADIX * 4);
+  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);
+  L.totals = take(4 * RS_MAX_RADIX * 4);
   L.total = o;
   return L;
 }
