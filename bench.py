@@ -129,12 +129,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs ROCm devices (no CPU fallback exists)"
     torch.set_num_threads(max(1, min(effective_cores() // max(world, 1), 16)))   # host-side scene synthesis
+    # GRPG_BENCH_BACKEND=gloo is a single-GPU debugging aid only (all ranks share cuda:0, the
+    # final gather is staged through host memory); the real multi-GPU run uses RCCL ("nccl").
+    backend = os.environ.get("GRPG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank,
-                                device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", world_size=world,
+                                    rank=rank, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from gaussianrpg_amd.rasterizer import _C
@@ -168,10 +176,11 @@ def main():
         gather_bufs = None
         if world > 1:
             import torch.distributed as dist
+            cdev = dev if backend == "nccl" else torch.device("cpu")
             if rank == 0:
-                gather_bufs = [torch.empty_like(local) for _ in range(world)]
+                gather_bufs = [torch.empty(local.shape, dtype=local.dtype, device=cdev) for _ in range(world)]
             # warm the communicator outside the timed region
-            tiny = torch.zeros(1, device=dev)
+            tiny = torch.zeros(1, device=cdev)
             dist.all_reduce(tiny)
         torch.cuda.synchronize()
 
@@ -191,7 +200,7 @@ def main():
         for st_ in streams:
             torch.cuda.current_stream().wait_stream(st_)
         if world > 1:
-            dist.gather(local, gather_list=gather_bufs, dst=0)
+            dist.gather(local if backend == "nccl" else local.cpu(), gather_list=gather_bufs, dst=0)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -209,7 +218,7 @@ def main():
 
         elapsed = t1 - t0
         if world > 1:
-            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 

@@ -24,6 +24,15 @@ __device__ __forceinline__ float ndc2pix(float v, int S) {
   return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
 }
 
+// [P,4] quaternion: one 16-byte load when the array is 16-byte aligned (always, for a tensor
+// torch allocated), four dword loads for an offset view.
+__device__ __forceinline__ float4 load_quat(const float* __restrict__ rotations, const int idx) {
+  if ((reinterpret_cast<uintptr_t>(rotations) & 15) == 0)
+    return reinterpret_cast<const float4*>(rotations)[idx];
+  return make_float4(rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2],
+                     rotations[4 * idx + 3]);
+}
+
 struct Projected {
   float px, py, depth;
   float conic[3];

@@ -26,9 +26,9 @@ namespace grpg {
 
 // Everything up to the tile rectangle.  Returns false if the Gaussian is culled
 // (near plane, det==0, empty rectangle) -- forward.cu:192-237.
-__device__ __forceinline__ bool project_and_bound(const int idx, const float* __restrict__ means3D,
-                                                  const float* __restrict__ scales,
-                                                  const float scale_modifier,
+__device__ __forceinline__ bool project_and_bound(const int idx, const float mx, const float my,
+                                                  const float mz, const float s0, const float s1,
+                                                  const float s2, const float scale_modifier,
                                                   const float* __restrict__ rotations,
                                                   const float* __restrict__ cov3D_precomp,
                                                   const float* __restrict__ view,
@@ -37,7 +37,6 @@ __device__ __forceinline__ bool project_and_bound(const int idx, const float* __
                                                   const float tan_fovx, const float tan_fovy,
                                                   const float focal_x, const float focal_y,
                                                   Projected& o) {
-  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
   // in_frustum, auxiliary.h:139-164
   const float hx = proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12];
   const float hy = proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13];
@@ -50,9 +49,8 @@ __device__ __forceinline__ bool project_and_bound(const int idx, const float* __
 #pragma unroll
     for (int i = 0; i < 6; i++) o.cov3d[i] = cov3D_precomp[6 * idx + i];
   } else {
-    const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-    cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2],
-                         scale_modifier, q, o.cov3d);
+    const float4 q = load_quat(rotations, idx);
+    cov3d_from_scale_rot(s0, s1, s2, scale_modifier, q, o.cov3d);
   }
   Cov2D cv;
   cov2d_project(mx, my, mz, view, focal_x, focal_y, tan_fovx, tan_fovy, o.cov3d, cv);
@@ -121,11 +119,41 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   const int H, const int gx, const int gy, const float tan_fovx,
                   const float tan_fovy, const float focal_x, const float focal_y,
                   int* __restrict__ radii, float4* __restrict__ rec,
-                  uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+                  uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
+                  const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
+  // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
+  // loads.  Stage the workgroup's 256 x 12 B = 3 KB per array through LDS with 16-byte loads
+  // instead (the slab of workgroup b starts at byte 3072*b, so it is 16-byte aligned).
+  __shared__ float s_mean[256 * 3];
+  __shared__ float s_scale[256 * 3];
+  const int base = blockIdx.x * 256;
+  const int nval = min(256, P - base) * 3;   // floats in this workgroup's slab
+  {
+    const int t4 = threadIdx.x * 4;
+    if (vec_ok && t4 + 3 < nval) {
+      reinterpret_cast<float4*>(s_mean)[threadIdx.x] =
+          reinterpret_cast<const float4*>(means3D + (size_t)base * 3)[threadIdx.x];
+      if (scales != nullptr)
+        reinterpret_cast<float4*>(s_scale)[threadIdx.x] =
+            reinterpret_cast<const float4*>(scales + (size_t)base * 3)[threadIdx.x];
+    } else if (t4 < nval) {
+      for (int e = t4; e < min(t4 + 4, nval); e++) {
+        s_mean[e] = means3D[(size_t)base * 3 + e];
+        if (scales != nullptr) s_scale[e] = scales[(size_t)base * 3 + e];
+      }
+    }
+  }
+  __syncthreads();
+  const int idx = base + threadIdx.x;
   if (idx >= P) return;
+  const float mx = s_mean[3 * threadIdx.x], my = s_mean[3 * threadIdx.x + 1],
+              mz = s_mean[3 * threadIdx.x + 2];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (scales != nullptr) {
+    s0 = s_scale[3 * threadIdx.x]; s1 = s_scale[3 * threadIdx.x + 1]; s2 = s_scale[3 * threadIdx.x + 2];
+  }
   Projected o;
-  const bool vis = project_and_bound(idx, means3D, scales, scale_modifier, rotations,
+  const bool vis = project_and_bound(idx, mx, my, mz, s0, s1, s2, scale_modifier, rotations,
                                      cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
                                      focal_x, focal_y, o);
   if (!vis) {
@@ -137,10 +165,17 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   float rgb[3];
   uint32_t clamped = 0;
   if (colors_precomp == nullptr) {
-    const float dx = means3D[3 * idx] - campos[0];
-    const float dy = means3D[3 * idx + 1] - campos[1];
-    const float dz = means3D[3 * idx + 2] - campos[2];
-    sh_to_rgb(D, shs + (size_t)idx * M * 3, dx, dy, dz, rgb, clamped);
+    const float dx = mx - campos[0];
+    const float dy = my - campos[1];
+    const float dz = mz - campos[2];
+    if (M == 4 && vec_ok) {   // degree <= 1, every shipped config: 48 B per Gaussian as three 16-byte loads
+      const float4* sp = reinterpret_cast<const float4*>(shs + (size_t)idx * 12);
+      const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+      const float sh12[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+      sh_to_rgb(D > 1 ? 1 : D, sh12, dx, dy, dz, rgb, clamped);
+    } else {
+      sh_to_rgb(D, shs + (size_t)idx * M * 3, dx, dy, dz, rgb, clamped);
+    }
   } else {
     rgb[0] = colors_precomp[3 * idx];
     rgb[1] = colors_precomp[3 * idx + 1];
@@ -166,7 +201,11 @@ visible_filter_kernel(const int P, const float* __restrict__ means3D,
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= P) return;
   Projected o;
-  const bool vis = project_and_bound(idx, means3D, scales, scale_modifier, rotations,
+  const bool has_s = scales != nullptr;
+  const bool vis = project_and_bound(idx, means3D[3 * idx], means3D[3 * idx + 1],
+                                     means3D[3 * idx + 2], has_s ? scales[3 * idx] : 0.f,
+                                     has_s ? scales[3 * idx + 1] : 0.f,
+                                     has_s ? scales[3 * idx + 2] : 0.f, scale_modifier, rotations,
                                      cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
                                      focal_x, focal_y, o);
   radii[idx] = vis ? o.radius : 0;
@@ -195,7 +234,8 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
       colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
-      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles);
+      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles,
+      ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
 }
 
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,

@@ -173,7 +173,7 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
 #pragma unroll
     for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
   } else {
-    q = reinterpret_cast<const float4*>(rotations)[idx];
+    q = load_quat(rotations, idx);
     cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2],
                          scale_modifier, q, c3);
   }

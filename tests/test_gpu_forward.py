@@ -264,3 +264,26 @@ def test_pack_u8(dev):
     ref = tj.pack_u8(x)
     assert got.dtype == torch.uint8 and got.shape == ref.shape
     assert int((got.int() - ref.int()).abs().max()) == 0
+
+
+def test_misaligned_input_views(dev):
+    """Inputs that are offset views (data pointer not 16-byte aligned) take the scalar-load path of
+    preprocess and must give identical results."""
+    sc, cam = hz.toy_scene(1000, seed=18, sh_degree=1), hz.trajectory_camera(0, W=96, H=64)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, 1))
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    camd = hz.trajectory_camera(0, W=96, H=64, device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 1)))
+
+    def shifted(t):     # contiguous view starting 4 bytes into a larger allocation
+        flat = torch.zeros(t.numel() + 1, device=dev)
+        flat[1:] = t.reshape(-1).to(dev)
+        v = flat[1:].view(t.shape)
+        assert v.is_contiguous() and v.data_ptr() % 16 != 0
+        return v
+    color, radii, depth, alpha, _ = rast(means3D=shifted(sc.means3D), means2D=None,
+                                         opacities=sc.opacity.to(dev), shs=shifted(sc.shs),
+                                         scales=shifted(sc.scales), rotations=shifted(sc.rotations))
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    assert_image_close("color", color.cpu().numpy(), o["color"], o["fragile"])
