@@ -250,12 +250,23 @@ def main():
         render_ms = stages["render"]
         b_render = 44.0 * R_avg + 8.0 * T_tiles + 20.0 * N
         b_frame = P * (48 + 12 * M) + 40.0 * V_avg + 88.0 * R_avg + 16.0 * T_tiles + 20.0 * N
+        # HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_gpu.sh
+        # (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), if a profile of
+        # this same workload has been committed; otherwise null.
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
+            wl = tr.get("workload", {})
+            if wl.get("P") == P and wl.get("width") == W and wl.get("height") == H:
+                traffic = tr["render_forward_kernel"]["hbm_bytes_corrected"]
+        except Exception:
+            traffic = None
         roof = None
         if render_ms:
             ach = b_render / (render_ms * 1e-3) / 1e9
             roof = {"kernel": "render_forward_kernel", "bound": "hbm", "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": b_render,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": b_render,
                     "avg_launch_ms": render_ms,
                     "note": "render is VALU-bound (about 25 flop per pixel-splat pair), see DESIGN.md §6"}
         ach_f = b_frame / (ms_per_step * 1e-3) / 1e9

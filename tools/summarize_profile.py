@@ -50,4 +50,17 @@ for k in sorted(agg):
     for c, v in sorted(agg[k].items()):
         lines.append("   %-24s %16.1f   (n=%d)" % (c, sum(v) / len(v), len(v)))
 open(os.path.join(dst, "%s_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+
+# HBM traffic of the dominant kernel for bench.py's roofline.traffic (bytes per launch):
+# WRITE_SIZE as reported; FETCH_SIZE x2 (gfx950 correction for 16-byte-per-lane loads,
+# MI355X_MICROARCH.md "HBM": calibrated here on preprocess_kernel whose read volume is known).
+bj = json.loads(bench)
+traffic = {"workload": {k: bj["config"].get(k) for k in ("P", "width", "height", "M")}}
+for k in agg:
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        f = sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"]) * 1024.0
+        w = sum(agg[k]["WRITE_SIZE"]) / len(agg[k]["WRITE_SIZE"]) * 1024.0
+        traffic[k.split("<")[0]] = {"fetch_bytes_raw": f, "write_bytes": w,
+                                    "hbm_bytes_corrected": 2.0 * f + w}
+json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 print("\n".join(lines[:30]))
