@@ -11,21 +11,24 @@
 //     LIGHT tiles (short lists): one wave owns the whole 16x16 tile, 4 vertically adjacent pixels
 //     per lane -- a splat's 48-byte record is broadcast from LDS once per wave whether a lane
 //     shades 1 pixel or 4, so LDS traffic per pixel-pair drops 4x and the dx-only terms of the
-//     quadratic are shared.  HEAVY tiles (a street scene's horizon tiles hold up to ~35 k splats
-//     and would serialise the whole frame behind one wave): the tile is split into four 16x4
-//     sub-tiles, one wave each at 1 pixel per lane, 4 splats per iteration for ILP.
-//   * A tile-classification pre-pass builds the two work lists; heavy tiles are dispatched first
-//     (longest-processing-time-first) from the same launch.
-//   * Each wave stages batches of 64 splat records (one 48-byte gather per lane) into its private
-//     3 KB LDS slice.  While staging, every lane runs a CONSERVATIVE rectangle cull for "its"
-//     splat (exact minimum of the conic's quadratic over the wave's pixel rectangle,
-//     blend_math.h); a 64-bit ballot of the survivors drives the inner loop, so splats that
-//     cannot reach any pixel of the (sub-)tile cost ~1/64 of a lane-op instead of a full
-//     evaluation.  The reference bins by the 3-sigma bounding SQUARE, so a large share of the
-//     list never touches the tile.
-//   * The blend part of an iteration is skipped wave-uniformly when no lane accepted the splat.
-//   * Wave-uniform early exit via ballot when every pixel of the wave is saturated.
-// The kernel is VALU-bound (about 25 flop-equivalents per surviving pixel-splat pair), not
+//     quadratic are shared.  HEAVY tiles (>= heavy_min entries; a street scene's horizon tiles
+//     hold up to ~35 k splats and would serialise the whole frame behind one wave): four 16x4
+//     quarter-tile waves at 1 pixel per lane, fed through an LDS ring (blend_heavy below).
+//   * A tile-classification pre-pass builds the work lists; the longest lists are dispatched
+//     first (longest-processing-time-first) from the same launch.
+//   * emit (binning.hip) stores a 4-bit mask in the top bits of every point-list entry: which
+//     16x4 quarters of the tile the splat can reach at all (exact minimum of the conic's
+//     quadratic over the quarter's rectangle, blend_math.h).  A record is only ever loaded for an
+//     entry whose mask concerns the wave.  The reference bins by the 3-sigma bounding SQUARE, so
+//     about 2/3 of the (quarter, entry) pairs are dead.
+//   * Surviving records are culled once more against the bounding box of the wave's still-LIVE
+//     pixels (shrinks as pixels saturate), compacted with ballot + popcount into the wave's
+//     private LDS slice, and only those are evaluated, G at a time (independent alpha chains for
+//     ILP, then the in-order blend).  Decisions per pixel are unchanged: both culls only remove
+//     splats that every pixel of the rectangle would reject.
+//   * The blend part of a group is skipped wave-uniformly when no lane accepted a splat;
+//     wave-uniform early exit via ballot when every pixel of the wave is saturated.
+// The kernel is VALU-issue-bound (about 25 flop-equivalents per surviving pixel-splat pair), not
 // HBM-bound; its compulsory HBM traffic is 4 B (id) + 40 B (record fields) per tile instance
 // + 20 B per pixel.
 #include <cstdio>
