@@ -4,39 +4,76 @@
 // Reference semantics (cuda_rasterizer/forward.cu:410-432, backward.cu:526-544):
 //   power = -0.5 (a dx^2 + c dy^2) - b dx dy ;  reject if power > 0
 //   alpha = min(0.99, opacity * exp(power))  ;  reject if alpha < 1/255
-// Evaluated here as  power = hA - dy * (hc*dy + bdx)  with hA = -0.5 a dx^2, bdx = b dx,
-// hc = 0.5 c  (two FMAs per pixel, dx-only terms shared by the pixels of a lane) and
-// exp(x) = v_exp_f32(x * log2 e).  Differences to the oracle's unfused fp32 evaluation are a few
-// ulp of the largest term; the parity tests allow the other branch only on pixels the oracle
-// flags as threshold-fragile.
+// Evaluated here in base 2 with the conic pre-scaled once per splat,
+//   A = -0.5 log2(e) a,  B = -log2(e) b,  C = -0.5 log2(e) c          (splat_q, 3 multiplies)
+//   power2 = log2(e) power = (A dx) dx + dy (C dy + B dx)             (3 mul + 2 fma per pair)
+//   exp(power) = v_exp_f32(power2)                                     (no per-pair scaling)
+// and power > 0  <=>  power2 > 0.  Every step is an explicit multiply or fma (nothing the compiler
+// may contract differently in two kernels), so the forward, the semantic pass and the backward
+// get bit-identical power2 / G / alpha whether they run the scalar or the packed (v_pk_*) form.
+// Differences to the oracle's unfused natural-base fp32 evaluation are a few ulp of the largest
+// term; the parity tests allow the other branch only on pixels the oracle flags as
+// threshold-fragile.
 #pragma once
 #include "common.h"
 
 namespace grpg {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+
+struct SplatQ {       // pre-scaled conic of one splat
+  float A, B, C;
+};
+
+__device__ __forceinline__ SplatQ splat_q(const float cx, const float cy, const float cz) {
+  SplatQ q;
+  q.A = (-0.5f * LOG2E) * cx;
+  q.B = (-LOG2E) * cy;
+  q.C = (-0.5f * LOG2E) * cz;
+  return q;
+}
+
 struct SplatTerms {   // per (lane, splat): everything that does not depend on the pixel row
   float hA, bdx, hc;
 };
 
-__device__ __forceinline__ SplatTerms splat_terms(const float dx, const float cx, const float cy,
-                                                  const float cz) {
+__device__ __forceinline__ SplatTerms splat_terms_q(const float dx, const SplatQ q) {
   SplatTerms t;
-  t.hA = -0.5f * cx * dx * dx;
-  t.bdx = cy * dx;
-  t.hc = 0.5f * cz;
+  t.hA = (q.A * dx) * dx;
+  t.bdx = q.B * dx;
+  t.hc = q.C;
   return t;
 }
 
-__device__ __forceinline__ float pair_power(const SplatTerms& t, const float dy) {
-  return fmaf(-dy, fmaf(t.hc, dy, t.bdx), t.hA);
+__device__ __forceinline__ SplatTerms splat_terms(const float dx, const float cx, const float cy,
+                                                  const float cz) {
+  return splat_terms_q(dx, splat_q(cx, cy, cz));
 }
 
-// alpha and G = exp(power); returns true if the pair passes both reference tests.
-__device__ __forceinline__ bool pair_alpha(const float power, const float opacity, float& G,
+// power2 = log2(e) * power
+__device__ __forceinline__ float pair_power(const SplatTerms& t, const float dy) {
+  return fmaf(dy, fmaf(t.hc, dy, t.bdx), t.hA);
+}
+
+// alpha and G = exp(power) = 2^power2; returns true if the pair passes both reference tests.
+__device__ __forceinline__ bool pair_alpha(const float power2, const float opacity, float& G,
                                            float& alpha) {
-  G = __expf(power);
-  alpha = fminf(0.99f, opacity * G);
-  return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+  G = __builtin_amdgcn_exp2f(power2);
+  alpha = fminf(ALPHA_MAX, opacity * G);
+  return !(power2 > 0.0f) && !(alpha < ALPHA_MIN);
+}
+
+// Two splats at once for one pixel (packed fp32: v_pk_mul_f32 / v_pk_fma_f32); lane-wise the same
+// operations in the same order as the scalar form above, hence the same bits.
+__device__ __forceinline__ v2f pair_power_x2(const v2f dx, const v2f dy, const v2f A, const v2f B,
+                                             const v2f C) {
+  const v2f hA = (A * dx) * dx;
+  const v2f bdx = B * dx;
+  return __builtin_elementwise_fma(dy, __builtin_elementwise_fma(C, dy, bdx), hA);
 }
 
 // Conservative whole-rectangle cull.  Pixels px in [x0,x1], py in [y0,y1] (inclusive, pixel

@@ -82,58 +82,129 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
 // GPI splats are evaluated per inner iteration (independent alpha chains), then blended in order.
 template <int PX>
 struct WavePix {   // per-lane blending state of PX pixels
-  float T[PX], Cr[PX], Cg[PX], Cb[PX], D[PX], Wt[PX];
+  float T[PX], Wt[PX];
+  v2f CrCg[PX], CbD[PX];   // (red, green) and (blue, depth) accumulators: one v_pk_fma_f32 each
   uint32_t last[PX];
   bool done[PX];
 };
+
+// In-order blend of one accepted/rejected splat into pixel k (forward.cu:425-440).
+template <int PX>
+__device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const bool ok,
+                                          const float alpha, const float4 col, const uint32_t pos) {
+  bool valid = ok && !s.done[k];
+  const float test_T = s.T[k] * (1.0f - alpha);
+  const bool term = valid && (test_T < 0.0001f);
+  s.done[k] = s.done[k] || term;
+  valid = valid && !term;
+  const float w = valid ? alpha * s.T[k] : 0.0f;
+  if (PX == 1) {
+    const v2f w2 = {w, w};
+    s.CrCg[k] = __builtin_elementwise_fma((v2f){col.x, col.y}, w2, s.CrCg[k]);
+    s.CbD[k] = __builtin_elementwise_fma((v2f){col.z, col.w}, w2, s.CbD[k]);
+  } else {   // 4 pixels per lane: leave the pairing to the register allocator (fewer spills)
+    s.CrCg[k].x = fmaf(col.x, w, s.CrCg[k].x);
+    s.CrCg[k].y = fmaf(col.y, w, s.CrCg[k].y);
+    s.CbD[k].x = fmaf(col.z, w, s.CbD[k].x);
+    s.CbD[k].y = fmaf(col.w, w, s.CbD[k].y);
+  }
+  s.Wt[k] += w;
+  s.T[k] = valid ? test_T : s.T[k];
+  s.last[k] = valid ? pos : s.last[k];
+}
+
+// LDS slot of a compacted survivor, light path (REC_F4 = 3 float4):
+//   [0] gx, gy, opacity, list position   [1] A, B, C (pre-scaled conic, blend_math.h), -
+//   [2] r, g, b, depth
+__device__ __forceinline__ void store_slot(float4* __restrict__ my, const int slot, const float4 a,
+                                           const float4 b, const float4 c, const uint32_t pos) {
+  const SplatQ q = splat_q(b.x, b.y, b.z);
+  my[slot * REC_F4 + 0] = make_float4(a.x, a.y, a.w, __uint_as_float(pos));
+  my[slot * REC_F4 + 1] = make_float4(q.A, q.B, q.C, 0.f);
+  my[slot * REC_F4 + 2] = make_float4(b.w, c.x, c.y, a.z);
+}
 
 // Evaluate G consecutive compacted survivors (LDS slots j0 .. j0+G-1, all present) for the lane's
 // PX pixels: G*PX independent power/exp/alpha chains, then the in-order blend.  Returns true if
 // the blend part ran (some lane accepted some splat).
 template <int PX, int G>
 __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __restrict__ my,
-                                            const int j0, const uint32_t idx0, const float pxf,
-                                            const int py0) {
-  float4 ra[G], rb[G], rc[G];
+                                            const int j0, const float pxf, const int py0) {
+  float4 ra[G], rq[G], rc[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    ra[g] = my[(j0 + g) * REC_F4 + 0];   // px, py, depth, opacity
-    rb[g] = my[(j0 + g) * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
-    rc[g] = my[(j0 + g) * REC_F4 + 2];   // G, B, position in batch, -
+    ra[g] = my[(j0 + g) * REC_F4 + 0];
+    rq[g] = my[(j0 + g) * REC_F4 + 1];
+    rc[g] = my[(j0 + g) * REC_F4 + 2];
   }
   float alpha[G][PX];
   bool ok[G][PX];
   bool any = false;
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const SplatTerms st = splat_terms(ra[g].x - pxf, rb[g].x, rb[g].y, rb[g].z);
+    const SplatQ q = {rq[g].x, rq[g].y, rq[g].z};
+    const SplatTerms st = splat_terms_q(ra[g].x - pxf, q);
 #pragma unroll
     for (int k = 0; k < PX; k++) {
       const float dy = ra[g].y - (float)(py0 + k);
       float Gv;
-      ok[g][k] = pair_alpha(pair_power(st, dy), ra[g].w, Gv, alpha[g][k]);
-      any = any || (ok[g][k] && !s.done[k]);
+      ok[g][k] = pair_alpha(pair_power(st, dy), ra[g].z, Gv, alpha[g][k]);
+      any = any | (ok[g][k] & !s.done[k]);
     }
   }
   if (__ballot(any) == 0ull) return false;   // nobody in the wave blends any of these splats
 #pragma unroll
   for (int g = 0; g < G; g++) {
 #pragma unroll
-    for (int k = 0; k < PX; k++) {
-      bool valid = ok[g][k] && !s.done[k];
-      const float test_T = s.T[k] * (1.0f - alpha[g][k]);
-      const bool term = valid && (test_T < 0.0001f);
-      s.done[k] = s.done[k] || term;
-      valid = valid && !term;
-      const float w = valid ? alpha[g][k] * s.T[k] : 0.0f;
-      s.Cr[k] = fmaf(rb[g].w, w, s.Cr[k]);
-      s.Cg[k] = fmaf(rc[g].x, w, s.Cg[k]);
-      s.Cb[k] = fmaf(rc[g].y, w, s.Cb[k]);
-      s.D[k] = fmaf(ra[g].z, w, s.D[k]);
-      s.Wt[k] += w;
-      s.T[k] = valid ? test_T : s.T[k];
-      s.last[k] = valid ? (idx0 + (uint32_t)__float_as_int(rc[g].z)) : s.last[k];
-    }
+    for (int k = 0; k < PX; k++)
+      blend_one<PX>(s, k, ok[g][k], alpha[g][k], rc[g], __float_as_uint(ra[g].w));
+  }
+  return true;
+}
+
+// Heavy path (1 pixel per lane): survivors are stored in PAIRS so that two splats are evaluated
+// per packed instruction.  LDS block of a pair (PAIR_F4 = 6 float4, same 48 B per splat):
+//   [0] gx0 gx1 gy0 gy1   [1] A0 A1 B0 B1   [2] C0 C1 op0 op1
+//   [3] r0 g0 b0 depth0   [4] r1 g1 b1 depth1   [5] pos0 pos1 - -
+constexpr int PAIR_F4 = 2 * REC_F4;
+
+__device__ __forceinline__ void store_pair_half(float4* __restrict__ my, const int slot,
+                                                const float gx, const float gy, const SplatQ q,
+                                                const float op, const float4 col,
+                                                const uint32_t pos) {
+  float4* blk = my + (slot >> 1) * PAIR_F4;
+  float* f = reinterpret_cast<float*>(blk) + (slot & 1);
+  f[0] = gx; f[2] = gy; f[4] = q.A; f[6] = q.B; f[8] = q.C; f[10] = op;
+  blk[3 + (slot & 1)] = col;
+  f[20] = __uint_as_float(pos);
+}
+
+// Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
+__device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
+                                           const int j0, const float pxf, const float pyf) {
+  const float4* blk = my + (j0 >> 1) * PAIR_F4;
+  float alpha[4];
+  bool ok[4];
+  const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float4 f0 = blk[h * PAIR_F4 + 0], f1 = blk[h * PAIR_F4 + 1], f2 = blk[h * PAIR_F4 + 2];
+    const v2f dx = (v2f){f0.x, f0.y} - px2, dy = (v2f){f0.z, f0.w} - py2;
+    const v2f p = pair_power_x2(dx, dy, (v2f){f1.x, f1.y}, (v2f){f1.z, f1.w}, (v2f){f2.x, f2.y});
+    const v2f G = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+    const v2f al = (v2f){f2.z, f2.w} * G;
+    alpha[2 * h + 0] = fminf(ALPHA_MAX, al.x);
+    alpha[2 * h + 1] = fminf(ALPHA_MAX, al.y);
+    ok[2 * h + 0] = !(p.x > 0.0f) && !(alpha[2 * h + 0] < ALPHA_MIN);
+    ok[2 * h + 1] = !(p.y > 0.0f) && !(alpha[2 * h + 1] < ALPHA_MIN);
+  }
+  const bool any = (ok[0] | ok[1] | ok[2] | ok[3]) & !s.done[0];
+  if (__ballot(any) == 0ull) return false;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4], pp = blk[h * PAIR_F4 + 5];
+    blend_one<1>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x));
+    blend_one<1>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y));
   }
   return true;
 }
@@ -163,7 +234,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   WavePix<PX> st;
 #pragma unroll
   for (int k = 0; k < PX; k++) {
-    st.T[k] = 1.0f; st.Cr[k] = st.Cg[k] = st.Cb[k] = 0.f; st.D[k] = 0.f; st.Wt[k] = 0.f;
+    st.T[k] = 1.0f; st.CrCg[k] = (v2f){0.f, 0.f}; st.CbD[k] = (v2f){0.f, 0.f}; st.Wt[k] = 0.f;
     st.last[k] = 0;
     st.done[k] = !(px < W && (py0 + k) < H);
   }
@@ -237,15 +308,10 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
                       !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
     const uint64_t mask = __ballot(keep);
     const int cnt = (int)__popcll(mask);
-    if (keep) {
-      const int slot = (int)__popcll(mask & lanemask_lt());
-      my[slot * REC_F4 + 0] = a;
-      my[slot * REC_F4 + 1] = b;
-      my[slot * REC_F4 + 2] = make_float4(c.x, c.y, __int_as_float(lane), 0.f);   // .z = position in batch
-    }
+    if (keep)   // list positions are 1-based (n_contrib convention of the reference)
+      store_slot(my, (int)__popcll(mask & lanemask_lt()), a, b, c, base - r_begin + 1 + (uint32_t)lane);
     if (TRACE) { tr->batches++; tr->survivors += (uint32_t)cnt; }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t idx0 = base - r_begin + 1;   // 1-based list position of entry 0 of the batch
 
     const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
     if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
@@ -253,12 +319,12 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
       // full groups of GPI survivors, then the remainder one by one: no dummy slots are evaluated
       int j0 = (TRACE && (ablate & 1)) ? cnt : 0;
       for (; j0 + GPI <= cnt; j0 += GPI) {
-        const bool blended = blend_group<PX, GPI>(st, my, j0, idx0, pxf, py0);
+        const bool blended = blend_group<PX, GPI>(st, my, j0, pxf, py0);
         if (TRACE && blended) tr->blends++;
       }
       if (GPI > 1) {
         for (; j0 < cnt; j0++) {
-          const bool blended = blend_group<PX, 1>(st, my, j0, idx0, pxf, py0);
+          const bool blended = blend_group<PX, 1>(st, my, j0, pxf, py0);
           if (TRACE && blended) tr->blends++;
         }
       }
@@ -274,11 +340,11 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     const int py = py0 + k;
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      out_color[pix] = st.Cr[k] + st.T[k] * bg0;
-      out_color[HW + pix] = st.Cg[k] + st.T[k] * bg1;
-      out_color[2 * HW + pix] = st.Cb[k] + st.T[k] * bg2;
+      out_color[pix] = st.CrCg[k].x + st.T[k] * bg0;
+      out_color[HW + pix] = st.CrCg[k].y + st.T[k] * bg1;
+      out_color[2 * HW + pix] = st.CbD[k].x + st.T[k] * bg2;
       out_alpha[pix] = st.Wt[k];
-      out_depth[pix] = st.D[k];
+      out_depth[pix] = st.CbD[k].y;
       if (WRITE_AUX) n_contrib[pix] = st.last[k];
     }
   }
@@ -326,7 +392,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   const uint64_t lt = lanemask_lt();
 
   WavePix<1> st;
-  st.T[0] = 1.0f; st.Cr[0] = st.Cg[0] = st.Cb[0] = 0.f; st.D[0] = 0.f; st.Wt[0] = 0.f;
+  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f}; st.Wt[0] = 0.f;
   st.last[0] = 0;
   st.done[0] = !(px < W && py < H);
 
@@ -407,23 +473,19 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                         !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
       const uint64_t mask = __ballot(keep);
       const int cnt = (int)__popcll(mask);
-      if (keep) {
-        const int slot = (int)__popcll(mask & lt);
-        my[slot * REC_F4 + 0] = a;
-        my[slot * REC_F4 + 1] = b;
-        my[slot * REC_F4 + 2] = make_float4(c.x, c.y, __uint_as_float(pos), 0.f);
+      if (keep)
+        store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                        make_float4(b.w, c.x, c.y, a.z), pos);
+      if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
+        const SplatQ zq = {0.f, 0.f, 0.f};
+        store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
       }
       if (TRACE) tr->survivors += (uint32_t)cnt;
       __builtin_amdgcn_wave_barrier();
       const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
       if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
-      int j0 = 0;
-      for (; j0 + 4 <= cnt; j0 += 4) {
-        const bool blended = blend_group<1, 4>(st, my, j0, 0u, pxf, py);
-        if (TRACE && blended) tr->blends++;
-      }
-      for (; j0 < cnt; j0++) {
-        const bool blended = blend_group<1, 1>(st, my, j0, 0u, pxf, py);
+      for (int j0 = 0; j0 < cnt; j0 += 4) {
+        const bool blended = blend_quad(st, my, j0, pxf, (float)py);
         if (TRACE && blended) tr->blends++;
       }
       if (TRACE) tr->t_loop += (uint32_t)(__builtin_readcyclecounter() - tc1);
@@ -437,11 +499,11 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   const size_t HW = (size_t)H * W;
   if (px < W && py < H) {
     const size_t pix = (size_t)py * W + px;
-    out_color[pix] = st.Cr[0] + st.T[0] * bg0;
-    out_color[HW + pix] = st.Cg[0] + st.T[0] * bg1;
-    out_color[2 * HW + pix] = st.Cb[0] + st.T[0] * bg2;
+    out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
+    out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
+    out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
     out_alpha[pix] = st.Wt[0];
-    out_depth[pix] = st.D[0];
+    out_depth[pix] = st.CbD[0].y;
     n_contrib[pix] = st.last[0];
   }
 }
