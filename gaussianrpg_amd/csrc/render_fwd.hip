@@ -80,37 +80,43 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
 //   PX = 4: rows y0 + (lane>>4)*4 + k, k<4   -> 16x16 pixels (a whole tile)
 //   PX = 1: rows y0 + (lane>>4)               -> 16x4 pixels (a quarter tile)
 // GPI splats are evaluated per inner iteration (independent alpha chains), then blended in order.
+// Per-lane predicates are carried as wave-level 64-bit lane masks (uint64_t in SGPRs): compare
+// results are masks already (ballot is free), all boolean algebra runs on the scalar unit, and
+// inverse_ballot hands a mask back to v_cndmask at no VALU cost.
+__device__ __forceinline__ uint64_t lanes(const bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+__device__ __forceinline__ bool in_mask(const uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 template <int PX>
 struct WavePix {   // per-lane blending state of PX pixels
   float T[PX], Wt[PX];
   v2f CrCg[PX], CbD[PX];   // (red, green) and (blue, depth) accumulators: one v_pk_fma_f32 each
   uint32_t last[PX];
-  bool done[PX];
+  uint64_t done[PX];       // lane masks: pixel k of the lane is saturated / outside the image
 };
 
-// In-order blend of one accepted/rejected splat into pixel k (forward.cu:425-440).
+// In-order blend of one splat into pixel k (forward.cu:425-440); ok_m = lanes that accept it.
 template <int PX>
-__device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const bool ok,
+__device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uint64_t ok_m,
                                           const float alpha, const float4 col, const uint32_t pos) {
-  bool valid = ok && !s.done[k];
-  const float test_T = s.T[k] * (1.0f - alpha);
-  const bool term = valid && (test_T < 0.0001f);
-  s.done[k] = s.done[k] || term;
-  valid = valid && !term;
-  const float w = valid ? alpha * s.T[k] : 0.0f;
+  const v2f tw = (v2f){1.0f - alpha, alpha} * (v2f){s.T[k], s.T[k]};   // T (1 - alpha), alpha T
+  const uint64_t lt_m = lanes(tw.x < 0.0001f);
+  const uint64_t live = ok_m & ~s.done[k];
+  s.done[k] |= live & lt_m;                       // terminated: this and all later splats rejected
+  const bool cont = in_mask(live & ~lt_m);
+  const float w = cont ? tw.y : 0.0f;
   if (PX == 1) {
     const v2f w2 = {w, w};
     s.CrCg[k] = __builtin_elementwise_fma((v2f){col.x, col.y}, w2, s.CrCg[k]);
     s.CbD[k] = __builtin_elementwise_fma((v2f){col.z, col.w}, w2, s.CbD[k]);
-  } else {   // 4 pixels per lane: leave the pairing to the register allocator (fewer spills)
+  } else {   // 4 pixels per lane: leave the pairing to the register allocator
     s.CrCg[k].x = fmaf(col.x, w, s.CrCg[k].x);
     s.CrCg[k].y = fmaf(col.y, w, s.CrCg[k].y);
     s.CbD[k].x = fmaf(col.z, w, s.CbD[k].x);
     s.CbD[k].y = fmaf(col.w, w, s.CbD[k].y);
   }
   s.Wt[k] += w;
-  s.T[k] = valid ? test_T : s.T[k];
-  s.last[k] = valid ? pos : s.last[k];
+  s.T[k] = cont ? tw.x : s.T[k];
+  s.last[k] = cont ? pos : s.last[k];
 }
 
 // LDS slot of a compacted survivor, light path (REC_F4 = 3 float4):
@@ -138,8 +144,8 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
     rc[g] = my[(j0 + g) * REC_F4 + 2];
   }
   float alpha[G][PX];
-  bool ok[G][PX];
-  bool any = false;
+  uint64_t ok[G][PX];
+  uint64_t any = 0ull;
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const SplatQ q = {rq[g].x, rq[g].y, rq[g].z};
@@ -147,12 +153,13 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
 #pragma unroll
     for (int k = 0; k < PX; k++) {
       const float dy = ra[g].y - (float)(py0 + k);
-      float Gv;
-      ok[g][k] = pair_alpha(pair_power(st, dy), ra[g].z, Gv, alpha[g][k]);
-      any = any | (ok[g][k] & !s.done[k]);
+      const float p = pair_power(st, dy);
+      alpha[g][k] = fminf(ALPHA_MAX, ra[g].z * __builtin_amdgcn_exp2f(p));   // == pair_alpha
+      ok[g][k] = lanes(!(p > 0.0f)) & lanes(!(alpha[g][k] < ALPHA_MIN));
+      any |= ok[g][k] & ~s.done[k];
     }
   }
-  if (__ballot(any) == 0ull) return false;   // nobody in the wave blends any of these splats
+  if (any == 0ull) return false;   // nobody in the wave blends any of these splats
 #pragma unroll
   for (int g = 0; g < G; g++) {
 #pragma unroll
@@ -184,7 +191,7 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
                                            const int j0, const float pxf, const float pyf) {
   const float4* blk = my + (j0 >> 1) * PAIR_F4;
   float alpha[4];
-  bool ok[4];
+  uint64_t ok[4];
   const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -195,11 +202,10 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
     const v2f al = (v2f){f2.z, f2.w} * G;
     alpha[2 * h + 0] = fminf(ALPHA_MAX, al.x);
     alpha[2 * h + 1] = fminf(ALPHA_MAX, al.y);
-    ok[2 * h + 0] = !(p.x > 0.0f) && !(alpha[2 * h + 0] < ALPHA_MIN);
-    ok[2 * h + 1] = !(p.y > 0.0f) && !(alpha[2 * h + 1] < ALPHA_MIN);
+    ok[2 * h + 0] = lanes(!(p.x > 0.0f)) & lanes(!(alpha[2 * h + 0] < ALPHA_MIN));
+    ok[2 * h + 1] = lanes(!(p.y > 0.0f)) & lanes(!(alpha[2 * h + 1] < ALPHA_MIN));
   }
-  const bool any = (ok[0] | ok[1] | ok[2] | ok[3]) & !s.done[0];
-  if (__ballot(any) == 0ull) return false;
+  if (((ok[0] | ok[1] | ok[2] | ok[3]) & ~s.done[0]) == 0ull) return false;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4], pp = blk[h * PAIR_F4 + 5];
@@ -236,7 +242,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   for (int k = 0; k < PX; k++) {
     st.T[k] = 1.0f; st.CrCg[k] = (v2f){0.f, 0.f}; st.CbD[k] = (v2f){0.f, 0.f}; st.Wt[k] = 0.f;
     st.last[k] = 0;
-    st.done[k] = !(px < W && (py0 + k) < H);
+    st.done[k] = lanes(!(px < W && (py0 + k) < H));
   }
 
   // Software pipeline over batches of 64 list entries: while batch i is blended, the records of
@@ -260,10 +266,10 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   if (r_begin + WAVE + (uint32_t)lane < r_end) id_n2 = point_list[r_begin + WAVE + lane];
 
   for (uint32_t base = r_begin; base < r_end; base += WAVE) {
-    bool alldone = true;
+    uint64_t alldone = ~0ull;
 #pragma unroll
-    for (int k = 0; k < PX; k++) alldone = alldone && st.done[k];
-    const uint64_t alive = __ballot(!alldone);
+    for (int k = 0; k < PX; k++) alldone &= st.done[k];
+    const uint64_t alive = ~alldone;
     if (alive == 0ull) break;
     if (alive != prev_alive) {
       // Shrink the cull rectangle to the bounding box of the pixels that are still live.  Exact:
@@ -275,7 +281,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
       float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
 #pragma unroll
       for (int k = 0; k < PX; k++) {
-        if (!st.done[k]) {
+        if (in_mask(~st.done[k])) {
           bx0 = pxf; bx1 = pxf;
           by0 = fminf(by0, (float)(py0 + k));
           by1 = fmaxf(by1, (float)(py0 + k));
@@ -394,7 +400,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   WavePix<1> st;
   st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f}; st.Wt[0] = 0.f;
   st.last[0] = 0;
-  st.done[0] = !(px < W && py < H);
+  st.done[0] = lanes(!(px < W && py < H));
 
   uint32_t in_pos = r_begin;   // next unread list entry          (wave-uniform)
   uint32_t head = 0, count = 0;   // ring state                   (wave-uniform)
@@ -409,12 +415,13 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   uint32_t ncur = 0;
 
   for (;;) {
-    const uint64_t alive = __ballot(!st.done[0]);
+    const uint64_t alive = ~st.done[0];
     if (alive == 0ull) break;
     if (alive != prev_alive) {   // shrink the cull box to the live pixels (exact, see blend_rect)
       prev_alive = alive;
-      float bx0 = st.done[0] ? 3e38f : pxf, bx1 = st.done[0] ? -3e38f : pxf;
-      float by0 = st.done[0] ? 3e38f : (float)py, by1 = st.done[0] ? -3e38f : (float)py;
+      const bool dn = in_mask(st.done[0]);
+      float bx0 = dn ? 3e38f : pxf, bx1 = dn ? -3e38f : pxf;
+      float by0 = dn ? 3e38f : (float)py, by1 = dn ? -3e38f : (float)py;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
         bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
