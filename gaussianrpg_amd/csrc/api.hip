@@ -195,7 +195,9 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   char* img = image_alloc(IL.total, image_user);
   if (!geom || !img) return fail(GRPG_ERR_ALLOC, "geometry/image buffer allocation failed");
 
-  float4* rec = (float4*)(geom + GL.rec);
+  float4* geo = (float4*)(geom + GL.geo);
+  float4* col = (float4*)(geom + GL.col);
+  const RecView rec = {geo, col};
   uint32_t* key_a = (uint32_t*)(geom + GL.key_a);
   uint32_t* key_b = (uint32_t*)(geom + GL.key_b);
   uint32_t* val_a = (uint32_t*)(geom + GL.val_a);
@@ -217,7 +219,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   if (P > 0) {
     tm.mark(0);
     launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                      cov3D_precomp, colors_precomp, cam, radii_int, rec, key_a, tiles);
+                      cov3D_precomp, colors_precomp, cam, radii_int, geo, col, key_a, tiles);
     STAGE_CHECK("preprocess");
     tm.mark(1);
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key; culled keys sort last.
@@ -227,8 +229,9 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     const uint32_t* sorted_gid = in_b ? val_b : val_a;  // 4 passes -> back in "a"
     STAGE_CHECK("depth sort");
     tm.mark(2);
+    uint32_t* emit_win = (uint32_t*)(geom + GL.emit_win);
     launch_offsets_scan(stream, (uint32_t)P, tiles_sorted, offsets, block_sums, GL.nblocks_scan,
-                        &gh->R);
+                        &gh->R, emit_win, GL.emit_win_cap);
     STAGE_CHECK("offsets scan");
     // The one host round trip per frame (reference: rasterizer_impl.cu:284).
     if (!g_pinned_u32) HIP_TRY(hipHostMalloc((void**)&g_pinned_u32, 64, hipHostMallocDefault));
@@ -254,7 +257,8 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     const int passes = radix_sort_num_passes(0, tbits);
     // emit into whichever pair makes the LAST pass land in "a" (point_list lives in val_a)
     const bool start_in_b = (passes & 1) != 0;
-    launch_emit(stream, (uint32_t)P, R, sorted_gid, offsets, rec, cam.gx, cam.gy,
+    launch_emit(stream, (uint32_t)P, R, sorted_gid, offsets, emit_win, GL.emit_win_cap, rec, cam.gx,
+                cam.gy,
                 start_in_b ? bkey_b : bkey_a, start_in_b ? bval_b : bval_a);
     STAGE_CHECK("emit");
     tm.mark(4);
@@ -341,7 +345,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
         h[2].H != (uint32_t)height)
       return fail(GRPG_ERR_BAD_BUFFER, "state buffers do not match this call (P/R/W/H or magic)");
   }
-  const float4* rec = (const float4*)(geom_buffer + GL.rec);
+  const RecView rec = {(const float4*)(geom_buffer + GL.geo), (const float4*)(geom_buffer + GL.col)};
   const int* radii_int = radii ? radii : (const int*)(geom_buffer + GL.radii);
   const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.val_a);
   const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
@@ -420,7 +424,7 @@ int grpg_debug_export(int P, int R, int width, int height, const char* geom_buff
   const BinLayout BL = bin_layout((size_t)R);
   const ImgLayout IL = img_layout((size_t)gx * gy, (size_t)width * height);
   launch_debug_export(stream, P, (uint32_t)R, width, height, gx, gy,
-                      (const float4*)(geom_buffer + GL.rec),
+                      RecView{(const float4*)(geom_buffer + GL.geo), (const float4*)(geom_buffer + GL.col)},
                       (const uint32_t*)(geom_buffer + GL.tiles),
                       (const uint32_t*)(binning_buffer + BL.key_a),
                       (const uint32_t*)(binning_buffer + BL.val_a),

@@ -13,14 +13,17 @@
 
 namespace grpg {
 
-// One thread per OUTPUT instance (not per Gaussian): slot s of the instance list is mapped back to
-// its (depth-sorted) Gaussian by a binary search over the exclusive offsets, restricted to the
-// index window [lo, hi] that the workgroup's 1024 consecutive slots can touch (two searches per
-// workgroup).  Work per thread is therefore independent of the footprint distribution -- in the
-// reference one thread loops over every tile of its Gaussian (rasterizer_impl.cu:98-108), which
-// is thousands of serial iterations for a near-camera splat, and after the depth sort the largest
-// footprints sit next to each other -- and the stores are perfectly coalesced.
-constexpr int EMIT_PER_BLOCK = 1024;
+// One thread per OUTPUT instance (not per Gaussian): a workgroup owns 1024 consecutive slots of the
+// instance list and maps every slot back to its (depth-sorted) Gaussian.  Two binary searches per
+// workgroup bound the index window [lo, hi] of Gaussians that can own those slots; every window
+// Gaussian then marks the slot where its run starts in an LDS array, and an inclusive max-scan over
+// the 1024 slots (4 consecutive slots per thread, wave DPP scan, 4-wave spine) yields the owner of
+// every slot -- about 10 instructions per slot instead of an 11-step binary search each.
+// Work per thread is independent of the footprint distribution -- in the reference one thread loops
+// over every tile of its Gaussian (rasterizer_impl.cu:98-108), thousands of serial iterations for a
+// near-camera splat, and after the depth sort the largest footprints sit next to each other -- and
+// each thread stores its 4 keys / 4 values with one 16-byte store.
+constexpr int EMIT_WIN = EMIT_PER_BLOCK + 64;   // window offsets staged in LDS (else global search)
 
 __device__ __forceinline__ uint32_t last_leq(const uint32_t* __restrict__ a, uint32_t lo,
                                              uint32_t hi, const uint32_t v) {
@@ -32,54 +35,112 @@ __device__ __forceinline__ uint32_t last_leq(const uint32_t* __restrict__ a, uin
   return lo;
 }
 
+// One instance: slot k of Gaussian g's tile rectangle (row-major, rasterizer_impl.cu:98-108)
+// -> tile id and value (id | quarter-reach mask << 28).
+__device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k,
+                                              const RecView rec, const int gx,
+                                              const int gy, uint32_t& key, uint32_t& val) {
+  const float4 r0 = rec.geo[2 * (size_t)g];       // px, py, opacity, radius
+  const float4 r1 = rec.geo[2 * (size_t)g + 1];   // conic, depth
+  const int radius = __float_as_int(r0.w);
+  int minx, miny, maxx, maxy;
+  get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
+  const uint32_t w = (uint32_t)(maxx - minx);
+  // k / w for k < gx*gy <= 2^24 (exact in fp32): float estimate, one correction step each way
+  uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
+  row -= (row * w > k) ? 1u : 0u;
+  row += ((row + 1u) * w <= k) ? 1u : 0u;
+  const uint32_t col = k - row * w;
+  const int tx = minx + (int)col, ty = miny + (int)row;
+  key = (uint32_t)(ty * gx + tx);
+  // Sub-tile mask: which 16x4 quarters of the tile can this splat reach at all?  Evaluated once
+  // here (the record is in registers anyway) and carried through the sort in the spare top bits
+  // of the value, so render knows before loading a record whether it is needed.
+  const uint32_t bits = quarter_reach_mask(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, (float)(tx * TILE),
+                                           (float)(ty * TILE));
+  val = g | (bits << SUBTILE_SHIFT);
+}
+
 __global__ void __launch_bounds__(256)
 emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sorted_gid,
-            const uint32_t* __restrict__ offsets, const float4* __restrict__ rec, const int gx,
-            const int gy, uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
+            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ emit_win,
+            const uint32_t emit_win_cap, const RecView rec, const int gx, const int gy,
+            uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
   __shared__ uint32_t s_win[2];
-  __shared__ uint32_t s_off[EMIT_PER_BLOCK + 64];
+  __shared__ uint32_t s_off[EMIT_WIN];
+  __shared__ uint32_t s_own[EMIT_PER_BLOCK];
+  __shared__ uint32_t s_wave[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t o0 = blockIdx.x * EMIT_PER_BLOCK;
   const uint32_t o1 = min(R, o0 + EMIT_PER_BLOCK);
-  if (threadIdx.x < 2)
-    s_win[threadIdx.x] = last_leq(offsets, 0, P - 1, threadIdx.x == 0 ? o0 : o1 - 1);
+  // window bounds: owner of the block's first slot, and (an upper bound of) the owner of its last
+  // slot = owner of the next block's first slot / of the list's last slot -- both left behind by
+  // the offsets scan (sort.hip:scan_down_kernel); binary search only beyond the table's capacity
+  if (tid < 2) {
+    const uint32_t b = blockIdx.x + tid;
+    s_win[tid] = b <= emit_win_cap ? emit_win[b]
+                                   : last_leq(offsets, 0, P - 1, tid == 0 ? o0 : o1 - 1);
+  }
+#pragma unroll
+  for (int r = 0; r < EMIT_PER_BLOCK / 256; r++) s_own[r * 256 + tid] = 0u;
   __syncthreads();
   const uint32_t lo = s_win[0], hi = s_win[1];
   // the window normally holds <= 1025 Gaussians (every visible Gaussian owns >= 1 slot; culled
-  // ones sort to the very end): stage its offsets in LDS so the per-slot search never leaves the CU
+  // ones sort to the very end)
   const uint32_t nwin = hi - lo + 1;
-  const bool in_lds = nwin <= (uint32_t)(EMIT_PER_BLOCK + 64);
-  if (in_lds)
-    for (uint32_t j = threadIdx.x; j < nwin; j += 256) s_off[j] = offsets[lo + j];
-  __syncthreads();
+  if (nwin <= (uint32_t)EMIT_WIN) {
+    // a Gaussian with zero instances shares its offset with its successor, so the LAST index with
+    // offsets[i] <= s owns slot s: mark run starts with the largest window index, then max-scan
+    for (uint32_t j = tid; j < nwin; j += 256) {
+      const uint32_t o = offsets[lo + j];
+      s_off[j] = o;
+      if (j > 0 && o < o1) atomicMax(&s_own[o - o0], j);   // j > 0  =>  o > o0
+    }
+    __syncthreads();
+    uint32_t own[4];
+    {
+      const uint4 v = reinterpret_cast<const uint4*>(s_own)[tid];
+      own[0] = v.x; own[1] = max(own[0], v.y); own[2] = max(own[1], v.z); own[3] = max(own[2], v.w);
+    }
+    uint32_t inc = own[3];
 #pragma unroll
-  for (int r = 0; r < EMIT_PER_BLOCK / 256; r++) {
-    const uint32_t s = o0 + r * 256 + threadIdx.x;
-    if (s >= o1) break;
-    // a Gaussian with zero instances shares its offset with its successor, so the LAST index
-    // with offsets[i] <= s is always the owner of slot s
-    const uint32_t i = in_lds ? lo + last_leq(s_off, 0, nwin - 1, s) : last_leq(offsets, lo, hi, s);
-    const uint32_t g = sorted_gid[i];
-    const uint32_t k = s - (in_lds ? s_off[i - lo] : offsets[i]);
-    const float4 r0 = rec[3 * (size_t)g];
-    const int radius = __float_as_int(rec[3 * (size_t)g + 2].w);
-    int minx, miny, maxx, maxy;
-    get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
-    const uint32_t w = (uint32_t)(maxx - minx);
-    const uint32_t row = k / w, col = k - row * w;
-    const int tx = minx + (int)col, ty = miny + (int)row;
-    tile_keys[s] = (uint32_t)(ty * gx + tx);
-    // Sub-tile mask: can this splat reach the w-th 16x4 quarter of the tile at all?  Evaluated
-    // once here (the record is in registers anyway) and carried through the sort in the spare
-    // top bits of the value, so render knows before loading a record whether it is needed.
-    const float4 r1 = rec[3 * (size_t)g + 1];
-    uint32_t bits = 0;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= (uint32_t)d) inc = max(inc, t);
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    const uint32_t excl_w = __shfl_up(inc, 1, 64);
+    __syncthreads();
+    uint32_t before = lane > 0 ? excl_w : 0u;   // max over the preceding threads of this wave ...
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (!splat_misses_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.w, (float)(tx * TILE),
-                             (float)(tx * TILE + 15), (float)(ty * TILE + 4 * q),
-                             (float)(ty * TILE + 4 * q + 3)))
-        bits |= 1u << q;
-    vals[s] = g | (bits << SUBTILE_SHIFT);
+    for (int w2 = 0; w2 < 3; w2++)
+      if ((uint32_t)w2 < wave) before = max(before, s_wave[w2]);   // ... and of the preceding waves
+    uint32_t key[4], val[4];
+    const uint32_t s0 = o0 + 4 * tid;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      key[r] = 0u; val[r] = 0u;
+      if (s0 + r < o1) {
+        const uint32_t j = max(own[r], before);
+        emit_instance(sorted_gid[lo + j], s0 + r - s_off[j], rec, gx, gy, key[r], val[r]);
+      }
+    }
+    if (s0 + 3 < o1) {   // o0 is a multiple of 1024 and the arrays are 256-byte aligned
+      reinterpret_cast<uint4*>(tile_keys)[s0 >> 2] = make_uint4(key[0], key[1], key[2], key[3]);
+      reinterpret_cast<uint4*>(vals)[s0 >> 2] = make_uint4(val[0], val[1], val[2], val[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (s0 + r < o1) { tile_keys[s0 + r] = key[r]; vals[s0 + r] = val[r]; }
+    }
+  } else {   // oversized window (runs of zero-instance Gaussians): per-slot search in global memory
+    for (uint32_t s = o0 + tid; s < o1; s += 256) {
+      const uint32_t i = last_leq(offsets, lo, hi, s);
+      uint32_t key, val;
+      emit_instance(sorted_gid[i], s - offsets[i], rec, gx, gy, key, val);
+      tile_keys[s] = key;
+      vals[s] = val;
+    }
   }
 }
 
@@ -95,11 +156,11 @@ tile_ranges_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
 }
 
 void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_gid,
-                 const uint32_t* offsets, const float4* rec, int gx, int gy, uint32_t* tile_keys,
-                 uint32_t* vals) {
+                 const uint32_t* offsets, const uint32_t* emit_win, uint32_t emit_win_cap,
+                 const RecView rec, int gx, int gy, uint32_t* tile_keys, uint32_t* vals) {
   if (P == 0 || R == 0) return;
   emit_kernel<<<(R + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK, 256, 0, s>>>(
-      P, R, sorted_gid, offsets, rec, gx, gy, tile_keys, vals);
+      P, R, sorted_gid, offsets, emit_win, emit_win_cap, rec, gx, gy, tile_keys, vals);
 }
 
 void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
@@ -111,14 +172,14 @@ void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, ui
 
 // ---------------------------------- debug / parity decoder --------------------------------
 __global__ void __launch_bounds__(256)
-debug_geom_kernel(const int P, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles,
+debug_geom_kernel(const int P, const RecView rec, const uint32_t* __restrict__ tiles,
                   float* means2D, float* depths, float* conic_opacity, float* rgb,
                   uint32_t* tiles_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const bool vis = tiles[i] > 0;
   float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-  if (vis) { a = rec[3 * (size_t)i]; b = rec[3 * (size_t)i + 1]; c = rec[3 * (size_t)i + 2]; }
+  if (vis) rec.load((size_t)i, a, b, c);
   if (means2D) { means2D[2 * i] = a.x; means2D[2 * i + 1] = a.y; }
   if (depths) depths[i] = a.z;
   if (conic_opacity) {
@@ -131,18 +192,18 @@ debug_geom_kernel(const int P, const float4* __restrict__ rec, const uint32_t* _
 
 __global__ void __launch_bounds__(256)
 debug_keys_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
-                  const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+                  const uint32_t* __restrict__ point_list, const RecView rec,
                   uint64_t* keys_sorted, uint32_t* point_list_out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
   const uint32_t g = point_list[i] & ID_MASK;
   if (keys_sorted)
-    keys_sorted[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec[3 * (size_t)g].z);
+    keys_sorted[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec.geo[2 * (size_t)g + 1].w);
   if (point_list_out) point_list_out[i] = g;
 }
 
 void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
-                         const float4* rec, const uint32_t* tiles, const uint32_t* tile_keys,
+                         const RecView rec, const uint32_t* tiles, const uint32_t* tile_keys,
                          const uint32_t* point_list, const uint2* ranges,
                          const uint32_t* n_contrib_in, uint64_t* keys_sorted,
                          uint32_t* point_list_out, uint32_t* ranges_out, uint32_t* n_contrib_out,

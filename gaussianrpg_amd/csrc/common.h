@@ -18,14 +18,28 @@ constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
 constexpr int SUBTILE_SHIFT = 28;
 
 // ---------------------------------------------------------------------------------------
-// Per-Gaussian record written by preprocess and gathered by render: 3 x float4 = 48 B.
-//   r0 = { px, py, depth(view z), opacity }
-//   r1 = { conic.x, conic.y, conic.z, R }
-//   r2 = { G, B, bits(clamped mask: bit0 R,bit1 G,bit2 B), bits(radius as int32) }
-// The reference keeps the same data in six arrays (GeometryState, rasterizer_impl.h:30-44);
-// one 48-byte record means a tile instance costs one contiguous gather instead of four.
+// Per-Gaussian projected attributes written by preprocess: 48 B in two arrays indexed by id.
+//   geo[2 id]     = { px, py, opacity, bits(radius as int32) }     32-byte aligned pair:
+//   geo[2 id + 1] = { conic.x, conic.y, conic.z, depth(view z) }   all that binning needs
+//   col[id]       = { R, G, B, bits(clamped mask: bit0 R, bit1 G, bit2 B) }
+// emit touches only the 32-byte geo pair (one sector of a random gather instead of 1.75 on
+// average for a packed 48-byte record); render and the backward gather geo + col.
+// The reference keeps the same data in six arrays (GeometryState, rasterizer_impl.h:30-44).
+// load() returns the working view used by the kernels:
+//   a = { px, py, depth, opacity }   b = { conic.x, conic.y, conic.z, R }
+//   c = { G, B, clamp bits, radius bits }
 // ---------------------------------------------------------------------------------------
-constexpr int REC_F4 = 3;
+constexpr int REC_F4 = 3;           // float4 per Gaussian over both arrays (and per LDS slot)
+struct RecView {
+  const float4* geo;
+  const float4* col;
+  __device__ __forceinline__ void load(const size_t id, float4& a, float4& b, float4& c) const {
+    const float4 g0 = geo[2 * id], g1 = geo[2 * id + 1], cc = col[id];
+    a = make_float4(g0.x, g0.y, g1.w, g0.z);
+    b = make_float4(g1.x, g1.y, g1.z, cc.x);
+    c = make_float4(cc.y, cc.z, cc.w, g0.w);
+  }
+};
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -54,11 +68,12 @@ constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
 constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS = 8;
 constexpr int SC_CHUNK = SC_THREADS * SC_ITEMS;  // 2048 per workgroup
+constexpr int EMIT_PER_BLOCK = 1024;             // instance-list slots per emit workgroup
 
 struct GeomLayout {
   size_t total;
-  size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums;
-  uint32_t nchunks_sort, nblocks_scan;
+  size_t geo, col, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
+  uint32_t nchunks_sort, nblocks_scan, emit_win_cap;
 };
 struct BinLayout {
   size_t total;
@@ -76,7 +91,8 @@ inline GeomLayout geom_layout(size_t P) {
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   L.nchunks_sort = (uint32_t)((P + RS_CHUNK - 1) / RS_CHUNK);
   L.nblocks_scan = (uint32_t)((P + SC_CHUNK - 1) / SC_CHUNK);
-  L.rec = take(P * REC_F4 * 16);
+  L.geo = take(P * 32);
+  L.col = take(P * 16);
   L.key_a = take(P * 4);
   L.key_b = take(P * 4);
   L.val_a = take(P * 4);
@@ -88,6 +104,10 @@ inline GeomLayout geom_layout(size_t P) {
   L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);   // u32 table or u64 status words
   L.totals = take(4 * RS_MAX_RADIX * 4);
   L.block_sums = take(((size_t)L.nblocks_scan + 1) * 4);
+  // owner (depth-sorted Gaussian index) of the first slot of every 1024-slot emit block, written by
+  // the offsets scan; blocks beyond the cap (R > 128 P, pathological) fall back to a binary search
+  L.emit_win_cap = (uint32_t)(P / 8 + 1024);
+  L.emit_win = take(((size_t)L.emit_win_cap + 2) * 4);
   L.total = o;
   return L;
 }
@@ -129,7 +149,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* rec, uint32_t* depth_key, uint32_t* tiles);
+                       float4* geo, float4* col, uint32_t* depth_key, uint32_t* tiles);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations,
                            const float* cov3D_precomp, const CameraArgs& cam, int* radii,
@@ -149,25 +169,25 @@ int radix_sort_num_passes(int begin_bit, int end_bit);
 // offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total (device) = sum.
 void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted,
                          uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
-                         uint32_t* total_out);
+                         uint32_t* total_out, uint32_t* emit_win, uint32_t emit_win_cap);
 
 void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_gid,
-                 const uint32_t* offsets, const float4* rec, int gx, int gy, uint32_t* tile_keys,
-                 uint32_t* vals);
+                 const uint32_t* offsets, const uint32_t* emit_win, uint32_t emit_win_cap,
+                 const RecView rec, int gx, int gy, uint32_t* tile_keys, uint32_t* vals);
 void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
                         uint32_t T);
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                           const float4* rec, int W, int H, int gx, int gy, const float* bg,
+                           const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
                            uint32_t heavy_min);
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                            const float4* rec, const float* semantics, int S, int W, int H, int gx,
+                            const RecView rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, float* out_semantic);
 
 void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                            const float4* rec, const float* semantics, int S, int W, int H, int gx,
+                            const RecView rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
@@ -175,7 +195,7 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
                             float* dL_dsemantic);
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,
-                                const int* radii, const float* shs, const float4* rec,
+                                const int* radii, const float* shs, const RecView rec,
                                 const float* scales, const float* rotations, float scale_modifier,
                                 const float* cov3D_precomp, const CameraArgs& cam,
                                 const float* dL_dmean2D, const float* dL_dconic,
@@ -187,7 +207,7 @@ void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint3
 void launch_pack_u8(hipStream_t s, const float* src, unsigned char* dst, size_t n);
 
 void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
-                         const float4* rec, const uint32_t* tiles, const uint32_t* tile_keys,
+                         const RecView rec, const uint32_t* tiles, const uint32_t* tile_keys,
                          const uint32_t* point_list, const uint2* ranges,
                          const uint32_t* n_contrib_in, uint64_t* keys_sorted,
                          uint32_t* point_list_out, uint32_t* ranges_out, uint32_t* n_contrib_out,

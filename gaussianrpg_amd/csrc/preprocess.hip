@@ -118,7 +118,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   const float* __restrict__ proj, const float* __restrict__ campos, const int W,
                   const int H, const int gx, const int gy, const float tan_fovx,
                   const float tan_fovy, const float focal_x, const float focal_y,
-                  int* __restrict__ radii, float4* __restrict__ rec,
+                  int* __restrict__ radii, float4* __restrict__ geo, float4* __restrict__ col,
                   uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
                   const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
   // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
@@ -184,9 +184,9 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   radii[idx] = o.radius;
   tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
   depth_key[idx] = __float_as_uint(o.depth);
-  rec[3 * idx + 0] = make_float4(o.px, o.py, o.depth, opacities[idx]);
-  rec[3 * idx + 1] = make_float4(o.conic[0], o.conic[1], o.conic[2], rgb[0]);
-  rec[3 * idx + 2] = make_float4(rgb[1], rgb[2], __uint_as_float(clamped), __int_as_float(o.radius));
+  geo[2 * idx + 0] = make_float4(o.px, o.py, opacities[idx], __int_as_float(o.radius));
+  geo[2 * idx + 1] = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
+  col[idx] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
 }
 
 __global__ void __launch_bounds__(256)
@@ -229,12 +229,12 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* rec, uint32_t* depth_key, uint32_t* tiles) {
+                       float4* geo, float4* col, uint32_t* depth_key, uint32_t* tiles) {
   if (P <= 0) return;
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
       colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
-      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles,
+      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, geo, col, depth_key, tiles,
       ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
 }
 

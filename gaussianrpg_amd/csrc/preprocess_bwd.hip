@@ -9,7 +9,7 @@
 //
 // Sigma and T are RECOMPUTED with the forward's own functions (gaussian_math.h, same
 // -ffp-contract=off arithmetic), so nothing but the 48-byte record survives from the forward;
-// the SH clamp mask comes from rec[2].z.  HBM-bound streaming kernel: reads (71+12M) B and
+// the SH clamp mask comes from col[id].w.  HBM-bound streaming kernel: reads (71+12M) B and
 // writes up to (64+12M) B per Gaussian.
 #include "common.h"
 
@@ -154,7 +154,7 @@ __device__ __forceinline__ void cov3d_backward(const float s0, const float s1, c
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(const int P, const int D, const int M, const float* __restrict__ means3D,
                            const int* __restrict__ radii, const float* __restrict__ shs,
-                           const float4* __restrict__ rec, const float* __restrict__ scales,
+                           const RecView rec, const float* __restrict__ scales,
                            const float* __restrict__ rotations, const float scale_modifier,
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                            const float* __restrict__ proj, const float* __restrict__ campos,
@@ -246,7 +246,7 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   const float d2z = (view[10] - view[11] * mul3) * gdep;
   gmx += d2x; gmy += d2y; gmz += d2z;
   if (shs != nullptr) {
-    const uint32_t clamped = __float_as_uint(rec[3 * (size_t)idx + 2].z);
+    const uint32_t clamped = __float_as_uint(rec.col[idx].w);
     const float dc3[3] = {dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
     float sx, sy, sz;
     sh_backward(D, shs + (size_t)idx * M * 3, mx - campos[0], my - campos[1], mz - campos[2],
@@ -266,7 +266,7 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
 }
 
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,
-                                const int* radii, const float* shs, const float4* rec,
+                                const int* radii, const float* shs, const RecView rec,
                                 const float* scales, const float* rotations, float scale_modifier,
                                 const float* cov3D_precomp, const CameraArgs& cam,
                                 const float* dL_dmean2D, const float* dL_dconic,

@@ -57,7 +57,7 @@ template <int PX, int SMAX>
 __device__ __forceinline__ void backward_rect(
     float4* __restrict__ my, const int lane, const uint32_t r_begin, const uint32_t r_end,
     const int x0, const int y0, const uint32_t bits_mask, const int W, const int H, const int S,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    const uint32_t* __restrict__ point_list, const RecView rec,
     const float* __restrict__ semantics, const float* __restrict__ bg,
     const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
@@ -119,8 +119,7 @@ __device__ __forceinline__ void backward_rect(
       const uint32_t v = point_list[r_begin + lo + lane];
       if (v & bits_mask) {   // the splat can reach this wave's pixels: only now touch its record
         lid = v & ID_MASK;
-        const float4* r = rec + (size_t)lid * REC_F4;
-        la = r[0]; lb = r[1]; lc = r[2];
+        rec.load(lid, la, lb, lc);
         keep = !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);
       }
     }
@@ -253,7 +252,7 @@ constexpr int NUM_CLASSES_B = 4;
 template <int SMAX>
 __global__ void __launch_bounds__(256)
 render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                       const float4* __restrict__ rec, const float* __restrict__ semantics,
+                       const RecView rec, const float* __restrict__ semantics,
                        const int S, const int W, const int H, const int gx, const uint32_t T,
                        const uint32_t* __restrict__ work, const float* __restrict__ bg,
                        const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
@@ -294,7 +293,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 }
 
 void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                            const float4* rec, const float* semantics, int S, int W, int H, int gx,
+                            const RecView rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,

@@ -215,14 +215,14 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
   return true;
 }
 
-struct WaveTrace { uint32_t batches, survivors, blends, t_stage, t_loop; };
+struct WaveTrace { uint32_t batches, survivors, blends, t_stage, t_loop; uint32_t it[4], cyc[4]; };
 
 template <int PX, int GPI, bool WRITE_AUX, bool TRACE = false>
 __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int lane,
                                            const uint32_t r_begin, const uint32_t r_end,
                                            const int x0, const int y0, const int W, const int H,
                                            const uint32_t* __restrict__ point_list,
-                                           const float4* __restrict__ rec,
+                                           const RecView rec,
                                            const float* __restrict__ bg,
                                            float* __restrict__ out_color,
                                            float* __restrict__ out_depth,
@@ -259,8 +259,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     const uint32_t v0 = point_list[r_begin + lane];
     live_n = (v0 >> SUBTILE_SHIFT) != 0u;
     if (live_n) {
-      const float4* r = rec + (size_t)(v0 & ID_MASK) * REC_F4;
-      a_n = r[0]; b_n = r[1]; c_n = r[2];
+      rec.load(v0 & ID_MASK, a_n, b_n, c_n);
     }
   }
   if (r_begin + WAVE + (uint32_t)lane < r_end) id_n2 = point_list[r_begin + WAVE + lane];
@@ -303,8 +302,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     if (base + WAVE + (uint32_t)lane < r_end) {        // records of the next batch
       live_n = (id_n2 >> SUBTILE_SHIFT) != 0u;
       if (live_n) {
-        const float4* r = rec + (size_t)(id_n2 & ID_MASK) * REC_F4;
-        a_n = r[0]; b_n = r[1]; c_n = r[2];
+        rec.load(id_n2 & ID_MASK, a_n, b_n, c_n);
       }
     }
     if (base + 2 * WAVE + (uint32_t)lane < r_end)      // ids of the batch after that
@@ -383,7 +381,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                                             const uint32_t r_end, const int x0, const int y0,
                                             const int W, const int H,
                                             const uint32_t* __restrict__ point_list,
-                                            const float4* __restrict__ rec,
+                                            const RecView rec,
                                             const float* __restrict__ bg,
                                             float* __restrict__ out_color,
                                             float* __restrict__ out_depth,
@@ -467,8 +465,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
       const uint32_t slot = (head + lane) & (QCAP - 1);
       const uint32_t id = qid[slot];
       pos_n = qpos[slot];
-      const float4* r = rec + (size_t)id * REC_F4;
-      a_n = r[0]; b_n = r[1]; c_n = r[2];
+      rec.load(id, a_n, b_n, c_n);
     }
     head = (head + nn) & (QCAP - 1);
     count -= nn;
@@ -495,7 +492,13 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
         const bool blended = blend_quad(st, my, j0, pxf, (float)py);
         if (TRACE && blended) tr->blends++;
       }
-      if (TRACE) tr->t_loop += (uint32_t)(__builtin_readcyclecounter() - tc1);
+      if (TRACE) {
+        const uint64_t tc2 = __builtin_readcyclecounter();
+        tr->t_loop += (uint32_t)(tc2 - tc1);
+        const int na = (int)__popcll(alive);   // live pixels when this batch was culled
+        const int bk = na <= 2 ? 0 : (na <= 8 ? 1 : (na <= 24 ? 2 : 3));
+        tr->it[bk]++; tr->cyc[bk] += (uint32_t)(tc2 - tc0);
+      }
       __builtin_amdgcn_wave_barrier();
     }
     a = a_n; b = b_n; c = c_n; pos = pos_n; ncur = nn;
@@ -521,7 +524,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 template <bool WRITE_AUX, int GPI_H, int GPI_L, bool TRACE = false>
 __global__ void __launch_bounds__(256, GRPG_RENDER_MIN_WAVES)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const float4* __restrict__ rec, const int W, const int H, const int gx,
+                      const RecView rec, const int W, const int H, const int gx,
                       const uint32_t T, const uint32_t* __restrict__ work,
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -531,7 +534,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  WaveTrace tr = {0, 0, 0, 0, 0};
+  WaveTrace tr = {0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
   const uint64_t t_start = TRACE ? wall_clock64() : 0;
   uint32_t tr_tile = 0xFFFFFFFFu, tr_len = 0;
   const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
@@ -571,6 +574,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     o[7] = (uint32_t)wave | ((tr.t_stage >> 8) << 4);   // stage cycles / 256 in the upper bits
     o[2] = tr.batches | 0u; o[4] = tr.blends;
     trace[(size_t)gridDim.x * RW_WAVES * 8 + ((size_t)blockIdx.x * RW_WAVES + wave)] = tr.t_loop;
+    uint32_t* o2 = trace + (size_t)gridDim.x * RW_WAVES * 9 + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
+    for (int i = 0; i < 4; i++) { o2[i] = tr.it[i]; o2[4 + i] = tr.cyc[i]; }
   }
 }
 
@@ -581,7 +586,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 template <int NCH>
 __global__ void __launch_bounds__(256)
 render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                       const float4* __restrict__ rec, const float* __restrict__ semantics,
+                       const RecView rec, const float* __restrict__ semantics,
                        const int S, const int c0, const int W, const int H, const int gx,
                        const int ntiles, float* __restrict__ out_semantic) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * 2];
@@ -611,9 +616,10 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     const uint32_t n = min((uint32_t)WAVE, range.y - base);
     if ((uint32_t)lane < n) {
       const uint32_t id = point_list[base + lane] & ID_MASK;
-      const float4* r = rec + (size_t)id * REC_F4;
-      my[lane * 2 + 0] = r[0];
-      my[lane * 2 + 1] = r[1];
+      float4 ra, rb, rc;
+      rec.load(id, ra, rb, rc);
+      my[lane * 2 + 0] = ra;
+      my[lane * 2 + 1] = rb;
 #pragma unroll
       for (int c = 0; c < NCH; c++)
         mysem[lane * NCH + c] = (c0 + c < S) ? semantics[(size_t)id * S + c0 + c] : 0.f;
@@ -657,7 +663,7 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 }
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                           const float4* rec, int W, int H, int gx, int gy, const float* bg,
+                           const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
                            uint32_t heavy_min) {
@@ -674,7 +680,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
   if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
     uint32_t* d_trace = nullptr;
-    const size_t words = (size_t)ntiles * RW_WAVES * 9;
+    const size_t words = (size_t)ntiles * RW_WAVES * 17;
     if (hipMalloc((void**)&d_trace, words * 4) == hipSuccess) {
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
       render_forward_kernel<true, 4, 1, true><<<ntiles, 256, 0, s>>>(
@@ -700,7 +706,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
 }
 
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                            const float4* rec, const float* semantics, int S, int W, int H, int gx,
+                            const RecView rec, const float* semantics, int S, int W, int H, int gx,
                             int gy, float* out_semantic) {
   const int ntiles = gx * gy;
   if (ntiles <= 0 || S <= 0) return;

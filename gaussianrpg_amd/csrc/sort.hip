@@ -453,7 +453,9 @@ scan_spine_kernel(uint32_t* __restrict__ block_sums, const uint32_t nblocks,
 
 __global__ void __launch_bounds__(SC_THREADS)
 scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
-                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets) {
+                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets,
+                 const uint32_t* __restrict__ total, uint32_t* __restrict__ emit_win,
+                 const uint32_t emit_win_cap) {
   __shared__ uint32_t s_wave[4];
   // thread t owns SC_ITEMS consecutive elements so that the scan order is the array order
   const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
@@ -470,17 +472,29 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
   for (int k = 0; k < SC_ITEMS; k++) {
     const uint32_t i = base + k;
     if (i < n) offsets[i] = ex;
+    // Element i owns instance slots [ex, ex + v): tell emit (binning.hip) which element owns the
+    // first slot of each of its 1024-slot blocks, and which element owns the very last slot.
+    if (v[k] > 0) {
+      const uint32_t end = ex + v[k];
+      for (uint32_t b = (ex + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK; b * EMIT_PER_BLOCK < end; b++)
+        if (b <= emit_win_cap) emit_win[b] = i;
+      if (end == *total) {
+        const uint32_t nb = (end + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK;
+        if (nb <= emit_win_cap && nb * EMIT_PER_BLOCK >= end) emit_win[nb] = i;
+      }
+    }
     ex += v[k];
   }
 }
 
 void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted,
                          uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
-                         uint32_t* total_out) {
+                         uint32_t* total_out, uint32_t* emit_win, uint32_t emit_win_cap) {
   if (n == 0) return;
   scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums);
   scan_spine_kernel<<<1, 256, 0, s>>>(block_sums, nblocks, total_out);
-  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums, offsets);
+  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums, offsets, total_out,
+                                                   emit_win, emit_win_cap);
 }
 
 }  // namespace grpg

@@ -2,10 +2,12 @@
 import sys
 import numpy as np
 raw = np.fromfile(sys.argv[1], dtype=np.uint32)
-nw = raw.size // 9
+nw = raw.size // 17
 t = raw[:nw * 8].reshape(-1, 8)
-tloop = raw[nw * 8:]
+tloop = raw[nw * 8:nw * 9]
+bucket = raw[nw * 9:].reshape(-1, 8)   # BLEND iterations / cycles by live-pixel count (<=2, <=8, <=24, >24)
 sel = t[:, 0] != 0xFFFFFFFF
+bucket = bucket[sel].astype(np.int64)
 v = t[sel]
 tloop = tloop[sel].astype(np.int64)
 tstage = (v[:, 7] >> 4).astype(np.int64) * 256
@@ -20,3 +22,8 @@ for i in np.argsort(-cyc)[:3]:
     print("  tile %d wave %d len %d batches %d surv %d blends %d  %.1f us  %.3f us/batch  stage %d cyc/batch  loop %d cyc/batch" % (
         tile[i], v[i, 7] & 15, v[i, 1], b[i], sv[i], bl[i], cyc[i] / 100, cyc[i] / max(b[i], 1) / 100,
         tstage[i] / max(b[i], 1), tloop[i] / max(b[i], 1)))
+print("heavy BLEND iterations by live pixels of the quarter (<=2, <=8, <=24, >24):")
+hb = bucket[~light]
+print("  all heavy waves: iters", hb[:, :4].sum(0), " Mcycles", (hb[:, 4:].sum(0) / 1e6).round(1))
+for i in np.argsort(-cyc)[:3]:
+    print("  tile %d wave %d: iters %s kcycles %s" % (tile[i], v[i, 7] & 15, bucket[i, :4], (bucket[i, 4:] / 1e3).round(0)))
