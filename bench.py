@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the frame loop alternates over (independent frames; 1 = serial)")
+    ap.add_argument("--host-threads", type=int, default=1,
+                    help="host threads issuing frames (each alternates over streams/host-threads "
+                         "streams); the op releases the GIL while it waits for num_rendered")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -193,10 +196,27 @@ def main():
         # VALU/latency-bound render of frame k overlaps the HBM-bound binning of frame k+1 and the
         # one host round trip per frame (num_rendered) no longer idles the GPU.
         streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+        nthreads = max(1, min(args.host_threads, len(streams)))
         t0 = time.perf_counter()
-        for s in range(K):
-            with torch.cuda.stream(streams[s % len(streams)]):
-                local[s] = tj.pack_u8(render_frame(frames_of(s)))
+        if nthreads == 1:
+            for s in range(K):
+                with torch.cuda.stream(streams[s % len(streams)]):
+                    local[s] = tj.pack_u8(render_frame(frames_of(s)))
+        else:
+            import threading
+
+            def issue(t):
+                torch.cuda.set_device(dev)
+                mine = streams[t::nthreads]
+                for n, s in enumerate(range(t, K, nthreads)):
+                    with torch.cuda.stream(mine[n % len(mine)]):
+                        local[s] = tj.pack_u8(render_frame(frames_of(s)))
+
+            workers = [threading.Thread(target=issue, args=(t,)) for t in range(nthreads)]
+            for w in workers:
+                w.start()
+            for w in workers:
+                w.join()
         for st_ in streams:
             torch.cuda.current_stream().wait_stream(st_)
         if world > 1:
@@ -281,6 +301,7 @@ def main():
                        "P": P, "V_avg": V_avg, "R_avg": R_avg, "T": T_tiles, "width": W,
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
                        "streams_per_gpu": max(1, args.streams),
+                       "host_threads_per_gpu": max(1, min(args.host_threads, max(1, args.streams))),
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
             "roofline": roof,
             "frame_roofline": {"bound": "hbm", "achieved": ach_f, "peak": HBM_PEAK_GBS,

@@ -110,13 +110,22 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
   TORCH_CHECK(p_bg && p_view && p_proj && p_cam, "bg/viewmatrix/projmatrix/campos must be non-empty");
 
   hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-  const int rendered = grpg_forward(
-      resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree, M,
-      S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov, p_view,
-      p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, out_color.data_ptr<float>(),
-      out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
-      S > 0 ? out_semantic.data_ptr<float>() : nullptr, P > 0 ? radii.data_ptr<int>() : nullptr,
-      debug ? 1 : 0, (void*)stream);
+  float* p_out_color = out_color.data_ptr<float>();
+  float* p_out_depth = out_depth.data_ptr<float>();
+  float* p_out_alpha = out_alpha.data_ptr<float>();
+  float* p_out_sem = S > 0 ? out_semantic.data_ptr<float>() : nullptr;
+  int* p_radii = P > 0 ? radii.data_ptr<int>() : nullptr;
+  int rendered;
+  {
+    // The call blocks once on the stream (num_rendered read-back): let other Python threads drive
+    // their own streams meanwhile.  The blob callbacks only touch ATen, never Python objects.
+    pybind11::gil_scoped_release nogil;
+    rendered = grpg_forward(
+        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree,
+        M, S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov,
+        p_view, p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, p_out_color, p_out_depth,
+        p_out_alpha, p_out_sem, p_radii, debug ? 1 : 0, (void*)stream);
+  }
   if (rendered < 0) raise_abi_error("grpg_forward", rendered);
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, out_semantic, radii,
                          geomBuffer, binningBuffer, imgBuffer);
