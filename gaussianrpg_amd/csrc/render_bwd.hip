@@ -154,7 +154,10 @@ __device__ __forceinline__ void backward_rect(
         const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]);
         if (valid) {
           any = true;
-          T[k] = T[k] / (1.f - alpha);
+          // one reciprocal serves both divisions of backward.cu:547,596 (1 ulp: the recovered T is
+          // the inverse of a rounded product chain anyway)
+          const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+          T[k] = T[k] * inv_1ma;
           const float dch = alpha * T[k];
           float dL_dopa = 0.f;
           acc_r[k] = last_alpha[k] * last_r[k] + (1.f - last_alpha[k]) * acc_r[k];
@@ -189,7 +192,7 @@ __device__ __forceinline__ void backward_rect(
           dL_dopa += (1.f - acc_a[k]) * dLa[k];
           dL_dopa *= T[k];
           last_alpha[k] = alpha;
-          dL_dopa += (-T_final[k] / (1.f - alpha)) * bgdot[k];
+          dL_dopa += (-T_final[k] * inv_1ma) * bgdot[k];
           const float dL_dG = a.w * dL_dopa;
           const float gdx = G * dx, gdy = G * dy;
           const float dG_ddelx = -gdx * b.x - gdy * b.y;
