@@ -21,12 +21,16 @@
 //     (wave, Gaussian): 64-256x fewer atomics.  Summation order differs from the reference's
 //     (unspecified) atomic order, so gradients agree to rounding, not bitwise -- exactly as two
 //     runs of the reference differ from each other.
+#include <cstdlib>
+
 #include "blend_math.h"
 #include "common.h"
 
 namespace grpg {
 
 constexpr int RB_WAVES = 4;
+constexpr int BQCAP = 512;     // ring capacity in entries (>= 64 + 256), power of two
+constexpr int BFILL_Q = 4;     // list entries per lane per FILL step
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_step(float v) {
@@ -45,6 +49,40 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Row sum (16 lanes) left in EVERY lane of the row: 4 DPP adds.
+__device__ __forceinline__ float row_sum_all(float v) {
+  v = dpp_step<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_step<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_step<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_step<0x140, 0xF>(v);  // row_mirror
+  return v;
+}
+
+// Halving exchanges of gfx950: a and b are two different quantities to be summed over the wave.
+// After the call `a` holds, in lanes 0-31, (a of lane L) + (a of lane L+32), and in lanes 32-63 the
+// same for b: two quantities cost one swap + one add instead of two full-width butterfly steps.
+__device__ __forceinline__ float halve32(const float a, const float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Same across the two 16-lane rows of each half: even rows end up with a, odd rows with b.
+__device__ __forceinline__ float halve16(const float a, const float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Wave totals of 12 quantities in 30 VALU instructions (66+ with one butterfly each).
+// Row r (lanes 16r .. 16r+15) returns in out[k] the total of v[k + 3 r]:
+//   step 1 pairs (v[k], v[k+6]) across the wave halves, step 2 pairs (., .+3) across rows,
+//   then a 16-lane row sum.
+__device__ __forceinline__ void wave_sum_12(const float (&v)[12], float (&out)[3]) {
+  float h[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) h[k] = halve32(v[k], v[k + 6]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[k] = row_sum_all(halve16(h[k], h[k + 3]));
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -55,7 +93,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // of a point-list entry that concern this wave (one bit for a quarter, all four for a whole tile).
 template <int PX, int SMAX>
 __device__ __forceinline__ void backward_rect(
-    float4* __restrict__ my, const int lane, const uint32_t r_begin, const uint32_t r_end,
+    float4* __restrict__ my, uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
+    const int lane, const uint32_t r_begin, const uint32_t r_end,
     const int x0, const int y0, const uint32_t bits_mask, const int W, const int H, const int S,
     const uint32_t* __restrict__ point_list, const RecView rec,
     const float* __restrict__ semantics, const float* __restrict__ bg,
@@ -64,7 +103,7 @@ __device__ __forceinline__ void backward_rect(
     const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpix_semantic,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
-    float* __restrict__ dL_dsemantic) {
+    float* __restrict__ dL_dsemantic, const int ablate) {
   constexpr int SM = SMAX > 0 ? SMAX : 1;
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
@@ -107,30 +146,90 @@ __device__ __forceinline__ void backward_rect(
   maxlast = wave_max_u32(maxlast);   // nothing behind the tile's deepest contributor matters
   const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:501-502
 
-  const uint64_t gt = ~(lanemask_lt() | (1ull << lane));   // lanes above this one
+  // Gradient scatter: after wave_sum_12 row r of the wave holds the totals of quantities 3r..3r+2
+  //   row 0: dL_dmean2D x, y, |.|   row 1: dL_dconic xx, xy, yy   row 2: dL_dcolor r, g, b
+  //   row 3: dL_dopacity, dL_ddepth, -
+  // Lane 16 r + k takes quantity 3 r + k, so ONE global_atomic_add_f32 with 11 active lanes covers a
+  // Gaussian: 5 cache lines per (wave, Gaussian) instead of 11 single-lane atomics.
+  const int row = lane >> 4, sub = lane & 15;
+  float* sc_ptr = nullptr;
+  uint32_t sc_stride = 0;
+  if (sub < 3) {
+    if (row == 0) { sc_ptr = dL_dmean2D + sub; sc_stride = 3; }
+    else if (row == 1) { sc_ptr = dL_dconic + (sub == 2 ? 3 : sub); sc_stride = 4; }
+    else if (row == 2) { sc_ptr = dL_dcolor + sub; sc_stride = 3; }
+    else if (sub < 2) { sc_ptr = sub == 0 ? dL_dopacity : dL_ddepth; sc_stride = 1; }
+  }
+
+  // Back-to-front traversal of list positions [0, count), decoupled like the forward's heavy path
+  // (render_fwd.hip): FILL scans 256 entries per step (prefetched one window ahead) and appends
+  // the ones whose sub-tile mask concerns this wave to an LDS ring, deepest first; POP takes up to
+  // 64 of them and starts the gather of their records; the PREVIOUS batch is culled, compacted and
+  // processed while that gather is in flight.  A dead entry costs 1/256 of a FILL step and no
+  // record is loaded for it; in a horizon tile only one entry in six concerns a given quarter.
+  const uint64_t lt = lanemask_lt();
   const uint32_t count = min(r_end - r_begin, maxlast);
-  for (uint32_t hi = count; hi > 0;) {
-    const uint32_t n = hi >= (uint32_t)WAVE ? (uint32_t)WAVE : hi;
-    const uint32_t lo = hi - n;   // batch covers list positions [lo, hi)
-    bool keep = false;
-    float4 la = make_float4(0, 0, 0, 0), lb = la, lc = la;
-    uint32_t lid = 0;
-    if ((uint32_t)lane < n) {
-      const uint32_t v = point_list[r_begin + lo + lane];
-      if (v & bits_mask) {   // the splat can reach this wave's pixels: only now touch its record
-        lid = v & ID_MASK;
-        rec.load(lid, la, lb, lc);
-        keep = !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);
+  uint32_t in_hi = count;           // list positions [0, in_hi) are still unread (wave-uniform)
+  uint32_t head = 0, rcount = 0;    // ring state                                (wave-uniform)
+  uint32_t win[BFILL_Q];
+#pragma unroll
+  for (int q = 0; q < BFILL_Q; q++) {
+    const uint32_t off = (uint32_t)(q * WAVE + lane);
+    win[q] = off < in_hi ? point_list[r_begin + in_hi - 1 - off] : 0u;
+  }
+  float4 la = make_float4(0, 0, 0, 0), lb = la, lc = la;   // current batch (records arrived)
+  uint32_t lpos = 0, lid = 0, ncur = 0;
+  for (;;) {
+    // ---- FILL ----
+    while (rcount < (uint32_t)WAVE && in_hi > 0) {
+      uint32_t v[BFILL_Q];
+#pragma unroll
+      for (int q = 0; q < BFILL_Q; q++) v[q] = win[q];
+      const uint32_t nxt = in_hi > (uint32_t)(BFILL_Q * WAVE) ? in_hi - BFILL_Q * WAVE : 0u;
+#pragma unroll
+      for (int q = 0; q < BFILL_Q; q++) {
+        const uint32_t off = (uint32_t)(q * WAVE + lane);
+        win[q] = off < nxt ? point_list[r_begin + nxt - 1 - off] : 0u;
       }
+#pragma unroll
+      for (int q = 0; q < BFILL_Q; q++) {
+        const uint32_t off = (uint32_t)(q * WAVE + lane);
+        const bool keep = (off < in_hi) && (v[q] & bits_mask);
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const uint32_t slot = (head + rcount + (uint32_t)__popcll(m & lt)) & (BQCAP - 1);
+          qid[slot] = v[q] & ID_MASK;
+          qpos[slot] = in_hi - 1 - off;   // 0-based list position == the reference's `contributor`
+        }
+        rcount += (uint32_t)__popcll(m);
+      }
+      in_hi = nxt;
     }
-    const uint64_t mask = __ballot(keep);
-    const int cnt = (int)__popcll(mask);
-    if (keep) {   // deepest entry (highest lane) first
-      const int slot = (int)__popcll(mask & gt);
-      my[slot * REC_F4 + 0] = la;
-      my[slot * REC_F4 + 1] = lb;
-      my[slot * REC_F4 + 2] = make_float4(lc.x, lc.y, __uint_as_float(lo + (uint32_t)lane),
-                                          __uint_as_float(lid));
+    // ---- POP: next batch of up to 64 entries (deepest first), start its record gather ----
+    const uint32_t nn = min(rcount, (uint32_t)WAVE);
+    float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
+    uint32_t npos = 0, nid = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (BQCAP - 1);
+      nid = qid[slot];
+      npos = qpos[slot];
+      rec.load(nid, na, nb, nc);
+    }
+    head = (head + nn) & (BQCAP - 1);
+    rcount -= nn;
+    // ---- the previous batch: cull, compact (deepest first), process ----
+    int cnt = 0;
+    if (ncur > 0) {
+      const bool keep = ((uint32_t)lane < ncur) &&
+                        !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);
+      const uint64_t mask = __ballot(keep);
+      cnt = (int)__popcll(mask);
+      if (keep) {
+        const int slot = (int)__popcll(mask & lt);
+        my[slot * REC_F4 + 0] = la;
+        my[slot * REC_F4 + 1] = lb;
+        my[slot * REC_F4 + 2] = make_float4(lc.x, lc.y, __uint_as_float(lpos), __uint_as_float(lid));
+      }
     }
     __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < cnt; j++) {
@@ -151,7 +250,8 @@ __device__ __forceinline__ void backward_rect(
       for (int k = 0; k < PX; k++) {
         const float dy = a.y - (float)(py0 + k);
         float G, alpha;   // identical arithmetic to the forward (blend_math.h)
-        const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]);
+        const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]) &&
+                           !(ablate & 4);
         if (valid) {
           any = true;
           // one reciprocal serves both divisions of backward.cu:547,596 (1 ulp: the recovered T is
@@ -209,34 +309,18 @@ __device__ __forceinline__ void backward_rect(
         }
       }
       if (__ballot(any) == 0ull) continue;   // wave-uniform: nobody in the tile used this splat
-      g_mx = wave_sum_to_lane63(g_mx);
-      g_my = wave_sum_to_lane63(g_my);
-      g_mabs = wave_sum_to_lane63(g_mabs);
-      g_cx = wave_sum_to_lane63(g_cx);
-      g_cy = wave_sum_to_lane63(g_cy);
-      g_cw = wave_sum_to_lane63(g_cw);
-      g_op = wave_sum_to_lane63(g_op);
-      g_r = wave_sum_to_lane63(g_r);
-      g_g = wave_sum_to_lane63(g_g);
-      g_b = wave_sum_to_lane63(g_b);
-      g_d = wave_sum_to_lane63(g_d);
+      if (ablate & 2) continue;   // experiment switch (GRPG_BWD_ABLATE): no reduction, no atomics
+      {
+        const float q[12] = {g_mx, g_my, g_mabs, g_cx, g_cy, g_cw, g_r, g_g, g_b, g_op, g_d, 0.f};
+        float tot[3];
+        wave_sum_12(q, tot);
+        if (sc_ptr && !(ablate & 1))
+          atomicAdd(sc_ptr + (size_t)gid * sc_stride, sub == 0 ? tot[0] : (sub == 1 ? tot[1] : tot[2]));
+      }
       if (SMAX > 0) {
 #pragma unroll
         for (int cc = 0; cc < SM; cc++) g_s[cc] = wave_sum_to_lane63(g_s[cc]);
-      }
-      if (lane == 63) {
-        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 0], g_mx);
-        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 1], g_my);
-        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 2], g_mabs);
-        atomicAdd(&dL_dconic[4 * (size_t)gid + 0], g_cx);
-        atomicAdd(&dL_dconic[4 * (size_t)gid + 1], g_cy);
-        atomicAdd(&dL_dconic[4 * (size_t)gid + 3], g_cw);
-        atomicAdd(&dL_dopacity[gid], g_op);
-        atomicAdd(&dL_dcolor[3 * (size_t)gid + 0], g_r);
-        atomicAdd(&dL_dcolor[3 * (size_t)gid + 1], g_g);
-        atomicAdd(&dL_dcolor[3 * (size_t)gid + 2], g_b);
-        atomicAdd(&dL_ddepth[gid], g_d);
-        if (SMAX > 0) {
+        if (lane == 63) {
 #pragma unroll
           for (int cc = 0; cc < SM; cc++)
             if (cc < S) atomicAdd(&dL_dsemantic[(size_t)gid * S + cc], g_s[cc]);
@@ -244,7 +328,8 @@ __device__ __forceinline__ void backward_rect(
       }
     }
     __builtin_amdgcn_wave_barrier();
-    hi = lo;
+    la = na; lb = nb; lc = nc; lpos = npos; lid = nid; ncur = nn;
+    if (ncur == 0 && in_hi == 0) break;   // ring empty (rcount == 0 here) and list exhausted
   }
 }
 
@@ -264,8 +349,10 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                        const float* __restrict__ dL_dpix_semantic, float* __restrict__ dL_dmean2D,
                        float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                        float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
-                       float* __restrict__ dL_dsemantic) {
+                       float* __restrict__ dL_dsemantic, const int ablate) {
   __shared__ float4 s_rec[RB_WAVES][WAVE * REC_F4];
+  __shared__ uint32_t s_qid[RB_WAVES][BQCAP];
+  __shared__ uint32_t s_qpos[RB_WAVES][BQCAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
   const uint32_t nheavy = n0 + n1 + n2;
@@ -284,10 +371,10 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
   const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
 #define RB_CALL(PXV, YOFF, BITS)                                                                  \
-  backward_rect<PXV, SMAX>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE + (YOFF), (BITS), W, H, \
+  backward_rect<PXV, SMAX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, rb, re, tx * TILE, ty * TILE + (YOFF), (BITS), W, H, \
                            S, point_list, rec, semantics, bg, alphas, n_contrib, dL_dpix,          \
                            dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic,     \
-                           dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic)
+                           dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, ablate)
   if (b < nheavy)
     RB_CALL(1, wave * 4, 1u << (SUBTILE_SHIFT + wave));
   else
@@ -305,10 +392,12 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             float* dL_dsemantic) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
+  // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
+  static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
 #define RB_ARGS                                                                                  \
   ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
       dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity,  \
-      dL_dcolor, dL_ddepth, dL_dsemantic
+      dL_dcolor, dL_ddepth, dL_dsemantic, ablate
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
   if (S <= 0)
     render_backward_kernel<0><<<ntiles, 256, 0, s>>>(RB_ARGS);
