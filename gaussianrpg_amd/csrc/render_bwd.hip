@@ -9,18 +9,22 @@
 // image blob are reused):
 //   * LIGHT tiles: one wave per tile, 4 pixels per lane.  HEAVY tiles: four 16x4 quarter-tile
 //     waves at 1 pixel per lane (a heavy tile no longer serialises behind one wave).
-//   * Per batch of 64 list entries (walked back to front, only up to the deepest contributor of
-//     the wave's pixels) a lane first looks at the sub-tile mask that emit stored in the point-list
-//     entry: the 48-byte record of a splat that cannot reach the wave's pixels is never loaded.
-//     Survivors are culled against the wave's pixel rectangle, compacted (deepest first) into the
-//     wave's LDS slice and only those are evaluated.
-//   * The reference issues 11+S float atomics per (pixel, Gaussian) pair.  Here the 11+S partial
-//     gradients of a splat are summed over the lane's pixels in registers, reduced across the wave
-//     with 6 DPP adds each (quad_perm x2, row_half_mirror, row_mirror, row_bcast15, row_bcast31 --
-//     no LDS traffic) and lane 63 issues ONE hardware global_atomic_add_f32 per field per
-//     (wave, Gaussian): 64-256x fewer atomics.  Summation order differs from the reference's
-//     (unspecified) atomic order, so gradients agree to rounding, not bitwise -- exactly as two
-//     runs of the reference differ from each other.
+//   * The list is walked back to front, only up to the deepest contributor of the wave's pixels,
+//     through the forward's FILL / POP / process pipeline: FILL scans 256 entries per step and
+//     keeps those whose sub-tile mask (set by emit) concerns the wave in an LDS ring; POP starts
+//     the record gather of up to 64 of them; the previous batch is meanwhile culled against the
+//     bounding box of the pixels that are ACTIVE at that depth (last contributor behind the
+//     batch), compacted deepest-first into LDS and processed.  No record is loaded for an entry
+//     the mask rules out.
+//   * The reference issues 11+S float atomics per (pixel, Gaussian) pair.  Here the 11 partial
+//     gradients of a splat are summed over the lane's pixels in registers and reduced across the
+//     wave together: two halving exchanges (v_permlane32_swap / v_permlane16_swap: two
+//     quantities per swap + add) leave three quantities per 16-lane row, four DPP adds finish the
+//     row sums -- 30 VALU instructions for all of them -- and lane 16 r + k of row r then owns
+//     quantity 3 r + k, so ONE global_atomic_add_f32 with 11 active lanes (5 cache lines) updates
+//     the Gaussian: 64-256x fewer atomic operations than the reference.  Summation order differs
+//     from the reference's (unspecified) atomic order, so gradients agree to rounding, not
+//     bitwise -- exactly as two runs of the reference differ from each other.
 #include <cstdlib>
 
 #include "blend_math.h"
@@ -108,8 +112,11 @@ __device__ __forceinline__ void backward_rect(
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
   const float pxf = (float)px;
-  const float rx0 = (float)x0, rx1 = (float)(x0 + 15);
-  const float ry0 = (float)y0, ry1 = (float)(y0 + 4 * PX - 1);
+  float rx0 = (float)x0, rx1 = (float)(x0 + 15);   // cull rectangle, see the active-pixel box below
+  float ry0 = (float)y0, ry1 = (float)(y0 + 4 * PX - 1);
+  uint64_t prev_act[PX];
+#pragma unroll
+  for (int k = 0; k < PX; k++) prev_act[k] = ~0ull;
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
@@ -220,6 +227,37 @@ __device__ __forceinline__ void backward_rect(
     // ---- the previous batch: cull, compact (deepest first), process ----
     int cnt = 0;
     if (ncur > 0) {
+      // Only pixels whose last contributor lies behind the batch's shallowest entry can use any of
+      // its splats: cull against the bounding box of THOSE pixels (it grows as the walk approaches
+      // the front; in a horizon tile only the never-saturating sky pixels are active for most of
+      // the list).  Exact: a splat is dropped only if no active pixel can accept it.
+      const uint32_t pos_min = (uint32_t)__builtin_amdgcn_readlane((int)lpos, (int)ncur - 1);
+      bool changed = false;
+#pragma unroll
+      for (int k = 0; k < PX; k++) {
+        const uint64_t act = __ballot(lastc[k] > pos_min);
+        changed = changed || (act != prev_act[k]);
+        prev_act[k] = act;
+      }
+      if (changed) {
+        float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+#pragma unroll
+        for (int k = 0; k < PX; k++) {
+          if (lastc[k] > pos_min) {
+            bx0 = pxf; bx1 = pxf;
+            by0 = fminf(by0, (float)(py0 + k));
+            by1 = fmaxf(by1, (float)(py0 + k));
+          }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+          bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+          by0 = fminf(by0, __shfl_xor(by0, d, 64));
+          by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+        }
+        rx0 = bx0; rx1 = bx1; ry0 = by0; ry1 = by1;
+      }
       const bool keep = ((uint32_t)lane < ncur) &&
                         !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);
       const uint64_t mask = __ballot(keep);
