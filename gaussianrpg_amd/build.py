@@ -33,6 +33,8 @@ HIP_UNITS = {
     "render_fwd.hip": [],
     # hardware global_atomic_add_f32 instead of a CAS loop
     "render_bwd.hip": ["-munsafe-fp-atomics"],
+    # bit-identical to oracle/knn_oracle.py: one rounding per operation
+    "knn.hip": ["-ffp-contract=off"],
     "api.hip": [],
 }
 HEADERS = ["common.h", "gaussian_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]

@@ -409,6 +409,24 @@ int grpg_pack_rgb_u8(const float* src, unsigned char* dst, size_t n, void* hip_s
   return GRPG_OK;
 }
 
+size_t grpg_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
+
+int grpg_knn_mean_dist2(int P, const float* points, float* mean_dists,
+                        grpg_alloc_fn workspace_alloc, void* workspace_user, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P < 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "negative size");
+  if (P == 0) return GRPG_OK;
+  if (!points || !mean_dists) return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (!workspace_alloc) return fail(GRPG_ERR_INVALID_ARGUMENT, "workspace allocator must not be NULL");
+  char* ws = workspace_alloc(knn_workspace_bytes(P), workspace_user);
+  if (!ws) return fail(GRPG_ERR_ALLOC, "knn workspace allocation failed");
+  if ((uintptr_t)ws & 255) return fail(GRPG_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+  launch_knn((hipStream_t)hip_stream, P, points, mean_dists, ws);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
 int grpg_debug_export(int P, int R, int width, int height, const char* geom_buffer,
                       const char* binning_buffer, const char* image_buffer, uint64_t* keys_sorted,
                       uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib, float* means2D,

@@ -233,4 +233,8 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 }
 #endif
 
+// distCUDA2 (knn.hip): mean squared distance to the 3 nearest other points.
+size_t knn_workspace_bytes(int P);
+void launch_knn(hipStream_t s, int P, const float* points, float* mean_dists, char* workspace);
+
 }  // namespace grpg

@@ -317,8 +317,27 @@ std::tuple<std::vector<float>, int> StageTiming() {
   return std::make_tuple(ms, calls);
 }
 
+// simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:14-25): [P,3] points -> [P] mean
+// squared distance to the 3 nearest other points.
+torch::Tensor distCUDA2(const torch::Tensor& points) {
+  require_device(points);
+  TORCH_CHECK(points.dim() == 2 && points.size(1) == 3, "points must be [P,3]");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(points.device());
+  const int P = points.size(0);
+  auto float_opts = points.options().dtype(torch::kFloat32);
+  torch::Tensor pts = points.to(torch::kFloat32).contiguous();
+  torch::Tensor means = torch::zeros({P}, float_opts);   // the reference returns torch::full(0)
+  torch::Tensor workspace = torch::empty({0}, points.options().dtype(torch::kByte));
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_knn_mean_dist2(P, pts.data_ptr<float>(), means.data_ptr<float>(), resize_blob,
+                                     &workspace, (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_knn_mean_dist2", rc);
+  return means;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians", &RasterizeGaussians);
+  m.def("distCUDA2", &distCUDA2);
   m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
   m.def("mark_visible", &markVisible);
   m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);

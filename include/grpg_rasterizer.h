@@ -174,6 +174,22 @@ GRPG_API int grpg_pack_rgb_u8(const float* src, unsigned char* dst, size_t n, vo
 GRPG_API int grpg_set_stage_timing(int enabled);
 GRPG_API int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls);
 
+/*
+ * distCUDA2: mean squared distance of every point to its 3 nearest OTHER points (used by the
+ * Street-Gaussians model files to initialise the Gaussian scales, lib/models/gaussian_model.py:63).
+ * Replaces  SimpleKNN::knn(int P, float3* points, float* meanDists)
+ * (submodules/simple-knn/simple_knn.h:16-19, simple_knn.cu:184-219) behind the torch op
+ * distCUDA2 (submodules/simple-knn/spatial.cu:14-25).  points: device [P,3] fp32, mean_dists:
+ * device [P] fp32 (every element written).  The reference allocates its scratch internally
+ * (thrust/cudaMalloc); here the caller's allocator provides ONE workspace of the size the
+ * library asks for (grpg_knn_workspace_bytes tells it in advance).  Fewer than 4 points leave
+ * FLT_MAX in the unused neighbour slots (result +inf), like the reference.
+ */
+GRPG_API size_t grpg_knn_workspace_bytes(int P);
+GRPG_API int grpg_knn_mean_dist2(int P, const float* points, float* mean_dists,
+                                 grpg_alloc_fn workspace_alloc, void* workspace_user,
+                                 void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,8 @@
 """Packaging of the drop-in module.  The native pieces are built in-tree by
 ``python -m gaussianrpg_amd.build`` (explicit hipcc / g++ commands for gfx950) and shipped as
 package data, so that ``pip install .`` yields the same importable names as the reference's
-submodule (``diff_gaussian_rasterization`` with its ``_C`` extension, DGR/setup.py:16-34)."""
+submodules (``diff_gaussian_rasterization`` with its ``_C`` extension, DGR/setup.py:16-34, and
+``simple_knn._C.distCUDA2``, submodules/simple-knn/setup.py)."""
 import os
 import sys
 
@@ -21,7 +22,7 @@ setup(
     description="MI355X-native (gfx950) 3D-Gaussian-splatting rasterizer, drop-in for "
                 "diff_gaussian_rasterization as used by GaussianRPG / Street-Gaussians",
     packages=find_packages(include=["gaussianrpg_amd", "gaussianrpg_amd.*",
-                                    "diff_gaussian_rasterization"]),
+                                    "diff_gaussian_rasterization", "simple_knn"]),
     package_data={"gaussianrpg_amd": ["*.so", "csrc/*"]},
     include_package_data=True,
     python_requires=">=3.8",
