@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the frame loop alternates over (independent frames; 1 = serial)")
+    ap.add_argument("--no-delivery", action="store_true",
+                    help="skip the host-delivery (rgb8 over PCIe) side measurement")
     ap.add_argument("--host-threads", type=int, default=1,
                     help="host threads issuing frames (each alternates over streams/host-threads "
                          "streams); the op releases the GIL while it waits for num_rendered")
@@ -236,6 +238,30 @@ def main():
             iso_sum, iso_calls = _C.stage_timing()
         _C.set_stage_timing(False)
 
+        # Host-delivered frames: the same loop, but every frame is packed to
+        # rgb8 on the device and lands in pinned host memory (3 B/pixel over PCIe), consumed one
+        # frame behind the producer.  Reported beside the headline figure, never as `value`.
+        delivery = None
+        if world == 1 and not args.no_delivery:
+            nd = K
+            fd = tj.FrameDelivery(H, W, depth=2 * len(streams), truncate=True)
+            torch.cuda.synchronize()
+            td0 = time.perf_counter()
+            checksum = 0
+            tickets = []
+            for s in range(nd):
+                with torch.cuda.stream(streams[s % len(streams)]):
+                    tickets.append(fd.submit(render_frame(frames_of(s))))   # pack clamps
+                if s >= len(streams):
+                    checksum += int(fd.get(tickets[s - len(streams)])[0, 0, 0])
+            for s in range(max(0, nd - len(streams)), nd):
+                checksum += int(fd.get(tickets[s])[0, 0, 0])
+            td1 = time.perf_counter()
+            delivery = {"frames_per_s": nd / (td1 - td0), "frames": nd,
+                        "bytes_per_frame": 3 * H * W,
+                        "what": "rgb8 [H,W,3] in pinned host memory (device pack + async D2H), "
+                                "consumer one frame behind"}
+
         elapsed = t1 - t0
         if world > 1:
             te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
@@ -309,6 +335,7 @@ def main():
                                "algorithmic_bytes_per_frame": b_frame},
             "stages_ms": stages,
             "stages_ms_serial": stages_iso,
+            "delivery": delivery,
         }
         if stages_iso["render"]:
             ach_i = b_render / (stages_iso["render"] * 1e-3) / 1e9

@@ -409,6 +409,20 @@ int grpg_pack_rgb_u8(const float* src, unsigned char* dst, size_t n, void* hip_s
   return GRPG_OK;
 }
 
+int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, int height, int width,
+                         int truncate, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (height < 0 || width < 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "negative size");
+  const size_t npix = (size_t)height * (size_t)width;
+  if (npix > 0 && (!src_chw || !dst_hwc)) return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (((uintptr_t)src_chw & 15) || ((uintptr_t)dst_hwc & 3))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "src must be 16-byte and dst 4-byte aligned");
+  launch_pack_hwc((hipStream_t)hip_stream, src_chw, dst_hwc, npix, truncate);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
 size_t grpg_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
 
 int grpg_knn_mean_dist2(int P, const float* points, float* mean_dists,

@@ -274,4 +274,50 @@ void launch_pack_u8(hipStream_t s, const float* src, unsigned char* dst, size_t 
                                                   src + n4 * 4, dst + n4 * 4, ntail);
 }
 
+// planar float [3,H,W] -> interleaved rgb8 [H,W,3] (a ROS sensor_msgs/Image "rgb8" payload).
+// One thread per 4 pixels: three 16-byte reads, one 12-byte write (three dwords).
+__global__ void __launch_bounds__(256)
+pack_hwc_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, const size_t npix,
+                const int truncate) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // group of 4 pixels
+  const size_t p0 = g * 4;
+  if (p0 >= npix) return;
+  const float bias = truncate ? 0.0f : 0.5f;
+  unsigned char b[12];
+  if (p0 + 4 <= npix && (npix & 3) == 0) {
+    const float4 r = *reinterpret_cast<const float4*>(src + p0);
+    const float4 gg = *reinterpret_cast<const float4*>(src + npix + p0);
+    const float4 bl = *reinterpret_cast<const float4*>(src + 2 * npix + p0);
+    const float rv[4] = {r.x, r.y, r.z, r.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w},
+                bv[4] = {bl.x, bl.y, bl.z, bl.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      b[3 * k + 0] = (unsigned char)(fminf(fmaxf(rv[k], 0.f), 1.f) * 255.0f + bias);
+      b[3 * k + 1] = (unsigned char)(fminf(fmaxf(gv[k], 0.f), 1.f) * 255.0f + bias);
+      b[3 * k + 2] = (unsigned char)(fminf(fmaxf(bv[k], 0.f), 1.f) * 255.0f + bias);
+    }
+    uint32_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      w[k] = (uint32_t)b[4 * k] | ((uint32_t)b[4 * k + 1] << 8) | ((uint32_t)b[4 * k + 2] << 16) |
+             ((uint32_t)b[4 * k + 3] << 24);
+    dst[3 * g + 0] = w[0]; dst[3 * g + 1] = w[1]; dst[3 * g + 2] = w[2];
+  } else {   // ragged pixel count: byte stores
+    unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
+    for (size_t p = p0; p < npix && p < p0 + 4; p++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        d8[3 * p + c] = (unsigned char)(fminf(fmaxf(src[c * npix + p], 0.f), 1.f) * 255.0f + bias);
+    }
+  }
+}
+
+void launch_pack_hwc(hipStream_t s, const float* src, unsigned char* dst, size_t npix,
+                     int truncate) {
+  if (npix == 0) return;
+  const size_t groups = (npix + 3) / 4;
+  pack_hwc_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, s>>>(src, (uint32_t*)dst, npix,
+                                                                 truncate);
+}
+
 }  // namespace grpg

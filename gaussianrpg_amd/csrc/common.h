@@ -205,6 +205,7 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
 void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t R,
                           uint32_t W, uint32_t H, uint32_t S);
 void launch_pack_u8(hipStream_t s, const float* src, unsigned char* dst, size_t n);
+void launch_pack_hwc(hipStream_t s, const float* src, unsigned char* dst, size_t npix, int truncate);
 
 void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
                          const RecView rec, const uint32_t* tiles, const uint32_t* tile_keys,

@@ -309,6 +309,21 @@ torch::Tensor PackU8(const torch::Tensor& color) {
   return out;
 }
 
+// float [3,H,W] -> uint8 [H,W,3] (rgb8); truncate=true reproduces the simulator's astype(uint8)
+torch::Tensor PackHWC(const torch::Tensor& color, const bool truncate) {
+  TORCH_CHECK(color.is_cuda() && color.scalar_type() == torch::kFloat32 && color.dim() == 3 &&
+                  color.size(0) == 3, "pack_hwc: float32 device tensor [3,H,W]");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(color.device());
+  torch::Tensor src = color.contiguous();
+  const int H = src.size(1), W = src.size(2);
+  torch::Tensor out = torch::empty({H, W, 3}, src.options().dtype(torch::kUInt8));
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_pack_rgb_u8_hwc(src.data_ptr<float>(), out.data_ptr<uint8_t>(), H, W,
+                                      truncate ? 1 : 0, (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_pack_rgb_u8_hwc", rc);
+  return out;
+}
+
 std::tuple<std::vector<float>, int> StageTiming() {
   std::vector<float> ms(GRPG_NUM_STAGES, 0.f);
   int calls = 0;
@@ -344,6 +359,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // additions (not in the reference module)
   m.def("debug_export", &DebugExport);
   m.def("pack_u8", &PackU8);
+  m.def("pack_hwc", &PackHWC);
   m.def("set_stage_timing", [](bool on) { grpg_set_stage_timing(on ? 1 : 0); });
   m.def("stage_timing", &StageTiming);
   m.def("abi_version", []() { return grpg_abi_version(); });

@@ -287,3 +287,28 @@ def test_misaligned_input_views(dev):
                                          scales=shifted(sc.scales), rotations=shifted(sc.rotations))
     np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
     assert_image_close("color", color.cpu().numpy(), o["color"], o["fragile"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(64, 64), (37, 53), (5, 7)])
+def test_pack_hwc_and_frame_delivery(hw):
+    """Device rgb8 packing == the simulator's host conversion (simulator.py:314), and the pinned
+    delivery ring hands out the right frames."""
+    import numpy as np
+    from gaussianrpg_amd import trajectory as tj
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 100 + W)
+    frames = [torch.rand(3, H, W, generator=g) * 1.2 - 0.1 for _ in range(5)]   # incl. out of range
+    fd = tj.FrameDelivery(H, W, depth=2)
+    tickets = []
+    for k, f in enumerate(frames):
+        tickets.append(fd.submit(f.cuda()))
+        if k >= 1:   # consume one frame behind the producer
+            got = fd.get(tickets[k - 1]).copy()
+            ref = (frames[k - 1].clamp(0, 1).numpy().transpose(1, 2, 0) * 255).astype(np.uint8)
+            np.testing.assert_array_equal(got, ref)
+    with pytest.raises(ValueError):
+        fd.get(tickets[0])          # fell out of the ring
+    rounded = tj.pack_hwc(frames[0].cuda(), truncate=False).cpu().numpy()
+    ref_r = (frames[0].clamp(0, 1).numpy().transpose(1, 2, 0) * 255 + 0.5).astype(np.uint8)
+    np.testing.assert_array_equal(rounded, ref_r)
