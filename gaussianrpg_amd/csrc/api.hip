@@ -195,9 +195,8 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   char* img = image_alloc(IL.total, image_user);
   if (!geom || !img) return fail(GRPG_ERR_ALLOC, "geometry/image buffer allocation failed");
 
-  float4* geo = (float4*)(geom + GL.geo);
-  float4* col = (float4*)(geom + GL.col);
-  const RecView rec = {geo, col};
+  float4* rec_w = (float4*)(geom + GL.rec);
+  const RecView rec = {rec_w};
   uint32_t* key_a = (uint32_t*)(geom + GL.key_a);
   uint32_t* key_b = (uint32_t*)(geom + GL.key_b);
   uint32_t* val_a = (uint32_t*)(geom + GL.val_a);
@@ -219,7 +218,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   if (P > 0) {
     tm.mark(0);
     launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                      cov3D_precomp, colors_precomp, cam, radii_int, geo, col, key_a, tiles);
+                      cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles);
     STAGE_CHECK("preprocess");
     tm.mark(1);
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key; culled keys sort last.
@@ -345,7 +344,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
         h[2].H != (uint32_t)height)
       return fail(GRPG_ERR_BAD_BUFFER, "state buffers do not match this call (P/R/W/H or magic)");
   }
-  const RecView rec = {(const float4*)(geom_buffer + GL.geo), (const float4*)(geom_buffer + GL.col)};
+  const RecView rec = {(const float4*)(geom_buffer + GL.rec)};
   const int* radii_int = radii ? radii : (const int*)(geom_buffer + GL.radii);
   const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.val_a);
   const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
@@ -456,7 +455,7 @@ int grpg_debug_export(int P, int R, int width, int height, const char* geom_buff
   const BinLayout BL = bin_layout((size_t)R);
   const ImgLayout IL = img_layout((size_t)gx * gy, (size_t)width * height);
   launch_debug_export(stream, P, (uint32_t)R, width, height, gx, gy,
-                      RecView{(const float4*)(geom_buffer + GL.geo), (const float4*)(geom_buffer + GL.col)},
+                      RecView{(const float4*)(geom_buffer + GL.rec)},
                       (const uint32_t*)(geom_buffer + GL.tiles),
                       (const uint32_t*)(binning_buffer + BL.key_a),
                       (const uint32_t*)(binning_buffer + BL.val_a),

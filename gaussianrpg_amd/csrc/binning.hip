@@ -40,8 +40,8 @@ __device__ __forceinline__ uint32_t last_leq(const uint32_t* __restrict__ a, uin
 __device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k,
                                               const RecView rec, const int gx,
                                               const int gy, uint32_t& key, uint32_t& val) {
-  const float4 r0 = rec.geo[2 * (size_t)g];       // px, py, opacity, radius
-  const float4 r1 = rec.geo[2 * (size_t)g + 1];   // conic, depth
+  const float4 r0 = rec.geo0(g);   // px, py, opacity, radius
+  const float4 r1 = rec.geo1(g);   // conic, depth
   const int radius = __float_as_int(r0.w);
   int minx, miny, maxx, maxy;
   get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
@@ -198,7 +198,7 @@ debug_keys_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
   if (i >= R) return;
   const uint32_t g = point_list[i] & ID_MASK;
   if (keys_sorted)
-    keys_sorted[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec.geo[2 * (size_t)g + 1].w);
+    keys_sorted[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec.geo1(g).w);
   if (point_list_out) point_list_out[i] = g;
 }
 

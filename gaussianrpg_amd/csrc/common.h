@@ -18,23 +18,28 @@ constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
 constexpr int SUBTILE_SHIFT = 28;
 
 // ---------------------------------------------------------------------------------------
-// Per-Gaussian projected attributes written by preprocess: 48 B in two arrays indexed by id.
-//   geo[2 id]     = { px, py, opacity, bits(radius as int32) }     32-byte aligned pair:
-//   geo[2 id + 1] = { conic.x, conic.y, conic.z, depth(view z) }   all that binning needs
-//   col[id]       = { R, G, B, bits(clamped mask: bit0 R, bit1 G, bit2 B) }
-// emit touches only the 32-byte geo pair (one sector of a random gather instead of 1.75 on
-// average for a packed 48-byte record); render and the backward gather geo + col.
+// Per-Gaussian projected attributes written by preprocess: one 64-byte, 64-byte-aligned record
+//   r[0] = { px, py, opacity, bits(radius as int32) }      first 32 bytes: all that binning needs
+//   r[1] = { conic.x, conic.y, conic.z, depth(view z) }
+//   r[2] = { R, G, B, bits(clamped mask: bit0 R, bit1 G, bit2 B) }
+//   r[3] = padding (written as zeros so that preprocess stores whole sectors)
+// so that the random per-instance gathers of emit (32 B) and of render / backward (48 B) each
+// touch exactly ONE 64-byte memory sector.  A packed 48-byte record straddles two sectors in
+// half of the cases, separate arrays always cost two (measured: +68 % FETCH_SIZE in render).
 // The reference keeps the same data in six arrays (GeometryState, rasterizer_impl.h:30-44).
 // load() returns the working view used by the kernels:
 //   a = { px, py, depth, opacity }   b = { conic.x, conic.y, conic.z, R }
 //   c = { G, B, clamp bits, radius bits }
 // ---------------------------------------------------------------------------------------
-constexpr int REC_F4 = 3;           // float4 per Gaussian over both arrays (and per LDS slot)
+constexpr int REC_F4 = 3;           // float4 per LDS slot of a staged record
+constexpr int REC_STRIDE = 4;       // float4 per Gaussian in HBM (64 bytes)
 struct RecView {
-  const float4* geo;
-  const float4* col;
+  const float4* rec;
+  __device__ __forceinline__ float4 geo0(const size_t id) const { return rec[REC_STRIDE * id]; }
+  __device__ __forceinline__ float4 geo1(const size_t id) const { return rec[REC_STRIDE * id + 1]; }
+  __device__ __forceinline__ float4 colour(const size_t id) const { return rec[REC_STRIDE * id + 2]; }
   __device__ __forceinline__ void load(const size_t id, float4& a, float4& b, float4& c) const {
-    const float4 g0 = geo[2 * id], g1 = geo[2 * id + 1], cc = col[id];
+    const float4 g0 = geo0(id), g1 = geo1(id), cc = colour(id);
     a = make_float4(g0.x, g0.y, g1.w, g0.z);
     b = make_float4(g1.x, g1.y, g1.z, cc.x);
     c = make_float4(cc.y, cc.z, cc.w, g0.w);
@@ -72,7 +77,7 @@ constexpr int EMIT_PER_BLOCK = 1024;             // instance-list slots per emit
 
 struct GeomLayout {
   size_t total;
-  size_t geo, col, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
+  size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap;
 };
 struct BinLayout {
@@ -91,8 +96,7 @@ inline GeomLayout geom_layout(size_t P) {
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   L.nchunks_sort = (uint32_t)((P + RS_CHUNK - 1) / RS_CHUNK);
   L.nblocks_scan = (uint32_t)((P + SC_CHUNK - 1) / SC_CHUNK);
-  L.geo = take(P * 32);
-  L.col = take(P * 16);
+  L.rec = take(P * REC_STRIDE * 16);
   L.key_a = take(P * 4);
   L.key_b = take(P * 4);
   L.val_a = take(P * 4);
@@ -149,7 +153,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* geo, float4* col, uint32_t* depth_key, uint32_t* tiles);
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations,
                            const float* cov3D_precomp, const CameraArgs& cam, int* radii,

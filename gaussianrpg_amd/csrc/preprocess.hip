@@ -118,7 +118,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   const float* __restrict__ proj, const float* __restrict__ campos, const int W,
                   const int H, const int gx, const int gy, const float tan_fovx,
                   const float tan_fovy, const float focal_x, const float focal_y,
-                  int* __restrict__ radii, float4* __restrict__ geo, float4* __restrict__ col,
+                  int* __restrict__ radii, float4* __restrict__ rec,
                   uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
                   const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
   // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
@@ -144,49 +144,68 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
     }
   }
   __syncthreads();
+  // The 64-byte records leave through LDS as well: every thread stages its record, then the
+  // workgroup stores the 16 KB slab with consecutive lanes on consecutive 16-byte pieces (whole
+  // sectors, fully coalesced; a lane-per-record store would touch 64 sectors per instruction).
+  // Culled Gaussians get an all-zero record (radius 0, opacity 0): nothing ever gathers it.
+  __shared__ float4 s_out[256 * REC_STRIDE];
   const int idx = base + threadIdx.x;
-  if (idx >= P) return;
-  const float mx = s_mean[3 * threadIdx.x], my = s_mean[3 * threadIdx.x + 1],
-              mz = s_mean[3 * threadIdx.x + 2];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  if (scales != nullptr) {
-    s0 = s_scale[3 * threadIdx.x]; s1 = s_scale[3 * threadIdx.x + 1]; s2 = s_scale[3 * threadIdx.x + 2];
-  }
-  Projected o;
-  const bool vis = project_and_bound(idx, mx, my, mz, s0, s1, s2, scale_modifier, rotations,
-                                     cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
-                                     focal_x, focal_y, o);
-  if (!vis) {
-    radii[idx] = 0;
-    tiles[idx] = 0;
-    depth_key[idx] = CULLED_KEY;
-    return;
-  }
-  float rgb[3];
-  uint32_t clamped = 0;
-  if (colors_precomp == nullptr) {
-    const float dx = mx - campos[0];
-    const float dy = my - campos[1];
-    const float dz = mz - campos[2];
-    if (M == 4 && vec_ok) {   // degree <= 1, every shipped config: 48 B per Gaussian as three 16-byte loads
-      const float4* sp = reinterpret_cast<const float4*>(shs + (size_t)idx * 12);
-      const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
-      const float sh12[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-      sh_to_rgb(D > 1 ? 1 : D, sh12, dx, dy, dz, rgb, clamped);
-    } else {
-      sh_to_rgb(D, shs + (size_t)idx * M * 3, dx, dy, dz, rgb, clamped);
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+  if (idx < P) {
+    const float mx = s_mean[3 * threadIdx.x], my = s_mean[3 * threadIdx.x + 1],
+                mz = s_mean[3 * threadIdx.x + 2];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (scales != nullptr) {
+      s0 = s_scale[3 * threadIdx.x]; s1 = s_scale[3 * threadIdx.x + 1]; s2 = s_scale[3 * threadIdx.x + 2];
     }
-  } else {
-    rgb[0] = colors_precomp[3 * idx];
-    rgb[1] = colors_precomp[3 * idx + 1];
-    rgb[2] = colors_precomp[3 * idx + 2];
+    Projected o;
+    const bool vis = project_and_bound(idx, mx, my, mz, s0, s1, s2, scale_modifier, rotations,
+                                       cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
+                                       focal_x, focal_y, o);
+    if (!vis) {
+      radii[idx] = 0;
+      tiles[idx] = 0;
+      depth_key[idx] = CULLED_KEY;
+    } else {
+      float rgb[3];
+      uint32_t clamped = 0;
+      if (colors_precomp == nullptr) {
+        const float dx = mx - campos[0];
+        const float dy = my - campos[1];
+        const float dz = mz - campos[2];
+        if (M == 4 && vec_ok) {   // degree <= 1, every shipped config: 48 B per Gaussian as three 16-byte loads
+          const float4* sp = reinterpret_cast<const float4*>(shs + (size_t)idx * 12);
+          const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+          const float sh12[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+          sh_to_rgb(D > 1 ? 1 : D, sh12, dx, dy, dz, rgb, clamped);
+        } else {
+          sh_to_rgb(D, shs + (size_t)idx * M * 3, dx, dy, dz, rgb, clamped);
+        }
+      } else {
+        rgb[0] = colors_precomp[3 * idx];
+        rgb[1] = colors_precomp[3 * idx + 1];
+        rgb[2] = colors_precomp[3 * idx + 2];
+      }
+      radii[idx] = o.radius;
+      tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
+      depth_key[idx] = __float_as_uint(o.depth);
+      r0 = make_float4(o.px, o.py, opacities[idx], __int_as_float(o.radius));
+      r1 = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
+      r2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
+    }
   }
-  radii[idx] = o.radius;
-  tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
-  depth_key[idx] = __float_as_uint(o.depth);
-  geo[2 * idx + 0] = make_float4(o.px, o.py, opacities[idx], __int_as_float(o.radius));
-  geo[2 * idx + 1] = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
-  col[idx] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
+  s_out[REC_STRIDE * threadIdx.x + 0] = r0;
+  s_out[REC_STRIDE * threadIdx.x + 1] = r1;
+  s_out[REC_STRIDE * threadIdx.x + 2] = r2;
+  s_out[REC_STRIDE * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int nrec4 = min(256, P - base) * REC_STRIDE;
+  float4* dst = rec + (size_t)REC_STRIDE * base;
+#pragma unroll
+  for (int k = 0; k < REC_STRIDE; k++) {
+    const int e = k * 256 + threadIdx.x;
+    if (e < nrec4) dst[e] = s_out[e];
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -229,12 +248,12 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* geo, float4* col, uint32_t* depth_key, uint32_t* tiles) {
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles) {
   if (P <= 0) return;
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
       colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
-      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, geo, col, depth_key, tiles,
+      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles,
       ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
 }
 

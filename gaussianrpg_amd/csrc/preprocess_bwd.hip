@@ -9,7 +9,7 @@
 //
 // Sigma and T are RECOMPUTED with the forward's own functions (gaussian_math.h, same
 // -ffp-contract=off arithmetic), so nothing but the 48-byte record survives from the forward;
-// the SH clamp mask comes from col[id].w.  HBM-bound streaming kernel: reads (71+12M) B and
+// the SH clamp mask comes from the record (r[2].w).  HBM-bound streaming kernel: reads (71+12M) B and
 // writes up to (64+12M) B per Gaussian.
 #include "common.h"
 
@@ -246,7 +246,7 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   const float d2z = (view[10] - view[11] * mul3) * gdep;
   gmx += d2x; gmy += d2y; gmz += d2z;
   if (shs != nullptr) {
-    const uint32_t clamped = __float_as_uint(rec.col[idx].w);
+    const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
     const float dc3[3] = {dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
     float sx, sy, sz;
     sh_backward(D, shs + (size_t)idx * M * 3, mx - campos[0], my - campos[1], mz - campos[2],
