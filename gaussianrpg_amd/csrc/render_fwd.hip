@@ -519,7 +519,10 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 }
 
 #ifndef GRPG_RENDER_MIN_WAVES
-#define GRPG_RENDER_MIN_WAVES 5   // waves per SIMD the register allocator must fit (<= 96 VGPRs)
+// waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
+// 112 KB of LDS per CU so that the other stream's sort workgroups can co-reside) measured slightly
+// ahead of 5 (96 VGPRs, 136 B of scratch per lane): 0.327 vs 0.333 ms, 1640 vs 1600 frames/s.
+#define GRPG_RENDER_MIN_WAVES 4
 #endif
 template <bool WRITE_AUX, int GPI_H, int GPI_L, bool TRACE = false>
 __global__ void __launch_bounds__(256, GRPG_RENDER_MIN_WAVES)
