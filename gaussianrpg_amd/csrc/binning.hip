@@ -145,14 +145,30 @@ emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sor
 }
 
 // identifyTileRanges, rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :313).
+// Four consecutive keys per thread (one 16-byte load + the two neighbours).
 __global__ void __launch_bounds__(256)
 tile_ranges_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
                    uint2* __restrict__ ranges) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R) return;
-  const uint32_t t = tile_keys[i];
-  if (i == 0 || tile_keys[i - 1] != t) ranges[t].x = i;
-  if (i == R - 1 || tile_keys[i + 1] != t) ranges[t].y = i + 1;
+  const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= R) return;
+  uint32_t k[6];   // k[0] = predecessor, k[1..4] = own keys, k[5] = successor
+  if (i0 + 4 <= R) {
+    const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);
+    k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < R ? tile_keys[i0 + j] : 0xFFFFFFFFu;
+  }
+  k[0] = i0 > 0 ? tile_keys[i0 - 1] : 0xFFFFFFFFu;
+  k[5] = i0 + 4 < R ? tile_keys[i0 + 4] : 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = i0 + j;
+    if (i >= R) break;
+    const uint32_t t = k[1 + j];
+    if (i == 0 || k[j] != t) ranges[t].x = i;
+    if (i == R - 1 || k[2 + j] != t) ranges[t].y = i + 1;
+  }
 }
 
 void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_gid,
@@ -167,7 +183,7 @@ void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, ui
                         uint32_t T) {
   (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
   if (R == 0) return;
-  tile_ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, tile_keys, ranges);
+  tile_ranges_kernel<<<(R + 1023) / 1024, 256, 0, s>>>(R, tile_keys, ranges);
 }
 
 // ---------------------------------- debug / parity decoder --------------------------------

@@ -88,10 +88,14 @@ radix_digit_scan_kernel(uint32_t* __restrict__ table, const uint32_t nchunks,
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// CBITS > 0: digit width known at compile time (the match-any loop unrolls into straight-line
+// code: one bit test + ballot, one sign-extended bit, two xor, two and per key bit, no branch);
+// CBITS == 0: width taken from `bits_rt`.
+template <int CBITS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                     const uint32_t n, const int shift, const int bits,
+                     const uint32_t n, const int shift, const int bits_rt,
                      const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
                      const uint32_t nchunks, const uint32_t* __restrict__ gather_src,
                      uint32_t* __restrict__ gather_dst) {
@@ -102,6 +106,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   __shared__ uint32_t s_vals[RS_CHUNK];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bits = CBITS > 0 ? CBITS : bits_rt;
   const uint32_t mask = (1u << bits) - 1u;
   const uint32_t chunk = blockIdx.x;
   const uint32_t chunk_base = chunk * RS_CHUNK;
@@ -113,6 +118,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
   uint32_t key[RS_ITEMS], val[RS_ITEMS], rnk[RS_ITEMS];
   const uint64_t lt = (1ull << lane) - 1ull;
+  // all of the wave's loads first (one memory round trip per workgroup instead of RS_ITEMS)
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; i++) {
     const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
@@ -120,13 +126,21 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const bool valid = local < chunk_n;
     key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
     val[i] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; i++) {
+    const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
+    const bool valid = local < chunk_n;
     const uint32_t d = (key[i] >> shift) & mask;
     // match-any over the wave: lanes holding the same digit
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < bits; b++) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
+    uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int b = 0; b < (CBITS > 0 ? CBITS : RS_MAX_BITS); b++) {
+      if (CBITS == 0 && b >= bits) break;
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(((d >> b) & 1u) != 0u);
+      // lanes whose bit b equals mine:  ~(bal ^ mine),  mine = all-ones if my bit is set
+      const uint32_t mine = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+      peers &= ~(bal ^ (((uint64_t)mine << 32) | mine));
     }
     const uint32_t before = (uint32_t)__popcll(peers & lt);
     const uint32_t prev = valid ? s_cnt[d * 4 + wave] : 0u;
@@ -167,16 +181,28 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   }
   __syncthreads();
 
-  for (uint32_t j = tid; j < chunk_n; j += RS_THREADS) {
-    const uint32_t k = s_keys[j];
-    const uint32_t d = (k >> shift) & mask;
-    const uint32_t g = s_gbase[d] + j;
-    keys_out[g] = k;
-    const uint32_t v = s_vals[j];
-    vals_out[g] = v;
-    // last pass of the depth sort: also emit the per-Gaussian tile count in sorted order, so the
-    // offsets scan streams a contiguous array instead of gathering tiles[gid[i]]
-    if (gather_src) gather_dst[g] = gather_src[v];
+  // last pass of the depth sort: also emit the per-Gaussian tile count in sorted order, so the
+  // offsets scan streams a contiguous array instead of gathering tiles[gid[i]].  The gather loads
+  // are issued for all of the thread's items before the first store (one round trip, not 8).
+  uint32_t gsrc[RS_ITEMS];
+  if (gather_src) {
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+      const uint32_t j = i * RS_THREADS + tid;
+      gsrc[i] = j < chunk_n ? gather_src[s_vals[j]] : 0u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; i++) {
+    const uint32_t j = i * RS_THREADS + tid;
+    if (j < chunk_n) {
+      const uint32_t k = s_keys[j];
+      const uint32_t d = (k >> shift) & mask;
+      const uint32_t g = s_gbase[d] + j;
+      keys_out[g] = k;
+      vals_out[g] = s_vals[j];
+      if (gather_src) gather_dst[g] = gsrc[i];
+    }
   }
 }
 
@@ -400,9 +426,14 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_
     uint32_t* vout = in_b ? val_a : val_b;
     radix_hist_kernel<<<nchunks, RS_THREADS, 0, s>>>(kin, n, shift, mask, table, nchunks);
     radix_digit_scan_kernel<<<1u << bits, 256, 0, s>>>(table, nchunks, totals);
-    radix_scatter_kernel<<<nchunks, RS_THREADS, 0, s>>>(
-        kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, shift, bits, table, totals,
-        nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst);
+#define RS_SCATTER(CB)                                                                        \
+  radix_scatter_kernel<CB><<<nchunks, RS_THREADS, 0, s>>>(                                    \
+      kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, shift, bits, table, totals,  \
+      nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst)
+    if (bits == 8) RS_SCATTER(8);        // depth sort
+    else if (bits == 7) RS_SCATTER(7);   // tile partition of a 1920x1280 frame (14 bits)
+    else RS_SCATTER(0);
+#undef RS_SCATTER
     in_b = !in_b;
     shift += bits;
   }

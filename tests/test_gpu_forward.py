@@ -312,3 +312,47 @@ def test_pack_hwc_and_frame_delivery(hw):
     rounded = tj.pack_hwc(frames[0].cuda(), truncate=False).cpu().numpy()
     ref_r = (frames[0].clamp(0, 1).numpy().transpose(1, 2, 0) * 255 + 0.5).astype(np.uint8)
     np.testing.assert_array_equal(rounded, ref_r)
+
+
+@pytest.mark.gpu
+def test_streams_and_threads_give_identical_frames(dev):
+    """Frames rendered back to back on one stream, alternating over two streams, and from two
+    host threads (the op releases the GIL while it waits for num_rendered) are bit-identical:
+    all state lives in the caller's blobs."""
+    import threading
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.street_scene(60_000, seed=5).to(dev)
+    cams = [hz.trajectory_camera(k, W=640, H=384, device=dev) for k in range(6)]
+    rs = [GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(c, 1))) for c in cams]
+
+    def render(i):
+        return rs[i](means3D=sc.means3D, means2D=None, opacities=sc.opacity, shs=sc.shs,
+                     scales=sc.scales, rotations=sc.rotations)[0]
+
+    ref = [render(i).clone() for i in range(6)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    out = [None] * 6
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 2]):
+            out[i] = render(i)
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(out[i], ref[i])
+
+    out2 = [None] * 6
+
+    def worker(t):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[t]):
+            for i in range(t, 6, 2):
+                out2[i] = render(i)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for w in th:
+        w.start()
+    for w in th:
+        w.join()
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(out2[i], ref[i])
