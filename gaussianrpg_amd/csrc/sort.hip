@@ -51,10 +51,16 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t n, const int
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * RS_CHUNK;
+  uint32_t kk[RS_ITEMS];   // all loads first: one memory round trip per workgroup
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; k++) {
     const uint32_t idx = base + k * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+    kk[k] = idx < n ? keys[idx] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; k++) {
+    const uint32_t idx = base + k * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(kk[k] >> shift) & mask], 1u);
   }
   __syncthreads();
   if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nchunks + blockIdx.x] = h[threadIdx.x];
@@ -455,12 +461,14 @@ scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
                    uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t s_wave[4];
   const uint32_t base = blockIdx.x * SC_CHUNK;
-  uint32_t s = 0;
+  uint32_t v[SC_ITEMS], s = 0;   // all loads in flight together
 #pragma unroll
   for (int k = 0; k < SC_ITEMS; k++) {
     const uint32_t i = base + k * SC_THREADS + threadIdx.x;
-    if (i < n) s += tiles[i];
+    v[k] = i < n ? tiles[i] : 0u;
   }
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; k++) s += v[k];
   uint32_t tot;
   block_exclusive_scan_256(s, s_wave, &tot);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
