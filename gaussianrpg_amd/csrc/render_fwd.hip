@@ -524,7 +524,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 // ahead of 5 (96 VGPRs, 136 B of scratch per lane): 0.327 vs 0.333 ms, 1640 vs 1600 frames/s.
 #define GRPG_RENDER_MIN_WAVES 4
 #endif
-template <bool WRITE_AUX, int GPI_H, int GPI_L, bool TRACE = false>
+template <bool WRITE_AUX, int GPI_L, bool TRACE = false>
 __global__ void __launch_bounds__(256, GRPG_RENDER_MIN_WAVES)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RecView rec, const int W, const int H, const int gx,
@@ -676,8 +676,8 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
                                                             work);
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
-#define RF_LAUNCH(GH, GL)                                                                      \
-  render_forward_kernel<true, GH, GL><<<ntiles, 256, 0, s>>>(                                   \
+#define RF_LAUNCH(GL)                                                                          \
+  render_forward_kernel<true, GL><<<ntiles, 256, 0, s>>>(                                       \
       ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,      \
       out_alpha, n_contrib)
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
@@ -686,7 +686,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
     const size_t words = (size_t)ntiles * RW_WAVES * 17;
     if (hipMalloc((void**)&d_trace, words * 4) == hipSuccess) {
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
-      render_forward_kernel<true, 4, 1, true><<<ntiles, 256, 0, s>>>(
+      render_forward_kernel<true, 1, true><<<ntiles, 256, 0, s>>>(
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
           out_alpha, n_contrib, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
@@ -697,14 +697,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
       return;
     }
   }
+  // splats per inner iteration of the light (4 pixels per lane) path; the heavy path always
+  // evaluates quads.  GRPG_RENDER_VARIANT=1 selects 1 (experiment switch; 2 measured best).
   static const int variant = [] { const char* e = getenv("GRPG_RENDER_VARIANT"); return e ? atoi(e) : 0; }();
-  switch (variant) {   // experiment switch: splats per inner iteration (heavy, light)
-    case 1: RF_LAUNCH(8, 1); break;
-    case 2: RF_LAUNCH(8, 2); break;
-    case 3: RF_LAUNCH(4, 1); break;
-    case 4: RF_LAUNCH(6, 1); break;
-    default: RF_LAUNCH(4, 2); break;   // measured best: 0.517 ms vs 0.575 ms for (4,1)
-  }
+  if (variant == 1) RF_LAUNCH(1);
+  else RF_LAUNCH(2);
 #undef RF_LAUNCH
 }
 

@@ -454,7 +454,7 @@ int radix_sort_num_passes(int begin_bit, int end_bit) {
 // ------------------------------------------------------------------------------------------
 // Exclusive scan of the per-Gaussian instance counts in depth-sorted order (written contiguously
 // by the last depth-sort pass) -> offsets[i]; replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:280).
-// Three launches: per-workgroup reduce, single-workgroup spine scan, per-workgroup downsweep.
+// Two launches: per-workgroup reduce, per-workgroup downsweep (which recomputes the spine).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SC_THREADS)
 scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
@@ -474,28 +474,34 @@ scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(256)
-scan_spine_kernel(uint32_t* __restrict__ block_sums, const uint32_t nblocks,
-                  uint32_t* __restrict__ total_out) {
-  __shared__ uint32_t s_wave[4];
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < nblocks; base += 256) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nblocks ? block_sums[i] : 0;
-    uint32_t tot;
-    const uint32_t ex = block_exclusive_scan_256(v, s_wave, &tot);
-    if (i < nblocks) block_sums[i] = ex + carry;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) *total_out = carry;
-}
-
 __global__ void __launch_bounds__(SC_THREADS)
 scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
-                 const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets,
-                 const uint32_t* __restrict__ total, uint32_t* __restrict__ emit_win,
-                 const uint32_t emit_win_cap) {
+                 const uint32_t* __restrict__ block_sums, const uint32_t nblocks,
+                 uint32_t* __restrict__ offsets, uint32_t* __restrict__ total_out,
+                 uint32_t* __restrict__ emit_win, const uint32_t emit_win_cap) {
   __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_spine[8];
+  // the spine (prefix of the workgroup sums before this workgroup, and the grand total) is
+  // recomputed by every workgroup from the <= a few thousand L2-resident sums: cheaper than a
+  // third launch with a single workgroup
+  {
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t i = threadIdx.x; i < nblocks; i += SC_THREADS) {
+      const uint32_t v = block_sums[i];
+      tot += v;
+      pre += i < blockIdx.x ? v : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      pre += (uint32_t)__shfl_xor((int)pre, d, 64);
+      tot += (uint32_t)__shfl_xor((int)tot, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_spine[(threadIdx.x >> 6) * 2] = pre; s_spine[(threadIdx.x >> 6) * 2 + 1] = tot; }
+    __syncthreads();
+  }
+  const uint32_t block_prefix = s_spine[0] + s_spine[2] + s_spine[4] + s_spine[6];
+  const uint32_t total = s_spine[1] + s_spine[3] + s_spine[5] + s_spine[7];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
   // thread t owns SC_ITEMS consecutive elements so that the scan order is the array order
   const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
   uint32_t v[SC_ITEMS], s = 0;
@@ -506,7 +512,7 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
     s += v[k];
   }
   uint32_t tot;
-  uint32_t ex = block_exclusive_scan_256(s, s_wave, &tot) + block_sums[blockIdx.x];
+  uint32_t ex = block_exclusive_scan_256(s, s_wave, &tot) + block_prefix;
 #pragma unroll
   for (int k = 0; k < SC_ITEMS; k++) {
     const uint32_t i = base + k;
@@ -517,7 +523,7 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
       const uint32_t end = ex + v[k];
       for (uint32_t b = (ex + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK; b * EMIT_PER_BLOCK < end; b++)
         if (b <= emit_win_cap) emit_win[b] = i;
-      if (end == *total) {
+      if (end == total) {
         const uint32_t nb = (end + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK;
         if (nb <= emit_win_cap && nb * EMIT_PER_BLOCK >= end) emit_win[nb] = i;
       }
@@ -531,9 +537,8 @@ void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted
                          uint32_t* total_out, uint32_t* emit_win, uint32_t emit_win_cap) {
   if (n == 0) return;
   scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums);
-  scan_spine_kernel<<<1, 256, 0, s>>>(block_sums, nblocks, total_out);
-  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums, offsets, total_out,
-                                                   emit_win, emit_win_cap);
+  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums, nblocks, offsets,
+                                                   total_out, emit_win, emit_win_cap);
 }
 
 }  // namespace grpg
