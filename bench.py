@@ -203,7 +203,7 @@ def main():
         if nthreads == 1:
             for s in range(K):
                 with torch.cuda.stream(streams[s % len(streams)]):
-                    local[s] = tj.pack_u8(render_frame(frames_of(s)))
+                    tj.pack_u8(render_frame(frames_of(s)), out=local[s])
         else:
             import threading
 
@@ -212,7 +212,7 @@ def main():
                 mine = streams[t::nthreads]
                 for n, s in enumerate(range(t, K, nthreads)):
                     with torch.cuda.stream(mine[n % len(mine)]):
-                        local[s] = tj.pack_u8(render_frame(frames_of(s)))
+                        tj.pack_u8(render_frame(frames_of(s)), out=local[s])
 
             workers = [threading.Thread(target=issue, args=(t,)) for t in range(nthreads)]
             for w in workers:

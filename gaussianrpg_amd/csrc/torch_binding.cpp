@@ -297,11 +297,20 @@ DebugExport(const torch::Tensor& geomBuffer, const torch::Tensor& binningBuffer,
   return std::make_tuple(keys, plist, ranges, ncontrib, means2D, depths, conic, rgb, tiles);
 }
 
-torch::Tensor PackU8(const torch::Tensor& color) {
+// out: optional preallocated uint8 tensor of the same shape (e.g. a slot of the gather buffer), so
+// that the packed frame is written in place instead of being copied there afterwards
+torch::Tensor PackU8(const torch::Tensor& color, const c10::optional<torch::Tensor>& out_opt) {
   TORCH_CHECK(color.is_cuda() && color.scalar_type() == torch::kFloat32, "pack_u8: float32 device tensor");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(color.device());
   torch::Tensor src = color.contiguous();
-  torch::Tensor out = torch::empty(src.sizes(), src.options().dtype(torch::kUInt8));
+  torch::Tensor out;
+  if (out_opt.has_value() && out_opt->defined()) {
+    out = *out_opt;
+    TORCH_CHECK(out.is_cuda() && out.scalar_type() == torch::kUInt8 && out.is_contiguous() &&
+                    out.numel() == src.numel(), "pack_u8: out must be a contiguous uint8 device tensor of the same size");
+  } else {
+    out = torch::empty(src.sizes(), src.options().dtype(torch::kUInt8));
+  }
   hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   const int rc = grpg_pack_rgb_u8(src.data_ptr<float>(), out.data_ptr<uint8_t>(), (size_t)src.numel(),
                                   (void*)stream);
@@ -358,7 +367,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);
   // additions (not in the reference module)
   m.def("debug_export", &DebugExport);
-  m.def("pack_u8", &PackU8);
+  m.def("pack_u8", &PackU8, pybind11::arg("color"), pybind11::arg("out") = pybind11::none());
   m.def("pack_hwc", &PackHWC);
   m.def("set_stage_timing", [](bool on) { grpg_set_stage_timing(on ? 1 : 0); });
   m.def("stage_timing", &StageTiming);

@@ -53,13 +53,18 @@ def shard_frames(num_frames: int, rank: int, world: int) -> List[int]:
     return list(range(rank, num_frames, world))
 
 
-def pack_u8(color: torch.Tensor) -> torch.Tensor:
+def pack_u8(color: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """float [3,H,W] -> uint8 [3,H,W] (eval-mode clamp of render_kernel,
-    street_gaussian_renderer.py:236-237, then the x255 of the image writers)."""
+    street_gaussian_renderer.py:236-237, then the x255 of the image writers).  ``out``: optional
+    preallocated contiguous uint8 tensor (a slot of the gather buffer) written in place."""
     if color.is_cuda:
         from .rasterizer import _C          # one fused HIP launch instead of four torch kernels
-        return _C.pack_u8(color)
-    return (color.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8)   # host-side logic tests only
+        return _C.pack_u8(color, out)
+    res = (color.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8)   # host-side logic tests only
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def pack_hwc(color: torch.Tensor, truncate: bool = True) -> torch.Tensor:
@@ -135,18 +140,19 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
             streams = [torch.cuda.Stream() for _ in range(num_streams)]
         if streams:
             with torch.cuda.stream(streams[j % len(streams)]):
-                img = pack_u8(render_frame(i))
+                color = render_frame(i)
                 if local is None:
-                    local = torch.zeros((per_rank,) + tuple(img.shape), dtype=torch.uint8,
-                                        device=img.device)
+                    local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
+                                        device=color.device)
                     for st in streams:          # the buffer must exist before any stream writes it
                         st.wait_stream(torch.cuda.current_stream())
-                local[j] = img
+                pack_u8(color, out=local[j])    # packed straight into its slot of the gather buffer
             continue
-        img = pack_u8(render_frame(i))
+        color = render_frame(i)
         if local is None:
-            local = torch.zeros((per_rank,) + tuple(img.shape), dtype=torch.uint8, device=img.device)
-        local[j] = img
+            local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
+                                device=color.device)
+        pack_u8(color, out=local[j])
     if streams:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
