@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the frame loop alternates over (independent frames; 1 = serial)")
+    ap.add_argument("--gather-batch", type=int, default=25,
+                    help="N > 1: frames per asynchronous gather to rank 0 (0 = one gather at the end)")
     ap.add_argument("--no-delivery", action="store_true",
                     help="skip the host-delivery (rgb8 over PCIe) side measurement")
     ap.add_argument("--host-threads", type=int, default=1,
@@ -200,10 +202,22 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
         nthreads = max(1, min(args.host_threads, len(streams)))
         t0 = time.perf_counter()
+        works = []
+        GB = max(1, args.gather_batch)
         if nthreads == 1:
             for s in range(K):
                 with torch.cuda.stream(streams[s % len(streams)]):
                     tj.pack_u8(render_frame(frames_of(s)), out=local[s])
+                # RCCL only for the image gather, issued per batch of frames so that it travels over
+                # xGMI while the next batch renders; only the last batch's transfer is exposed
+                if world > 1 and args.gather_batch > 0 and ((s + 1) % GB == 0 or s == K - 1):
+                    b0 = (s // GB) * GB
+                    for st_ in streams:
+                        torch.cuda.current_stream().wait_stream(st_)
+                    src = local[b0:s + 1] if backend == "nccl" else local[b0:s + 1].cpu()
+                    works.append(dist.gather(
+                        src, gather_list=[g[b0:s + 1] for g in gather_bufs] if rank == 0 else None,
+                        dst=0, async_op=True))
         else:
             import threading
 
@@ -222,7 +236,11 @@ def main():
         for st_ in streams:
             torch.cuda.current_stream().wait_stream(st_)
         if world > 1:
-            dist.gather(local if backend == "nccl" else local.cpu(), gather_list=gather_bufs, dst=0)
+            if works:
+                for w_ in works:
+                    w_.wait()
+            else:   # one gather at the end (--gather-batch 0, or the multi-threaded issue loop)
+                dist.gather(local if backend == "nccl" else local.cpu(), gather_list=gather_bufs, dst=0)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -327,6 +345,7 @@ def main():
                        "P": P, "V_avg": V_avg, "R_avg": R_avg, "T": T_tiles, "width": W,
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
                        "streams_per_gpu": max(1, args.streams),
+                       "gather_batch_frames": args.gather_batch if world > 1 else None,
                        "host_threads_per_gpu": max(1, min(args.host_threads, max(1, args.streams))),
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
             "roofline": roof,

@@ -121,50 +121,74 @@ class FrameDelivery:
 
 
 def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int, rank: int,
-                   world: int, *, gather: bool = True, group=None,
-                   num_streams: int = 2) -> Optional[torch.Tensor]:
+                   world: int, *, gather: bool = True, group=None, num_streams: int = 2,
+                   gather_batch: Optional[int] = None) -> Optional[torch.Tensor]:
     """Render this rank's frames with ``render_frame(i) -> float [3,H,W]`` and gather all frames
     on rank 0 as uint8 [num_frames,3,H,W] (None on other ranks / when gather=False).
 
-    Exactly one collective (``dist.gather`` of a fixed-size uint8 block per rank) at the end.
-    On a GPU the frame loop alternates over ``num_streams`` HIP streams: frames are independent, so
-    the VALU-bound render of frame k overlaps the HBM-bound binning of frame k+1 and the op's one
-    host round trip per frame (num_rendered) no longer idles the device (+20 % frames/s measured).
+    The only collective is ``dist.gather`` of fixed-size uint8 blocks to rank 0: one at the end, or
+    -- ``gather_batch=B`` -- one asynchronous gather per B frame slots, issued as soon as the batch
+    is rendered so that it travels over xGMI while the next batch renders (only the last batch's
+    transfer is exposed).  On a GPU the frame loop alternates over ``num_streams`` HIP streams:
+    frames are independent, so the VALU-bound render of frame k overlaps the HBM-bound binning of
+    frame k+1 and the op's one host round trip per frame (num_rendered) no longer idles the device.
     """
     mine = shard_frames(num_frames, rank, world)
     per_rank = (num_frames + world - 1) // world
+    if not mine:   # more ranks than frames
+        raise ValueError("rank %d owns no frame (num_frames=%d < world=%d)" % (rank, num_frames, world))
+    batched = bool(gather and world > 1 and gather_batch and gather_batch > 0)
     local = None
+    bufs = None
+    works = []
     streams = None
-    for j, i in enumerate(mine):
-        if streams is None and torch.cuda.is_available() and num_streams > 1:
-            streams = [torch.cuda.Stream() for _ in range(num_streams)]
-        if streams:
-            with torch.cuda.stream(streams[j % len(streams)]):
+    on_gpu = False
+    for j in range(per_rank):
+        if j < len(mine):
+            i = mine[j]
+            if streams is None and torch.cuda.is_available() and num_streams > 1:
+                streams = [torch.cuda.Stream() for _ in range(num_streams)]
+            if streams:
+                with torch.cuda.stream(streams[j % len(streams)]):
+                    color = render_frame(i)
+                    if local is None:
+                        on_gpu = color.is_cuda
+                        local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
+                                            device=color.device)
+                        for st in streams:      # the buffer must exist before any stream writes it
+                            st.wait_stream(torch.cuda.current_stream())
+                    pack_u8(color, out=local[j])   # packed straight into its gather-buffer slot
+            else:
                 color = render_frame(i)
                 if local is None:
                     local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
                                         device=color.device)
-                    for st in streams:          # the buffer must exist before any stream writes it
-                        st.wait_stream(torch.cuda.current_stream())
-                pack_u8(color, out=local[j])    # packed straight into its slot of the gather buffer
-            continue
-        color = render_frame(i)
-        if local is None:
-            local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
-                                device=color.device)
-        pack_u8(color, out=local[j])
+                pack_u8(color, out=local[j])
+        if batched and ((j + 1) % gather_batch == 0 or j == per_rank - 1):
+            import torch.distributed as dist
+            b0 = (j // gather_batch) * gather_batch
+            if streams and on_gpu:   # the collective must see the frames of this batch
+                for st in streams:
+                    torch.cuda.current_stream().wait_stream(st)
+            if rank == 0 and bufs is None:
+                bufs = [torch.empty_like(local) for _ in range(world)]
+            works.append(dist.gather(local[b0:j + 1],
+                                     gather_list=[b[b0:j + 1] for b in bufs] if rank == 0 else None,
+                                     dst=0, group=group, async_op=True))
     if streams:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
-    if local is None:   # more ranks than frames
-        raise ValueError("rank %d owns no frame (num_frames=%d < world=%d)" % (rank, num_frames, world))
     if not gather:
         return None
     if world == 1:
         return local[:num_frames]
     import torch.distributed as dist
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-    dist.gather(local, gather_list=bufs, dst=0, group=group)
+    if batched:
+        for w in works:
+            w.wait()
+    else:
+        bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        dist.gather(local, gather_list=bufs, dst=0, group=group)
     if rank != 0:
         return None
     out = torch.empty((num_frames,) + tuple(local.shape[1:]), dtype=torch.uint8, device=local.device)

@@ -42,12 +42,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, gather_batch=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        frames = tj.render_sharded(_oracle_frame_renderer(), NFRAMES, rank, world)
+        frames = tj.render_sharded(_oracle_frame_renderer(), NFRAMES, rank, world,
+                                   gather_batch=gather_batch)
         if rank == 0:
             assert frames is not None and frames.shape == (NFRAMES, 3, H, W)
             np.save(out_path, frames.numpy())
@@ -78,11 +79,14 @@ def test_tape_matches_reference_format_and_camera():
         assert torch.allclose(a.campos, torch.tensor([0.0, 0.0, 0.5 * k]), atol=1e-6)
 
 
-def test_two_rank_gloo_gather_equals_single_process(tmp_path):
+@pytest.mark.parametrize("gather_batch", [None, 2])
+def test_two_rank_gloo_gather_equals_single_process(tmp_path, gather_batch):
+    """One final gather, and asynchronous gathers per batch of 2 frame slots (3 slots per rank:
+    a full and a ragged batch), both equal the single-process result."""
     single = tj.render_sharded(_oracle_frame_renderer(), NFRAMES, 0, 1)
     assert single.shape == (NFRAMES, 3, H, W) and single.dtype == torch.uint8
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, gather_batch), nprocs=2, join=True)
     got = np.load(out)
     np.testing.assert_array_equal(got, single.numpy())
     # frames differ from each other (the camera moves), so a wrong ordering would be caught
