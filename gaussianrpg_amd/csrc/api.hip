@@ -278,7 +278,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     tm.mark(6);
     launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
                           out_color, out_depth, out_alpha, n_contrib,
-                          (uint32_t*)(img + IL.work), heavy_tile_min());
+                          (uint32_t*)(img + IL.work), heavy_tile_min(), R);
     STAGE_CHECK("render");
     tm.mark(7);
     if (S > 0) {

@@ -53,7 +53,8 @@ constexpr int NUM_CLASSES = 4;
 
 __global__ void __launch_bounds__(256)
 classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
-                      const uint32_t heavy_min, uint32_t* __restrict__ work) {
+                      const uint32_t heavy_min, const uint32_t c0_mul, const uint32_t c1_mul,
+                      uint32_t* __restrict__ work) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63;
   int cls = -1;
@@ -61,7 +62,7 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
     const uint2 r = ranges[t];
     const uint32_t len = r.y - r.x;
     const uint64_t hm = heavy_min;
-    cls = len >= 8 * hm ? 0 : (len >= 2 * hm ? 1 : (len >= hm ? 2 : 3));
+    cls = len >= c0_mul * hm ? 0 : (len >= c1_mul * hm ? 1 : (len >= hm ? 2 : 3));
   }
   // wave-aggregated slot allocation: one atomic per (wave, class) instead of one per tile
   // (9600 same-address atomics serialise at ~11 ns each = 100 us, measured)
@@ -518,6 +519,204 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Producer / consumer wave pairs for the LONGEST tiles (class 0 when pc_mode is on).
+//
+// A horizon quarter is a serial chain (the T recurrence) that outlives the rest of the launch, and
+// a wave running alone on its SIMD issues one instruction per ~6 cycles whatever it does.  Half
+// of that chain is not the recurrence at all: scanning the list (FILL), gathering records (POP),
+// culling and compacting.  Such a tile is rendered by TWO workgroups (quarters 0-1 and 2-3), and
+// each quarter gets two waves of its workgroup: the producer runs FILL / POP / cull / compaction
+// and hands compacted batches over through two LDS buffers; the consumer only evaluates and
+// blends quads.  Hand-over protocol
+// (all in LDS, workgroup-scope acquire/release, no workgroup barrier after the start):
+//   flag[b] == 0          buffer b is free (consumer -> producer)
+//   flag[b] == cnt + 1    buffer b holds cnt compacted survivors (producer -> consumer)
+//   flag[b] == PC_DONE    end of the list
+//   stop                  the consumer saturated all its pixels: the producer may quit
+//   box[4]                bounding box of the still-live pixels (consumer -> producer).  The
+//                         producer may read a stale or half-updated box: boxes only shrink, so any
+//                         mix of old and new bounds is a superset of the current box (the cull
+//                         stays conservative, results are unchanged).
+// Same arithmetic in the same order as blend_heavy: bit-identical images.
+// Spin loops are bounded (PC_SPIN_LIMIT): a protocol error ends the wave instead of hanging.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t PC_DONE = 0xFFFFFFFFu;
+constexpr uint32_t PC_SPIN_LIMIT = 1u << 24;
+
+struct PCCtrl {
+  uint32_t flag[2];
+  uint32_t stop;
+  uint32_t pad;
+  float box[4];
+};
+
+__device__ __forceinline__ uint32_t pc_load(const uint32_t* p) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void pc_store(uint32_t* p, const uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
+                                            uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
+                                            PCCtrl* __restrict__ ctl, const int lane,
+                                            const int quarter, const uint32_t r_begin,
+                                            const uint32_t r_end,
+                                            const uint32_t* __restrict__ point_list,
+                                            const RecView rec) {
+  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
+  const uint64_t lt = lanemask_lt();
+  uint32_t in_pos = r_begin, head = 0, count = 0;
+  uint32_t win[FILL_Q];
+#pragma unroll
+  for (int q = 0; q < FILL_Q; q++) {
+    const uint32_t i = in_pos + q * WAVE + lane;
+    win[q] = i < r_end ? point_list[i] : 0u;
+  }
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+  uint32_t pos = 0, ncur = 0;
+  int cur = 0;
+  bool stopped = false;
+  for (;;) {
+    if (pc_load(&ctl->stop) != 0u) { stopped = true; break; }
+    // ---- FILL ----
+    while (count < (uint32_t)WAVE && in_pos < r_end) {
+      uint32_t v[FILL_Q];
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
+      const uint32_t nxt = in_pos + FILL_Q * WAVE;
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = nxt + q * WAVE + lane;
+        win[q] = i < r_end ? point_list[i] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = in_pos + q * WAVE + lane;
+        const bool keep = (i < r_end) && (v[q] & bit);
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
+          qid[slot] = v[q] & ID_MASK;
+          qpos[slot] = i - r_begin + 1;
+        }
+        count += (uint32_t)__popcll(m);
+      }
+      in_pos = nxt;
+    }
+    // ---- POP ----
+    const uint32_t nn = min(count, (uint32_t)WAVE);
+    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
+    uint32_t pos_n = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (QCAP - 1);
+      const uint32_t id = qid[slot];
+      pos_n = qpos[slot];
+      rec.load(id, a_n, b_n, c_n);
+    }
+    head = (head + nn) & (QCAP - 1);
+    count -= nn;
+    // ---- cull + compact the previous batch into the free buffer, publish it ----
+    if (ncur > 0) {
+      const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
+      const bool keep = ((uint32_t)lane < ncur) &&
+                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
+      const uint64_t mask = __ballot(keep);
+      const int cnt = (int)__popcll(mask);
+      if (cnt > 0) {
+        uint32_t spins = 0;
+        while (pc_load(&ctl->flag[cur]) != 0u) {   // wait until the consumer released this buffer
+          if (pc_load(&ctl->stop) != 0u || ++spins > PC_SPIN_LIMIT) { stopped = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (stopped) break;
+        float4* my = cur ? buf1 : buf0;
+        if (keep)
+          store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                          make_float4(b.w, c.x, c.y, a.z), pos);
+        if (lane < ((4 - (cnt & 3)) & 3)) {
+          const SplatQ zq = {0.f, 0.f, 0.f};
+          store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+        }
+        pc_store(&ctl->flag[cur], (uint32_t)cnt + 1u);
+        cur ^= 1;
+      }
+    }
+    a = a_n; b = b_n; c = c_n; pos = pos_n; ncur = nn;
+    if (ncur == 0 && in_pos >= r_end) break;
+  }
+  if (!stopped) {   // end-of-list marker
+    uint32_t spins = 0;
+    while (pc_load(&ctl->flag[cur]) != 0u) {
+      if (pc_load(&ctl->stop) != 0u || ++spins > PC_SPIN_LIMIT) return;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    pc_store(&ctl->flag[cur], PC_DONE);
+  }
+}
+
+__device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
+                                            const float4* __restrict__ buf1,
+                                            PCCtrl* __restrict__ ctl, const int lane,
+                                            const int x0, const int y0, const int W, const int H,
+                                            const float* __restrict__ bg,
+                                            float* __restrict__ out_color,
+                                            float* __restrict__ out_depth,
+                                            float* __restrict__ out_alpha,
+                                            uint32_t* __restrict__ n_contrib) {
+  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
+  const float pxf = (float)px;
+  WavePix<1> st;
+  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f}; st.Wt[0] = 0.f;
+  st.last[0] = 0;
+  st.done[0] = lanes(!(px < W && py < H));
+  uint64_t prev_alive = ~0ull;
+  int cur = 0;
+  if (~st.done[0] == 0ull) pc_store(&ctl->stop, 1u);   // nothing to do (quarter outside the image)
+  else for (;;) {
+    uint32_t f, spins = 0;
+    while ((f = pc_load(&ctl->flag[cur])) == 0u) {
+      if (++spins > PC_SPIN_LIMIT) { f = PC_DONE; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (f == PC_DONE) break;
+    const int cnt = (int)(f - 1u);
+    const float4* my = cur ? buf1 : buf0;
+    for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad(st, my, j0, pxf, (float)py);
+    pc_store(&ctl->flag[cur], 0u);   // hand the buffer back
+    cur ^= 1;
+    const uint64_t alive = ~st.done[0];
+    if (alive == 0ull) { pc_store(&ctl->stop, 1u); break; }
+    if (alive != prev_alive) {   // shrink the producer's cull box to the live pixels
+      prev_alive = alive;
+      const bool dn = in_mask(st.done[0]);
+      float bx0 = dn ? 3e38f : pxf, bx1 = dn ? -3e38f : pxf;
+      float by0 = dn ? 3e38f : (float)py, by1 = dn ? -3e38f : (float)py;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+        by0 = fminf(by0, __shfl_xor(by0, d, 64));
+        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+      }
+      if (lane == 0) { ctl->box[0] = bx0; ctl->box[1] = bx1; ctl->box[2] = by0; ctl->box[3] = by1; }
+    }
+  }
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const size_t HW = (size_t)H * W;
+  if (px < W && py < H) {
+    const size_t pix = (size_t)py * W + px;
+    out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
+    out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
+    out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
+    out_alpha[pix] = st.Wt[0];
+    out_depth[pix] = st.CbD[0].y;
+    n_contrib[pix] = st.last[0];
+  }
+}
+
 #ifndef GRPG_RENDER_MIN_WAVES
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
 // 112 KB of LDS per CU so that the other stream's sort workgroups can co-reside) measured slightly
@@ -532,22 +731,52 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                      uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
+                      const uint32_t pc_slots, uint32_t* __restrict__ trace = nullptr,
+                      const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
+  __shared__ PCCtrl s_ctl[2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WaveTrace tr = {0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
   const uint64_t t_start = TRACE ? wall_clock64() : 0;
   uint32_t tr_tile = 0xFFFFFFFFu, tr_len = 0;
   const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
-  const uint32_t nheavy = n0 + n1 + n2;
-  const uint32_t b = blockIdx.x;
   const uint32_t* lists = work + NUM_CLASSES;
+  // pc_slots > 0: class 0 holds the few longest tiles; each is rendered by two workgroups (half
+  // tiles) with a producer and a consumer wave per quarter.  The first pc_slots workgroups are
+  // reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
+  if (pc_slots != 0u && blockIdx.x < pc_slots) {
+    if (blockIdx.x >= 2u * n0) return;
+    const uint32_t tile = lists[blockIdx.x >> 1];
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+    const uint2 range = ranges[tile];
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    const int slot = wave & 1;                                   // quarter slot inside this workgroup
+    const int q = (int)(blockIdx.x & 1u) * 2 + slot;            // quarter of the tile
+    const int x0 = tx * TILE, y0 = ty * TILE + q * 4;
+    if (wave < 2 && lane == 0) {   // the consumer initialises its quarter's control block
+      s_ctl[slot].flag[0] = 0u; s_ctl[slot].flag[1] = 0u; s_ctl[slot].stop = 0u; s_ctl[slot].pad = 0u;
+      s_ctl[slot].box[0] = (float)x0; s_ctl[slot].box[1] = (float)(x0 + 15);
+      s_ctl[slot].box[2] = (float)y0; s_ctl[slot].box[3] = (float)(y0 + 3);
+    }
+    __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
+    if (wave < 2)
+      pc_consumer(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
+                  out_depth, out_alpha, n_contrib);
+    else
+      pc_producer(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
+                  rb, re, point_list, rec);
+    return;
+  }
+  const uint32_t nh0 = pc_slots != 0u ? 0u : n0;   // class 0 rendered above in pc mode
+  const uint32_t nheavy = nh0 + n1 + n2;
+  const uint32_t b = blockIdx.x - pc_slots;
   if (b < nheavy) {
     // heavy tile: four independent 16x4 sub-tiles, 1 pixel per lane, 4 splats per iteration
-    const uint32_t tile = b < n0 ? lists[b]
-                                 : (b < n0 + n1 ? lists[T + (b - n0)] : lists[2 * T + (b - n0 - n1)]);
+    const uint32_t tile = b < nh0 ? lists[b]
+                                  : (b < nh0 + n1 ? lists[T + (b - nh0)] : lists[2 * T + (b - nh0 - n1)]);
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
@@ -669,26 +898,33 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
-                           uint32_t heavy_min) {
+                           uint32_t heavy_min, uint32_t R) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   (void)hipMemsetAsync(work, 0, NUM_CLASSES * sizeof(uint32_t), s);
+  // Producer/consumer wave pairs for the few longest tiles (GRPG_RENDER_PC=0 turns them off):
+  // class 0 then means >= GRPG_PC_MUL x heavy_min entries (default 32 -> 8192) and classes 1, 2
+  // >= 8x / >= 1x heavy_min; without it the classes are >= 8x, >= 2x, >= 1x (LPT order only).
+  static const int pc = [] { const char* e = getenv("GRPG_RENDER_PC"); return e ? atoi(e) : 1; }();
+  static const uint32_t pc_mul = [] { const char* e = getenv("GRPG_PC_MUL"); return e ? (uint32_t)atoi(e) : 32u; }();
+  // at most R / (pc_mul * heavy_min) tiles can be that long: two workgroups each
+  const uint32_t pc_slots = pc ? 2u * (uint32_t)((size_t)R / ((size_t)pc_mul * heavy_min) + 1) : 0u;
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
-                                                            work);
+                                                            pc ? pc_mul : 8u, pc ? 8u : 2u, work);
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
 #define RF_LAUNCH(GL)                                                                          \
-  render_forward_kernel<true, GL><<<ntiles, 256, 0, s>>>(                                       \
+  render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, 0, s>>>(                            \
       ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,      \
-      out_alpha, n_contrib)
+      out_alpha, n_contrib, pc_slots)
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
   if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
     uint32_t* d_trace = nullptr;
-    const size_t words = (size_t)ntiles * RW_WAVES * 17;
+    const size_t words = (size_t)(ntiles + pc_slots) * RW_WAVES * 17;
     if (hipMalloc((void**)&d_trace, words * 4) == hipSuccess) {
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
-      render_forward_kernel<true, 1, true><<<ntiles, 256, 0, s>>>(
+      render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, 0, s>>>(
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
-          out_alpha, n_contrib, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
+          out_alpha, n_contrib, pc_slots, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
       (void)hipMemcpyAsync(h.data(), d_trace, words * 4, hipMemcpyDeviceToHost, s);
       (void)hipStreamSynchronize(s);

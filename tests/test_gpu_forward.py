@@ -86,6 +86,10 @@ CASES = {
     "smoke_overdraw": lambda: (hz.smoke_scene(1500, seed=3), hz.smoke_camera(128, 96)),
     "street_20k": lambda: (hz.street_scene(20000, seed=3), hz.trajectory_camera(3, W=480, H=320)),
     "street_200k": lambda: (hz.street_scene(200000, seed=8), hz.trajectory_camera(10, W=960, H=640)),
+    # four tiles with 10-18 k entries, pixels that keep blending past entry 15 000: the lists long
+    # enough for the producer/consumer wave pairs of render_fwd.hip (>= 8192 entries)
+    "long_lists": lambda: (hz.toy_scene(40000, seed=21, sh_degree=1, depth=6.0, spread=0.8, scale=0.015),
+                           hz.trajectory_camera(0, W=64, H=64)),
 }
 
 
@@ -356,3 +360,21 @@ def test_streams_and_threads_give_identical_frames(dev):
     torch.cuda.synchronize()
     for i in range(6):
         assert torch.equal(out2[i], ref[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"GRPG_RENDER_PC": "0"}, {"GRPG_PC_MUL": "1"},
+                                 {"GRPG_RENDER_VARIANT": "1", "GRPG_HEAVY_MIN": "64"},
+                                 {"GRPG_SORT": "onesweep"}])
+def test_alternative_code_paths(env):
+    """The experiment switches are read once per process, so the parity cases are re-run in a
+    subprocess: no producer/consumer pairs; pairs for EVERY heavy tile; light path with one splat
+    per iteration and a low heavy threshold; look-back radix passes."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "test_forward_matches_oracle or test_giant_splat"],
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
