@@ -901,6 +901,25 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   }
 }
 
+// Producer/consumer wave pairs for the few longest tiles (GRPG_RENDER_PC=0 turns them off):
+// class 0 then means >= GRPG_PC_MUL x heavy_min entries (default 32 -> 8192) and classes 1, 2
+// >= 8x / >= 1x heavy_min; without it the classes are >= 8x, >= 2x, >= 1x (LPT order only).
+bool render_pc_enabled() {
+  static const int pc = [] { const char* e = getenv("GRPG_RENDER_PC"); return e ? atoi(e) : 1; }();
+  return pc != 0;
+}
+uint32_t render_pc_mul() {
+  static const uint32_t m = [] { const char* e = getenv("GRPG_PC_MUL"); return e ? (uint32_t)atoi(e) : 32u; }();
+  return m < 1u ? 1u : m;
+}
+// workgroups reserved for half tiles of class 0: at most R / (pc_mul * heavy_min) tiles can be
+// that long, two workgroups each; 0 = producer/consumer mode off.  The forward and the backward of
+// one frame must agree (both derive it from num_rendered and the same environment).
+uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min) {
+  if (!render_pc_enabled()) return 0u;
+  return 2u * (uint32_t)((size_t)R / ((size_t)render_pc_mul() * heavy_min) + 1);
+}
+
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
@@ -909,13 +928,9 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   (void)hipMemsetAsync(work, 0, NUM_CLASSES * sizeof(uint32_t), s);
-  // Producer/consumer wave pairs for the few longest tiles (GRPG_RENDER_PC=0 turns them off):
-  // class 0 then means >= GRPG_PC_MUL x heavy_min entries (default 32 -> 8192) and classes 1, 2
-  // >= 8x / >= 1x heavy_min; without it the classes are >= 8x, >= 2x, >= 1x (LPT order only).
-  static const int pc = [] { const char* e = getenv("GRPG_RENDER_PC"); return e ? atoi(e) : 1; }();
-  static const uint32_t pc_mul = [] { const char* e = getenv("GRPG_PC_MUL"); return e ? (uint32_t)atoi(e) : 32u; }();
-  // at most R / (pc_mul * heavy_min) tiles can be that long: two workgroups each
-  const uint32_t pc_slots = pc ? 2u * (uint32_t)((size_t)R / ((size_t)pc_mul * heavy_min) + 1) : 0u;
+  const bool pc = render_pc_enabled();
+  const uint32_t pc_mul = render_pc_mul();
+  const uint32_t pc_slots = render_pc_slots(R, heavy_min);
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
                                                             pc ? pc_mul : 8u, pc ? 8u : 2u, work);
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
