@@ -14,8 +14,10 @@
 //     quadratic are shared.  HEAVY tiles (>= heavy_min entries; a street scene's horizon tiles
 //     hold up to ~35 k splats and would serialise the whole frame behind one wave): four 16x4
 //     quarter-tile waves at 1 pixel per lane, fed through an LDS ring (blend_heavy below).
-//   * A tile-classification pre-pass builds the work lists; the longest lists are dispatched
-//     first (longest-processing-time-first) from the same launch.
+//   * A tile-classification pre-pass builds the work lists; one launch dispatches them longest
+//     processing time first: the few tiles with >= 8192 entries (two workgroups each, a PRODUCER
+//     and a CONSUMER wave per quarter, see pc_producer / pc_consumer), tiles with >= 2048
+//     entries, the light tiles, the remaining heavy tiles.
 //   * emit (binning.hip) stores a 4-bit mask in the top bits of every point-list entry: which
 //     16x4 quarters of the tile the splat can reach at all (exact minimum of the conic's
 //     quadratic over the quarter's rectangle, blend_math.h).  A record is only ever loaded for an
