@@ -24,7 +24,7 @@ using namespace grpg;
 namespace {
 
 thread_local std::string g_last_error;
-thread_local bool g_timing_enabled = false;
+thread_local int g_timing_enabled = 0;   // 0 off, 1 all stages, 2 render stage only
 thread_local uint32_t* g_pinned_u32 = nullptr;
 
 int fail(int code, const std::string& msg) {
@@ -87,14 +87,16 @@ thread_local std::vector<TimingRecord*> g_free;
 struct StageTimer {
   hipStream_t s;
   TimingRecord* r = nullptr;
-  StageTimer(hipStream_t s_, bool on) : s(s_) {
-    if (!on) return;
+  int mode = 0;
+  StageTimer(hipStream_t s_, int mode_) : s(s_), mode(mode_) {
+    if (!mode) return;
     if (!g_free.empty()) { r = g_free.back(); g_free.pop_back(); }
     else { r = new TimingRecord(); for (auto& e : r->ev) (void)hipEventCreate(&e); }
     r->n = 0;
   }
   void mark(int next_stage) {
     if (!r || r->n > GRPG_NUM_STAGES) return;
+    if (mode == 2 && next_stage != 6 && next_stage != 7) return;   // render start / render end only
     (void)hipEventRecord(r->ev[r->n], s);
     r->stage_of[r->n] = next_stage;
     r->n++;
@@ -128,7 +130,7 @@ int grpg_abi_version(void) { return GRPG_ABI_VERSION; }
 const char* grpg_last_error(void) { return g_last_error.c_str(); }
 
 int grpg_set_stage_timing(int enabled) {
-  g_timing_enabled = enabled != 0;
+  g_timing_enabled = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
   for (auto* r : g_pending) g_free.push_back(r);
   g_pending.clear();
   return GRPG_OK;

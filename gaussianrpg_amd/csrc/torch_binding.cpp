@@ -369,7 +369,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("debug_export", &DebugExport);
   m.def("pack_u8", &PackU8, pybind11::arg("color"), pybind11::arg("out") = pybind11::none());
   m.def("pack_hwc", &PackHWC);
-  m.def("set_stage_timing", [](bool on) { grpg_set_stage_timing(on ? 1 : 0); });
+  m.def("set_stage_timing", [](int mode) { grpg_set_stage_timing(mode); });   // 0 off, 1 all, 2 render only
   m.def("stage_timing", &StageTiming);
   m.def("abi_version", []() { return grpg_abi_version(); });
 }

@@ -182,7 +182,8 @@ GRPG_API int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, 
  * over those calls into stage_ms_sum[GRPG_NUM_STAGES] and their count into *num_calls, then
  * forgets them.  Stages: 0 preprocess, 1 depth sort, 2 offsets scan (+ the num_rendered read-back
  * and binning-blob allocation), 3 instance emit, 4 tile sort, 5 tile ranges, 6 render,
- * 7 semantic render.
+ * 7 semantic render.  enabled == 2 records only the two events around the render stage (the
+ * cheap mode for a timed region: 2 event records per call instead of 9).
  */
 #define GRPG_NUM_STAGES 8
 GRPG_API int grpg_set_stage_timing(int enabled);
