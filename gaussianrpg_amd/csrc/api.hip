@@ -245,7 +245,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     char* bin = binning_alloc(BL.total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
     launch_write_headers(stream, geom, bin, img, (uint32_t)P, R, (uint32_t)width, (uint32_t)height,
-                         (uint32_t)S);
+                         (uint32_t)S, ranges, (uint32_t)T, (uint32_t*)(img + IL.work));
     uint32_t* bkey_a = (uint32_t*)(bin + BL.key_a);
     uint32_t* bkey_b = (uint32_t*)(bin + BL.key_b);
     uint32_t* bval_a = (uint32_t*)(bin + BL.val_a);
@@ -302,7 +302,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     char* bin = binning_alloc(bin_layout(0).total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
     launch_write_headers(stream, geom, bin, img, 0u, 0u, (uint32_t)width, (uint32_t)height,
-                         (uint32_t)S);
+                         (uint32_t)S, nullptr, 0u, nullptr);
   }
   return (int)R;
 }

@@ -190,7 +190,7 @@ void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_g
 
 void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
                         uint32_t T) {
-  (void)hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), s);
+  // ranges were zeroed by write_headers_kernel (same stream, earlier in the frame)
   if (R == 0) return;
   tile_ranges_kernel<<<(R + 1023) / 1024, 256, 0, s>>>(R, tile_keys, ranges);
 }
@@ -250,10 +250,17 @@ void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx,
 // Blob headers are written by one tiny launch instead of three pageable H2D copies (each of
 // which costs a staging copy + a ~5 us copy kernel on the stream).
 // ------------------------------------------------------------------------------------------
-__global__ void write_headers_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img,
-                                     const uint32_t P, const uint32_t R, const uint32_t W,
-                                     const uint32_t H, const uint32_t S) {
-  const uint32_t t = threadIdx.x;
+// The same launch zeroes the tile ranges (identifyTileRanges leaves empty tiles untouched,
+// rasterizer_impl.cu:313) and the render work-list counters: two memset launches less per frame.
+__global__ void __launch_bounds__(256)
+write_headers_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img,
+                     const uint32_t P, const uint32_t R, const uint32_t W,
+                     const uint32_t H, const uint32_t S, uint2* __restrict__ ranges,
+                     const uint32_t T, uint32_t* __restrict__ work) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (ranges)
+    for (uint32_t i = t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
+  if (work && t < 4) work[t] = 0u;
   if (t < 3) {
     BlobHeader* h = t == 0 ? geom : (t == 1 ? bin : img);
     if (h) {
@@ -264,9 +271,11 @@ __global__ void write_headers_kernel(BlobHeader* geom, BlobHeader* bin, BlobHead
 }
 
 void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t R,
-                          uint32_t W, uint32_t H, uint32_t S) {
-  write_headers_kernel<<<1, 64, 0, s>>>((BlobHeader*)geom, (BlobHeader*)bin, (BlobHeader*)img, P,
-                                        R, W, H, S);
+                          uint32_t W, uint32_t H, uint32_t S, uint2* ranges, uint32_t T,
+                          uint32_t* work) {
+  const uint32_t blocks = ranges ? (T + 255) / 256 : 1;
+  write_headers_kernel<<<blocks ? blocks : 1, 256, 0, s>>>(
+      (BlobHeader*)geom, (BlobHeader*)bin, (BlobHeader*)img, P, R, W, H, S, ranges, T, work);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -208,7 +208,8 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
 
 void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t R,
-                          uint32_t W, uint32_t H, uint32_t S);
+                          uint32_t W, uint32_t H, uint32_t S, uint2* ranges /* zeroed, may be NULL */,
+                          uint32_t T, uint32_t* work /* render counters zeroed, may be NULL */);
 void launch_pack_u8(hipStream_t s, const float* src, unsigned char* dst, size_t n);
 void launch_pack_hwc(hipStream_t s, const float* src, unsigned char* dst, size_t npix, int truncate);
 

@@ -929,7 +929,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            uint32_t heavy_min, uint32_t R) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
-  (void)hipMemsetAsync(work, 0, NUM_CLASSES * sizeof(uint32_t), s);
+  // work[0..3] were zeroed by write_headers_kernel (same stream, earlier in the frame)
   const bool pc = render_pc_enabled();
   const uint32_t pc_mul = render_pc_mul();
   const uint32_t pc_slots = render_pc_slots(R, heavy_min);
