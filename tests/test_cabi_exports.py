@@ -49,6 +49,13 @@ def test_abi_version_and_loud_failure_without_gpu(lib):
     rc = lib.grpg_mark_visible(0, None, None, None, None, None)
     assert rc == -2, "expected GRPG_ERR_NO_DEVICE, got %d" % rc      # no CPU fallback
     assert b"no usable HIP device" in lib.grpg_last_error()
+    # the "next rows" entry points fail the same way: distCUDA2 and the rgb8 frame pack
+    lib.grpg_knn_mean_dist2.restype = ctypes.c_int
+    assert lib.grpg_knn_mean_dist2(4, None, None, None, None, None) == -2
+    lib.grpg_pack_rgb_u8_hwc.restype = ctypes.c_int
+    assert lib.grpg_pack_rgb_u8_hwc(None, None, 4, 4, 1, None) == -2
+    lib.grpg_knn_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.grpg_knn_workspace_bytes(1000) > 1000 * 24   # pure size query, no device needed
 
 
 def test_python_api_rejects_cpu_tensors():
