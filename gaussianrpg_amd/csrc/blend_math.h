@@ -116,7 +116,7 @@ __device__ __forceinline__ bool splat_misses_rect(const float gx, const float gy
 
 // Which of the four 16x4 quarters (rows y0+4q .. y0+4q+3, columns x0 .. x0+15) of a tile can the
 // splat reach at all?  Bit q set = quarter q may hold a pixel that passes the alpha test.
-// CONSERVATIVE (never clears a bit on doubt) and tight (tools/check_masks.py: 35.6 % of the
+// CONSERVATIVE (never clears a bit on doubt) and tight (tests/mask_check.py: 35.6 % of the
 // (quarter, instance) pairs of the bench frame survive, brute force over pixel centres: 35.6 %).
 //
 // alpha >= 1/255  <=>  Q(u) = a ux^2 + 2 b ux uy + c uy^2 <= t = 2 ln(255 opacity), u = pixel - centre:

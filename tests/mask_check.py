@@ -1,10 +1,11 @@
-"""Dev tool (CPU): validate the sub-tile reach masks that emit computes (csrc/blend_math.h:
-quarter_reach_mask) against brute force over the pixel centres, on the bench frame.
+"""Test infrastructure (CPU): validate the sub-tile reach masks that emit computes
+(csrc/blend_math.h: quarter_reach_mask) against brute force over the pixel centres, on the bench
+frame.  Run directly for the full-size check, or through tests/test_mask_conservative.py.
 
 The mask must be CONSERVATIVE: a quarter that holds a pixel which passes the reference's alpha
 test (forward.cu:410-420) must never be dropped.  Emulates the kernel's fp32 arithmetic with numpy
 float32 and compares with float64 truth on a sample of tile instances; also reports how tight the
-masks are.   usage: python tools/check_masks.py [P] [samples]
+masks are.   usage: python tests/mask_check.py [P] [samples]
 """
 import os
 import sys
@@ -68,9 +69,8 @@ def truth_mask(gx, gy, a, b, c, op, X0, Y0):
     return m
 
 
-def main():
-    P = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-    nsamp = int(sys.argv[2]) if len(sys.argv) > 2 else 1_500_000
+def run(P=2_000_000, nsamp=1_500_000, verbose=True):
+    """Returns (false-miss quarter bits, truth survive fraction, mask survive fraction)."""
     sc = hz.street_scene(P, seed=2)
     cam = hz.trajectory_camera(0)
     kw = hz.settings_kwargs(cam, 1)
@@ -105,12 +105,15 @@ def main():
         ref[sl] = truth_mask(*a)
     missed = ref & ~got
     pc = lambda m: np.unpackbits(m[:, None], axis=1)[:, 4:].sum()   # noqa: E731
-    print("R=%d sampled=%d" % (R, len(gid)))
-    print("FALSE MISSES (must be 0): %d quarter bits in %d instances" % (pc(missed), int((missed != 0).sum())))
-    print("quarter survive: truth %.4f  mask %.4f   tile survive: truth %.4f mask %.4f" % (
-        pc(ref) / (4.0 * len(gid)), pc(got) / (4.0 * len(gid)), (ref != 0).mean(), (got != 0).mean()))
-    return 0 if pc(missed) == 0 else 1
+    if verbose:
+        print("R=%d sampled=%d" % (R, len(gid)))
+        print("FALSE MISSES (must be 0): %d quarter bits in %d instances" % (pc(missed), int((missed != 0).sum())))
+        print("quarter survive: truth %.4f  mask %.4f   tile survive: truth %.4f mask %.4f" % (
+            pc(ref) / (4.0 * len(gid)), pc(got) / (4.0 * len(gid)), (ref != 0).mean(), (got != 0).mean()))
+    return int(pc(missed)), pc(ref) / (4.0 * len(gid)), pc(got) / (4.0 * len(gid))
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    nsamp = int(sys.argv[2]) if len(sys.argv) > 2 else 1_500_000
+    sys.exit(0 if run(P, nsamp)[0] == 0 else 1)
