@@ -110,6 +110,13 @@ def test_backward_street(dev):
     _run(dev, sc, hz.trajectory_camera(5, W=480, H=320), torch.zeros(3), seed=5)
 
 
+def test_backward_long_lists(dev):
+    """Tiles with 10-18 k entries whose pixels keep blending past entry 15 000 (the forward renders
+    them with producer/consumer wave pairs; the backward walks the whole list back to front)."""
+    sc = hz.toy_scene(40000, seed=21, sh_degree=1, depth=6.0, spread=0.8, scale=0.015)
+    _run(dev, sc, hz.trajectory_camera(0, W=64, H=64), torch.tensor([0.1, 0.4, 0.2]), seed=11)
+
+
 def test_backward_colors_and_cov_precomp(dev):
     sc = hz.toy_scene(1200, seed=33, sh_degree=1, scale=0.1)
     _run(dev, sc, hz.trajectory_camera(0, W=96, H=64), torch.ones(3), use_colors=True, use_cov=True,
