@@ -37,7 +37,7 @@ HIP_UNITS = {
     "knn.hip": ["-ffp-contract=off"],
     "api.hip": [],
 }
-HEADERS = ["common.h", "gaussian_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]
+HEADERS = ["common.h", "gaussian_math.h", "blend_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]
 
 
 def _hipcc():

@@ -3,16 +3,23 @@
 // (cuda_rasterizer/rasterizer_impl.cu:197-343, :396-505, :141-153, :345-392).
 //
 // Forward schedule on the caller's stream:
-//   preprocess -> depth sort of P (key,id) pairs, 4 x 8-bit passes -> exclusive scan of the
-//   per-Gaussian tile counts in depth order -> [one 4-byte D2H + stream sync: num_rendered] ->
-//   binning blob alloc -> instance emit -> stable tile partition (ceil(log2 T) bits, <= 2 passes)
-//   -> tile ranges -> render (-> semantic render).
+//   frame init -> preprocess -> depth sort of the (key,id) pairs, 4 x 8-bit passes -> exclusive
+//   scan of the per-Gaussian tile counts in depth order (num_rendered lands in device memory and
+//   in a pinned host word) -> instance emit -> stable tile partition (ceil(log2 T) bits, <= 2
+//   passes) -> tile ranges -> render (-> semantic render).
+// The binning blob is carved for a capacity remembered from earlier frames, every kernel reads the
+// instance count from device memory, and the host waits for the count only AFTER the whole frame
+// is enqueued (it needs it for the return value): no bubble in the stream.  First frame of a
+// shape, exact mode, or capacity overflow: wait first / redo the tail, like the reference's one
+// blocking read (rasterizer_impl.cu:284).
 // There is no CPU fallback: without a usable HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,7 +32,90 @@ namespace {
 
 thread_local std::string g_last_error;
 thread_local int g_timing_enabled = 0;   // 0 off, 1 all stages, 2 render stage only
-thread_local uint32_t* g_pinned_u32 = nullptr;
+
+// ---- num_rendered hand-over: pinned, device-mapped host words + one event per (thread, device) ----
+struct HostWord {
+  int dev = -1;
+  uint32_t* host_ptr = nullptr;   // [0] num_rendered, [1] Gaussians in the sorted arrays
+  uint32_t* dev_ptr = nullptr;    // the same memory as the device addresses it
+  hipEvent_t ev = nullptr;
+};
+thread_local std::vector<HostWord> g_host_words;
+
+HostWord* host_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (auto& h : g_host_words)
+    if (h.dev == dev) return &h;
+  HostWord h;
+  h.dev = dev;
+  if (hipHostMalloc((void**)&h.host_ptr, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+  if (hipHostGetDevicePointer((void**)&h.dev_ptr, h.host_ptr, 0) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  h.host_ptr[0] = 0u; h.host_ptr[1] = 0u;
+  g_host_words.push_back(h);
+  return &g_host_words.back();
+}
+
+// ---- capacity hints: high-water mark of num_rendered per (device, P, W, H), process-wide ----
+struct CapKey { int dev, P, W, H; };
+struct CapHint {
+  CapKey key{-1, 0, 0, 0};
+  uint32_t high = 0;      // decaying high-water mark of num_rendered
+  uint64_t stamp = 0;     // last use (LRU replacement)
+  bool valid = false;
+};
+std::mutex g_hint_mu;
+CapHint g_hints[16];
+uint64_t g_hint_clock = 0;
+std::atomic<int> g_binning_mode{[] {
+  const char* e = getenv("GRPG_SYNC_R");
+  return (e && atoi(e) != 0) ? GRPG_BINNING_EXACT : GRPG_BINNING_SPECULATIVE;
+}()};
+
+bool same_key(const CapKey& a, const CapKey& b) {
+  return a.dev == b.dev && a.P == b.P && a.W == b.W && a.H == b.H;
+}
+// capacity carved for an expected count: +25 % head room, 64 Ki granules (stable blob sizes, so the
+// caller's caching allocator hands the same block back every frame)
+uint32_t padded_capacity(uint32_t r) {
+  const uint64_t c = ((uint64_t)r + r / 4 + 65536 + 65535) / 65536 * 65536;
+  return (uint32_t)(c > 0x7FFF0000ull ? 0x7FFF0000ull : c);
+}
+uint32_t capacity_from_hint(const CapKey& k) {
+  static const long forced = [] { const char* e = getenv("GRPG_RCAP_TEST"); return e ? atol(e) : -1L; }();
+  if (forced >= 0) return (uint32_t)forced;   // test hook: exercises the overflow / redo path
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  for (auto& h : g_hints)
+    if (h.valid && same_key(h.key, k)) { h.stamp = ++g_hint_clock; return padded_capacity(h.high); }
+  return 0u;
+}
+void update_hint(const CapKey& k, uint32_t R) {
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  CapHint* slot = nullptr;
+  for (auto& h : g_hints)
+    if (h.valid && same_key(h.key, k)) { slot = &h; break; }
+  if (!slot) {
+    slot = &g_hints[0];
+    for (auto& h : g_hints) {
+      if (!h.valid) { slot = &h; break; }
+      if (h.stamp < slot->stamp) slot = &h;
+    }
+    *slot = CapHint{};
+    slot->key = k;
+    slot->valid = true;
+  }
+  const uint32_t decayed = slot->high - slot->high / 64;   // lets the mark follow a shrinking scene
+  slot->high = R > decayed ? R : decayed;
+  slot->stamp = ++g_hint_clock;
+}
+
+// The fat depth sort (sort.hip) sweeps the whole count table in every workgroup: fine up to a few
+// hundred chunks, quadratic beyond.  GRPG_DEPTH_SORT=classic forces the three-kernel passes.
+bool depth_sort_is_fat(uint32_t nchunks_ds) {
+  static const bool classic = [] { const char* e = getenv("GRPG_DEPTH_SORT"); return e && e[0] == 'c'; }();
+  return !classic && nchunks_ds <= DS_MAX_CHUNKS;
+}
 
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -94,8 +184,11 @@ struct StageTimer {
     else { r = new TimingRecord(); for (auto& e : r->ev) (void)hipEventCreate(&e); }
     r->n = 0;
   }
+  int tail_n = -1;   // record count when the tail of the frame (emit onwards) began
+  void restart_tail() { if (r && tail_n >= 0) r->n = tail_n; }
   void mark(int next_stage) {
     if (!r || r->n > GRPG_NUM_STAGES) return;
+    if (next_stage == 3) tail_n = r->n;
     if (mode == 2 && next_stage != 6 && next_stage != 7) return;   // render start / render end only
     (void)hipEventRecord(r->ev[r->n], s);
     r->stage_of[r->n] = next_stage;
@@ -155,6 +248,18 @@ int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls) {
   return GRPG_OK;
 }
 
+int grpg_set_binning_mode(int mode) {
+  if (mode != GRPG_BINNING_SPECULATIVE && mode != GRPG_BINNING_EXACT)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "unknown binning mode");
+  g_binning_mode.store(mode);
+  return GRPG_OK;
+}
+int grpg_reset_capacity_hints(void) {
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  for (auto& h : g_hints) h = CapHint{};
+  return GRPG_OK;
+}
+
 int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
                  void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D,
                  int M, int S, const float* background, int width, int height,
@@ -209,86 +314,135 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   uint32_t* table = (uint32_t*)(geom + GL.table);
   uint32_t* totals = (uint32_t*)(geom + GL.totals);
   uint32_t* block_sums = (uint32_t*)(geom + GL.block_sums);
+  uint32_t* ds_table = (uint32_t*)(geom + GL.ds_table);
   BlobHeader* gh = (BlobHeader*)geom;
   uint2* ranges = (uint2*)(img + IL.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
-
+  uint32_t* work = (uint32_t*)(img + IL.work);
 
   StageTimer tm(stream, g_timing_enabled);
   uint32_t R = 0;
 
   if (P > 0) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HostWord* hw = host_word();
+    if (!hw) return fail(GRPG_ERR_HIP, "pinned host word / event allocation failed");
+    // Instance capacity of the binning blob.  Speculative mode (default): from the high-water mark
+    // of earlier frames of this (device, P, W, H), so the blob is carved and every kernel of the
+    // frame is enqueued BEFORE the host learns num_rendered; the kernels read the count from device
+    // memory.  Exact mode, or no history yet: wait for the count first, like the reference
+    // (rasterizer_impl.cu:284).
+    const bool fat_sort = depth_sort_is_fat(GL.nchunks_ds);
+    const CapKey ck = {dev, P, width, height};
+    uint32_t Rcap = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? capacity_from_hint(ck) : 0u;
+    const bool speculative = Rcap != 0u;
+    char* bin = nullptr;
+    BinLayout BL{};
+    if (speculative) {
+      BL = bin_layout((size_t)Rcap);
+      bin = binning_alloc(BL.total, binning_user);
+      if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
+    }
     tm.mark(0);
+    launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
+                      (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
+                      geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
     launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                      cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles);
+                      cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles,
+                      fat_sort ? ds_table : nullptr);
     STAGE_CHECK("preprocess");
     tm.mark(1);
-    // (depth_bits, id) order: stable sort of ids by the 32-bit depth key; culled keys sort last.
+    // (depth_bits, id) order: stable sort of ids by the 32-bit depth key.
     uint32_t* tiles_sorted = (uint32_t*)(geom + GL.tiles_sorted);
-    const bool in_b = radix_sort_pairs(stream, (uint32_t)P, key_a, val_a, key_b, val_b, true, 0, 32,
-                                       table, totals, GL.nchunks_sort, tiles, tiles_sorted);
-    const uint32_t* sorted_gid = in_b ? val_b : val_a;  // 4 passes -> back in "a"
+    const uint32_t* sorted_gid;
+    if (fat_sort) {   // drops the culled Gaussians: V pairs remain
+      depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
+                     tiles, tiles_sorted, block_sums);
+      sorted_gid = val_a;
+    } else {          // culled keys sort last (tile count 0); V stays P
+      const bool in_b = radix_sort_pairs(stream, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true,
+                                         0, 32, table, totals, GL.nchunks_sort, false, tiles,
+                                         tiles_sorted);
+      sorted_gid = in_b ? val_b : val_a;  // 4 passes -> back in "a"
+    }
     STAGE_CHECK("depth sort");
     tm.mark(2);
     uint32_t* emit_win = (uint32_t*)(geom + GL.emit_win);
-    launch_offsets_scan(stream, (uint32_t)P, tiles_sorted, offsets, block_sums, GL.nblocks_scan,
-                        &gh->R, emit_win, GL.emit_win_cap);
+    launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, offsets, block_sums, GL.nblocks_scan,
+                        fat_sort, &gh->R, hw->dev_ptr, emit_win, GL.emit_win_cap);
     STAGE_CHECK("offsets scan");
-    // The one host round trip per frame (reference: rasterizer_impl.cu:284).
-    if (!g_pinned_u32) HIP_TRY(hipHostMalloc((void**)&g_pinned_u32, 64, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(g_pinned_u32, &gh->R, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    R = *g_pinned_u32;
-    if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+    HIP_TRY(hipEventRecord(hw->ev, stream));   // fires when num_rendered sits in the pinned word
 
-    const BinLayout BL = bin_layout((size_t)R);
-    char* bin = binning_alloc(BL.total, binning_user);
-    if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
-    launch_write_headers(stream, geom, bin, img, (uint32_t)P, R, (uint32_t)width, (uint32_t)height,
-                         (uint32_t)S, ranges, (uint32_t)T, (uint32_t*)(img + IL.work));
-    uint32_t* bkey_a = (uint32_t*)(bin + BL.key_a);
-    uint32_t* bkey_b = (uint32_t*)(bin + BL.key_b);
-    uint32_t* bval_a = (uint32_t*)(bin + BL.val_a);
-    uint32_t* bval_b = (uint32_t*)(bin + BL.val_b);
-    uint32_t* btable = (uint32_t*)(bin + BL.table);
-    uint32_t* btotals = (uint32_t*)(bin + BL.totals);
-
-    tm.mark(3);
     const int tbits = bits_for(T);
     const int passes = radix_sort_num_passes(0, tbits);
-    // emit into whichever pair makes the LAST pass land in "a" (point_list lives in val_a)
-    const bool start_in_b = (passes & 1) != 0;
-    launch_emit(stream, (uint32_t)P, R, sorted_gid, offsets, emit_win, GL.emit_win_cap, rec, cam.gx,
-                cam.gy,
-                start_in_b ? bkey_b : bkey_a, start_in_b ? bval_b : bval_a);
-    STAGE_CHECK("emit");
-    tm.mark(4);
-    if (passes > 0) {
-      bool res_b;
-      if (start_in_b)
-        res_b = !radix_sort_pairs(stream, R, bkey_b, bval_b, bkey_a, bval_a, false, 0, tbits,
-                                  btable, btotals, BL.nchunks_sort);
-      else
-        res_b = radix_sort_pairs(stream, R, bkey_a, bval_a, bkey_b, bval_b, false, 0, tbits,
-                                 btable, btotals, BL.nchunks_sort);
-      if (res_b && R > 0) return fail(GRPG_ERR_HIP, "internal: tile sort landed in the wrong buffer");
+    const int bits0 = radix_sort_first_pass_bits(0, tbits);
+    // everything behind the offsets scan, for a binning blob of capacity `cap`
+    auto enqueue_tail = [&](char* binp, const BinLayout& L, uint32_t cap) -> int {
+      uint32_t* bkey_a = (uint32_t*)(binp + L.key_a);
+      uint32_t* bkey_b = (uint32_t*)(binp + L.key_b);
+      uint32_t* bval_a = (uint32_t*)(binp + L.val_a);
+      uint32_t* bval_b = (uint32_t*)(binp + L.val_b);
+      uint32_t* btable = (uint32_t*)(binp + L.table);
+      uint32_t* btotals = (uint32_t*)(binp + L.totals);
+      tm.mark(3);
+      // emit into whichever pair makes the LAST pass land in "a" (point_list lives in val_a)
+      const bool start_in_b = (passes & 1) != 0;
+      launch_emit(stream, &gh->V, &gh->R, cap, sorted_gid, offsets, emit_win, GL.emit_win_cap, rec,
+                  cam.gx, cam.gy, start_in_b ? bkey_b : bkey_a, start_in_b ? bval_b : bval_a,
+                  passes > 0 ? btable : nullptr, (1u << bits0) - 1u, L.nchunks_sort);
+      STAGE_CHECK("emit");
+      tm.mark(4);
+      if (passes > 0 && cap > 0) {
+        bool res_b;
+        if (start_in_b)
+          res_b = !radix_sort_pairs(stream, cap, &gh->R, bkey_b, bval_b, bkey_a, bval_a, false, 0, tbits,
+                                    btable, btotals, L.nchunks_sort, true);
+        else
+          res_b = radix_sort_pairs(stream, cap, &gh->R, bkey_a, bval_a, bkey_b, bval_b, false, 0, tbits,
+                                   btable, btotals, L.nchunks_sort, true);
+        if (res_b) return fail(GRPG_ERR_HIP, "internal: tile sort landed in the wrong buffer");
+      }
+      STAGE_CHECK("tile sort");
+      tm.mark(5);
+      launch_tile_ranges(stream, &gh->R, cap, bkey_a, ranges, T);
+      STAGE_CHECK("tile ranges");
+      tm.mark(6);
+      launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
+                            out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap);
+      STAGE_CHECK("render");
+      tm.mark(7);
+      if (S > 0) {
+        launch_render_semantic(stream, ranges, bval_a, rec, semantics, S, width, height, cam.gx,
+                               cam.gy, out_semantic);
+        STAGE_CHECK("semantic render");
+      }
+      tm.mark(-1);
+      return GRPG_OK;
+    };
+
+    if (speculative) {
+      if (int rc = enqueue_tail(bin, BL, Rcap)) return rc;
     }
-    STAGE_CHECK("tile sort");
-    tm.mark(5);
-    launch_tile_ranges(stream, R, bkey_a, ranges, T);
-    STAGE_CHECK("tile ranges");
-    tm.mark(6);
-    launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
-                          out_color, out_depth, out_alpha, n_contrib,
-                          (uint32_t*)(img + IL.work), heavy_tile_min(), R);
-    STAGE_CHECK("render");
-    tm.mark(7);
-    if (S > 0) {
-      launch_render_semantic(stream, ranges, bval_a, rec, semantics, S, width, height, cam.gx,
-                             cam.gy, out_semantic);
-      STAGE_CHECK("semantic render");
+    // The one host wait of the frame.  In speculative mode the device is already busy with the
+    // rest of the frame (and the caller can enqueue the next one as soon as we return).
+    HIP_TRY(hipEventSynchronize(hw->ev));
+    R = hw->host_ptr[0];
+    if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+    if (!speculative || R > Rcap) {
+      // exact mode / first frame / capacity overflow (the speculative tail clamped its work to the
+      // old capacity and its results are discarded): carve the blob for the true count, redo the tail
+      const bool redo = speculative;
+      Rcap = speculative || g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? padded_capacity(R) : R;
+      BL = bin_layout((size_t)Rcap);
+      bin = binning_alloc(BL.total, binning_user);
+      if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
+      launch_bin_header(stream, bin, (uint32_t)P, Rcap, (uint32_t)width, (uint32_t)height, (uint32_t)S,
+                        redo ? ranges : nullptr, T, redo ? work : nullptr);
+      if (redo) tm.restart_tail();
+      if (int rc = enqueue_tail(bin, BL, Rcap)) return rc;
     }
-    tm.mark(-1);
+    update_hint(ck, R);
     tm.finish();
   } else {
     // P == 0: the reference launches nothing and its pre-zeroed planes stay zero
@@ -297,12 +451,11 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipMemsetAsync(out_depth, 0, N * 4, stream));
     HIP_TRY(hipMemsetAsync(out_alpha, 0, N * 4, stream));
     if (S > 0 && out_semantic) HIP_TRY(hipMemsetAsync(out_semantic, 0, (size_t)S * N * 4, stream));
-    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)T * 8, stream));
     HIP_TRY(hipMemsetAsync(n_contrib, 0, N * 4, stream));
     char* bin = binning_alloc(bin_layout(0).total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
-    launch_write_headers(stream, geom, bin, img, 0u, 0u, (uint32_t)width, (uint32_t)height,
-                         (uint32_t)S, nullptr, 0u, nullptr);
+    launch_frame_init(stream, geom, bin, img, 0u, 0u, 0u, (uint32_t)width, (uint32_t)height,
+                      (uint32_t)S, ranges, T, work, geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
   }
   return (int)R;
 }
@@ -329,11 +482,13 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
   if (S > 0 && (!semantics || !dL_dpix_semantic || !dL_dsemantic))
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL semantic pointer with S>0");
+  if (S > GRPG_MAX_SEMANTIC_BACKWARD)   // the blend backward carries the channels in registers
+    return fail(GRPG_ERR_INVALID_ARGUMENT,
+                "backward supports at most 32 semantic channels (the reference: 20, config.h:16)");
   hipStream_t stream = (hipStream_t)hip_stream;
   const CameraArgs cam = make_camera(viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy);
   const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
   const GeomLayout GL = geom_layout((size_t)P);
-  const BinLayout BL = bin_layout((size_t)R);
   const ImgLayout IL = img_layout(T, (size_t)width * height);
   if (debug) {  // validate the blobs (costs a sync; only in debug mode, like the reference's checks)
     BlobHeader h[3];
@@ -342,13 +497,14 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
     HIP_TRY(hipMemcpyAsync(&h[2], image_buffer, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (h[0].magic != GEOM_MAGIC || h[1].magic != BIN_MAGIC || h[2].magic != IMG_MAGIC ||
-        h[0].P != (uint32_t)P || h[1].R != (uint32_t)R || h[2].W != (uint32_t)width ||
-        h[2].H != (uint32_t)height)
+        h[0].P != (uint32_t)P || h[0].R != (uint32_t)R || h[1].Rcap < (uint32_t)R ||
+        h[2].W != (uint32_t)width || h[2].H != (uint32_t)height)
       return fail(GRPG_ERR_BAD_BUFFER, "state buffers do not match this call (P/R/W/H or magic)");
   }
   const RecView rec = {(const float4*)(geom_buffer + GL.rec)};
   const int* radii_int = radii ? radii : (const int*)(geom_buffer + GL.radii);
-  const uint32_t* point_list = (const uint32_t*)(binning_buffer + BL.val_a);
+  // the point list is the first array of the binning blob whatever capacity it was carved for
+  const uint32_t* point_list = (const uint32_t*)(binning_buffer + bin_layout(0).val_a);
   const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
   const uint32_t* n_contrib = (const uint32_t*)(image_buffer + IL.n_contrib);
 
@@ -454,7 +610,13 @@ int grpg_debug_export(int P, int R, int width, int height, const char* geom_buff
   hipStream_t stream = (hipStream_t)hip_stream;
   const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
   const GeomLayout GL = geom_layout((size_t)P);
-  const BinLayout BL = bin_layout((size_t)R);
+  // the binning blob was carved for a capacity >= R: read it from the blob's header
+  BlobHeader bh;
+  HIP_TRY(hipMemcpyAsync(&bh, binning_buffer, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (bh.magic != BIN_MAGIC || bh.Rcap < (uint32_t)R)
+    return fail(GRPG_ERR_BAD_BUFFER, "binning buffer does not match this call");
+  const BinLayout BL = bin_layout((size_t)bh.Rcap);
   const ImgLayout IL = img_layout((size_t)gx * gy, (size_t)width * height);
   launch_debug_export(stream, P, (uint32_t)R, width, height, gx, gy,
                       RecView{(const float4*)(geom_buffer + GL.rec)},

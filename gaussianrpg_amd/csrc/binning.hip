@@ -13,17 +13,23 @@
 
 namespace grpg {
 
-// One thread per OUTPUT instance (not per Gaussian): a workgroup owns 1024 consecutive slots of the
-// instance list and maps every slot back to its (depth-sorted) Gaussian.  Two binary searches per
-// workgroup bound the index window [lo, hi] of Gaussians that can own those slots; every window
-// Gaussian then marks the slot where its run starts in an LDS array, and an inclusive max-scan over
-// the 1024 slots (4 consecutive slots per thread, wave DPP scan, 4-wave spine) yields the owner of
-// every slot -- about 10 instructions per slot instead of an 11-step binary search each.
+// One thread per OUTPUT instance (not per Gaussian): a workgroup owns 2048 consecutive slots of the
+// instance list and maps every slot back to its (depth-sorted) Gaussian.  The offsets scan left the
+// index window [lo, hi] of Gaussians that can own those slots; every window Gaussian marks the slot
+// where its run starts in an LDS array, and an inclusive max-scan over the 2048 slots (4 consecutive
+// slots per thread, wave scan, 8-wave spine) yields the owner of every slot -- about 10
+// instructions per slot instead of an 11-step binary search each.
 // Work per thread is independent of the footprint distribution -- in the reference one thread loops
 // over every tile of its Gaussian (rasterizer_impl.cu:98-108), thousands of serial iterations for a
 // near-camera splat, and after the depth sort the largest footprints sit next to each other -- and
 // each thread stores its 4 keys / 4 values with one 16-byte store.
+// A workgroup's 2048 slots are exactly one chunk of the tile partition's radix passes (sort.hip),
+// so it also leaves that chunk's pass-0 digit histogram behind: one launch and one read of the
+// 4 R key bytes less.
+// The instance count R lives in device memory (the host learns it asynchronously, api.hip); the
+// grid is sized for the blob's capacity and surplus workgroups exit.
 constexpr int EMIT_WIN = EMIT_PER_BLOCK + 64;   // window offsets staged in LDS (else global search)
+constexpr int EMIT_WAVES = EMIT_THREADS / WAVE;
 
 __device__ __forceinline__ uint32_t last_leq(const uint32_t* __restrict__ a, uint32_t lo,
                                              uint32_t hi, const uint32_t v) {
@@ -59,37 +65,44 @@ __device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k
   val = g | (bits << SUBTILE_SHIFT);
 }
 
-__global__ void __launch_bounds__(256)
-emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sorted_gid,
+__global__ void __launch_bounds__(EMIT_THREADS)
+emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_dev,
+            const uint32_t R_cap, const uint32_t* __restrict__ sorted_gid,
             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ emit_win,
             const uint32_t emit_win_cap, const RecView rec, const int gx, const int gy,
-            uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
+            uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
+            uint32_t* __restrict__ hist_table /* [digit][nchunks], may be NULL */,
+            const uint32_t hist_mask, const uint32_t nchunks) {
   __shared__ uint32_t s_win[2];
   __shared__ uint32_t s_off[EMIT_WIN];
   __shared__ uint32_t s_own[EMIT_PER_BLOCK];
-  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_wave[EMIT_WAVES];
+  __shared__ uint32_t s_hist[RS_MAX_RADIX];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t R = min(*R_dev, R_cap);
   const uint32_t o0 = blockIdx.x * EMIT_PER_BLOCK;
+  if (o0 >= R) return;   // whole workgroup
   const uint32_t o1 = min(R, o0 + EMIT_PER_BLOCK);
+  const uint32_t nG = *V_dev;   // Gaussians in the depth-sorted arrays
   // window bounds: owner of the block's first slot, and (an upper bound of) the owner of its last
   // slot = owner of the next block's first slot / of the list's last slot -- both left behind by
   // the offsets scan (sort.hip:scan_down_kernel); binary search only beyond the table's capacity
   if (tid < 2) {
     const uint32_t b = blockIdx.x + tid;
     s_win[tid] = b <= emit_win_cap ? emit_win[b]
-                                   : last_leq(offsets, 0, P - 1, tid == 0 ? o0 : o1 - 1);
+                                   : last_leq(offsets, 0, nG - 1, tid == 0 ? o0 : o1 - 1);
   }
 #pragma unroll
-  for (int r = 0; r < EMIT_PER_BLOCK / 256; r++) s_own[r * 256 + tid] = 0u;
+  for (int r = 0; r < EMIT_PER_BLOCK / EMIT_THREADS; r++) s_own[r * EMIT_THREADS + tid] = 0u;
+  if (tid < RS_MAX_RADIX) s_hist[tid] = 0u;
   __syncthreads();
   const uint32_t lo = s_win[0], hi = s_win[1];
-  // the window normally holds <= 1025 Gaussians (every visible Gaussian owns >= 1 slot; culled
-  // ones sort to the very end)
+  // the window normally holds <= 2049 Gaussians (every visible Gaussian owns >= 1 slot)
   const uint32_t nwin = hi - lo + 1;
   if (nwin <= (uint32_t)EMIT_WIN) {
     // a Gaussian with zero instances shares its offset with its successor, so the LAST index with
     // offsets[i] <= s owns slot s: mark run starts with the largest window index, then max-scan
-    for (uint32_t j = tid; j < nwin; j += 256) {
+    for (uint32_t j = tid; j < nwin; j += EMIT_THREADS) {
       const uint32_t o = offsets[lo + j];
       s_off[j] = o;
       if (j > 0 && o < o1) atomicMax(&s_own[o - o0], j);   // j > 0  =>  o > o0
@@ -111,7 +124,7 @@ emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sor
     __syncthreads();
     uint32_t before = lane > 0 ? excl_w : 0u;   // max over the preceding threads of this wave ...
 #pragma unroll
-    for (int w2 = 0; w2 < 3; w2++)
+    for (int w2 = 0; w2 < EMIT_WAVES - 1; w2++)
       if ((uint32_t)w2 < wave) before = max(before, s_wave[w2]);   // ... and of the preceding waves
     uint32_t key[4], val[4];
     const uint32_t s0 = o0 + 4 * tid;
@@ -131,9 +144,12 @@ emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sor
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       key[r] = 0u; val[r] = 0u;
-      if (s0 + r < o1) emit_instance(gid4[r], k4[r], q0[r], q1[r], gx, gy, key[r], val[r]);
+      if (s0 + r < o1) {
+        emit_instance(gid4[r], k4[r], q0[r], q1[r], gx, gy, key[r], val[r]);
+        if (hist_table) atomicAdd(&s_hist[key[r] & hist_mask], 1u);
+      }
     }
-    if (s0 + 3 < o1) {   // o0 is a multiple of 1024 and the arrays are 256-byte aligned
+    if (s0 + 3 < o1) {   // o0 is a multiple of 2048 and the arrays are 256-byte aligned
       reinterpret_cast<uint4*>(tile_keys)[s0 >> 2] = make_uint4(key[0], key[1], key[2], key[3]);
       reinterpret_cast<uint4*>(vals)[s0 >> 2] = make_uint4(val[0], val[1], val[2], val[3]);
     } else {
@@ -142,22 +158,28 @@ emit_kernel(const uint32_t P, const uint32_t R, const uint32_t* __restrict__ sor
         if (s0 + r < o1) { tile_keys[s0 + r] = key[r]; vals[s0 + r] = val[r]; }
     }
   } else {   // oversized window (runs of zero-instance Gaussians): per-slot search in global memory
-    for (uint32_t s = o0 + tid; s < o1; s += 256) {
+    for (uint32_t s = o0 + tid; s < o1; s += EMIT_THREADS) {
       const uint32_t i = last_leq(offsets, lo, hi, s);
       const uint32_t g = sorted_gid[i];
       uint32_t key, val;
       emit_instance(g, s - offsets[i], rec.geo0(g), rec.geo1(g), gx, gy, key, val);
       tile_keys[s] = key;
       vals[s] = val;
+      if (hist_table) atomicAdd(&s_hist[key & hist_mask], 1u);
     }
+  }
+  if (hist_table) {   // pass-0 digit histogram of this chunk of the tile partition
+    __syncthreads();
+    if (tid <= hist_mask) hist_table[(size_t)tid * nchunks + blockIdx.x] = s_hist[tid];
   }
 }
 
 // identifyTileRanges, rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :313).
 // Four consecutive keys per thread (one 16-byte load + the two neighbours).
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
-                   uint2* __restrict__ ranges) {
+tile_ranges_kernel(const uint32_t* __restrict__ R_dev, const uint32_t R_cap,
+                   const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
+  const uint32_t R = min(*R_dev, R_cap);
   const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= R) return;
   uint32_t k[6];   // k[0] = predecessor, k[1..4] = own keys, k[5] = successor
@@ -180,19 +202,21 @@ tile_ranges_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
   }
 }
 
-void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_gid,
-                 const uint32_t* offsets, const uint32_t* emit_win, uint32_t emit_win_cap,
-                 const RecView rec, int gx, int gy, uint32_t* tile_keys, uint32_t* vals) {
-  if (P == 0 || R == 0) return;
-  emit_kernel<<<(R + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK, 256, 0, s>>>(
-      P, R, sorted_gid, offsets, emit_win, emit_win_cap, rec, gx, gy, tile_keys, vals);
+void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, uint32_t R_cap,
+                 const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
+                 uint32_t emit_win_cap, const RecView rec, int gx, int gy, uint32_t* tile_keys,
+                 uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks) {
+  if (R_cap == 0) return;
+  emit_kernel<<<(R_cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK, EMIT_THREADS, 0, s>>>(
+      V_dev, R_dev, R_cap, sorted_gid, offsets, emit_win, emit_win_cap, rec, gx, gy, tile_keys, vals,
+      hist_table, hist_mask, nchunks);
 }
 
-void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
-                        uint32_t T) {
-  // ranges were zeroed by write_headers_kernel (same stream, earlier in the frame)
-  if (R == 0) return;
-  tile_ranges_kernel<<<(R + 1023) / 1024, 256, 0, s>>>(R, tile_keys, ranges);
+void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
+                        const uint32_t* tile_keys, uint2* ranges, uint32_t T) {
+  // ranges were zeroed by frame_init_kernel (same stream, earlier in the frame)
+  if (R_cap == 0) return;
+  tile_ranges_kernel<<<(R_cap + 1023) / 1024, 256, 0, s>>>(R_dev, R_cap, tile_keys, ranges);
 }
 
 // ---------------------------------- debug / parity decoder --------------------------------
@@ -247,35 +271,66 @@ void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx,
 }
 
 // ------------------------------------------------------------------------------------------
-// Blob headers are written by one tiny launch instead of three pageable H2D copies (each of
-// which costs a staging copy + a ~5 us copy kernel on the stream).
+// One launch at the head of every frame: blob headers (instead of three pageable H2D copies), the
+// tile ranges (identifyTileRanges leaves empty tiles untouched, rasterizer_impl.cu:313), the render
+// work-list counters, and the words of the geometry blob that this frame accumulates into with
+// atomics (depth-sort count tables, scan block sums).  `bin` may be NULL when the binning blob
+// does not exist yet; write_bin_header_kernel then follows once it does.
 // ------------------------------------------------------------------------------------------
-// The same launch zeroes the tile ranges (identifyTileRanges leaves empty tiles untouched,
-// rasterizer_impl.cu:313) and the render work-list counters: two memset launches less per frame.
 __global__ void __launch_bounds__(256)
-write_headers_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img,
-                     const uint32_t P, const uint32_t R, const uint32_t W,
-                     const uint32_t H, const uint32_t S, uint2* __restrict__ ranges,
-                     const uint32_t T, uint32_t* __restrict__ work) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint32_t P,
+                  const uint32_t V_init, const uint32_t Rcap, const uint32_t W, const uint32_t H,
+                  const uint32_t S, uint2* __restrict__ ranges, const uint32_t T,
+                  uint32_t* __restrict__ work, uint4* __restrict__ zero16, const size_t nzero16) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = t; i < nzero16; i += stride) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
   if (ranges)
-    for (uint32_t i = t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
+    for (size_t i = t; i < T; i += stride) ranges[i] = make_uint2(0u, 0u);
   if (work && t < 4) work[t] = 0u;
   if (t < 3) {
     BlobHeader* h = t == 0 ? geom : (t == 1 ? bin : img);
     if (h) {
       h->magic = t == 0 ? GEOM_MAGIC : (t == 1 ? BIN_MAGIC : IMG_MAGIC);
-      h->P = P; h->R = R; h->W = W; h->H = H; h->S = S;
+      h->P = P; h->R = 0u; h->W = W; h->H = H; h->S = S; h->V = V_init; h->Rcap = Rcap;
     }
   }
 }
 
-void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t R,
-                          uint32_t W, uint32_t H, uint32_t S, uint2* ranges, uint32_t T,
-                          uint32_t* work) {
+void launch_frame_init(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t V_init,
+                       uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S, uint2* ranges, uint32_t T,
+                       uint32_t* work, char* zero_begin, size_t zero_bytes) {
+  const size_t nzero16 = zero_bytes / 16;   // the region is 256-byte aligned at both ends
+  size_t items = nzero16 > (size_t)T ? nzero16 : (size_t)T;
+  uint32_t blocks = (uint32_t)((items + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  frame_init_kernel<<<blocks, 256, 0, s>>>((BlobHeader*)geom, (BlobHeader*)bin, (BlobHeader*)img, P,
+                                            V_init, Rcap, W, H, S, ranges, T, work,
+                                            (uint4*)zero_begin, nzero16);
+}
+
+// Binning-blob header alone (the blob was sized after num_rendered became known), or a re-run of
+// the tail of the frame after a capacity overflow: ranges / work counters are cleared again.
+__global__ void __launch_bounds__(256)
+bin_header_kernel(BlobHeader* bin, const uint32_t P, const uint32_t Rcap, const uint32_t W,
+                  const uint32_t H, const uint32_t S, uint2* __restrict__ ranges, const uint32_t T,
+                  uint32_t* __restrict__ work) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (ranges)
+    for (uint32_t i = t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
+  if (work && t < 4) work[t] = 0u;
+  if (t == 0 && bin) {
+    bin->magic = BIN_MAGIC; bin->P = P; bin->R = 0u; bin->W = W; bin->H = H; bin->S = S;
+    bin->V = 0u; bin->Rcap = Rcap;
+  }
+}
+
+void launch_bin_header(hipStream_t s, char* bin, uint32_t P, uint32_t Rcap, uint32_t W, uint32_t H,
+                       uint32_t S, uint2* ranges, uint32_t T, uint32_t* work) {
   const uint32_t blocks = ranges ? (T + 255) / 256 : 1;
-  write_headers_kernel<<<blocks ? blocks : 1, 256, 0, s>>>(
-      (BlobHeader*)geom, (BlobHeader*)bin, (BlobHeader*)img, P, R, W, H, S, ranges, T, work);
+  bin_header_kernel<<<blocks ? blocks : 1, 256, 0, s>>>((BlobHeader*)bin, P, Rcap, W, H, S, ranges,
+                                                        T, work);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -55,10 +55,12 @@ constexpr uint32_t IMG_MAGIC = 0x47504932u;
 struct BlobHeader {      // first 256 bytes of every blob
   uint32_t magic;
   uint32_t P;
-  uint32_t R;            // num_rendered (device-written in the geometry blob)
+  uint32_t R;            // num_rendered (device-written in the geometry blob by the offsets scan)
   uint32_t W, H;
   uint32_t S;
-  uint32_t reserved[58];
+  uint32_t V;            // visible Gaussians (device-written in the geometry blob by the depth sort)
+  uint32_t Rcap;         // instance capacity the binning blob was carved for (binning blob)
+  uint32_t reserved[56];
 };
 static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 
@@ -73,12 +75,29 @@ constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
 constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS = 8;
 constexpr int SC_CHUNK = SC_THREADS * SC_ITEMS;  // 2048 per workgroup
-constexpr int EMIT_PER_BLOCK = 1024;             // instance-list slots per emit workgroup
+constexpr int EMIT_THREADS = 512;
+constexpr int EMIT_PER_BLOCK = 2048;             // instance-list slots per emit workgroup == RS_CHUNK:
+                                                 // emit leaves the tile sort's pass-0 histogram behind
+static_assert(EMIT_PER_BLOCK == RS_CHUNK, "emit block must equal one radix chunk");
+
+// "fat" depth sort (sort.hip): 1024-thread workgroups own 8192 keys; every workgroup derives its
+// digit bases straight from the [chunk][digit] count table, so a pass is ONE launch (+ one small
+// histogram launch for the next pass) instead of histogram / digit scan / scatter.
+constexpr int DS_THREADS = 1024;
+constexpr int DS_ITEMS = 8;
+constexpr int DS_CHUNK = DS_THREADS * DS_ITEMS;   // 8192 keys per workgroup
+constexpr int DS_WAVES = DS_THREADS / WAVE;       // 16
+constexpr int DS_RADIX = 256;
+constexpr int DS_PASSES = 4;
+constexpr uint32_t DS_MAX_CHUNKS = 512;           // beyond (P > 4 M) the table sweep per workgroup grows
+                                                  // quadratically: classic three-kernel passes instead
 
 struct GeomLayout {
   size_t total;
   size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
-  uint32_t nchunks_sort, nblocks_scan, emit_win_cap;
+  size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
+  size_t zero_begin, zero_end;   // region frame_init clears: ds_table + block_sums
+  uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
 struct BinLayout {
   size_t total;
@@ -107,9 +126,13 @@ inline GeomLayout geom_layout(size_t P) {
   L.radii = take(P * 4);
   L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);   // u32 table or u64 status words
   L.totals = take(4 * RS_MAX_RADIX * 4);
+  L.nchunks_ds = (uint32_t)((P + DS_CHUNK - 1) / DS_CHUNK);
+  L.zero_begin = o;
   L.block_sums = take(((size_t)L.nblocks_scan + 1) * 4);
-  // owner (depth-sorted Gaussian index) of the first slot of every 1024-slot emit block, written by
-  // the offsets scan; blocks beyond the cap (R > 128 P, pathological) fall back to a binary search
+  L.ds_table = take((size_t)DS_PASSES * (L.nchunks_ds ? L.nchunks_ds : 1) * DS_RADIX * 4);
+  L.zero_end = o;
+  // owner (depth-sorted Gaussian index) of the first slot of every 2048-slot emit block, written by
+  // the offsets scan; blocks beyond the cap (R > 256 P, pathological) fall back to a binary search
   L.emit_win_cap = (uint32_t)(P / 8 + 1024);
   L.emit_win = take(((size_t)L.emit_win_cap + 2) * 4);
   L.total = o;
@@ -153,7 +176,8 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* rec, uint32_t* depth_key, uint32_t* tiles);
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles,
+                       uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations,
                            const float* cov3D_precomp, const CameraArgs& cam, int* radii,
@@ -164,22 +188,34 @@ void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float
 // Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), in
 // passes of <= 8 bits.  (key_a,val_a) holds the input (val_a ignored when vals_iota: value i = i),
 // (key_b,val_b) is scratch.  Returns true if the result is in the "b" pair, false if in "a".
-bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                      uint32_t* val_b, bool vals_iota, int begin_bit, int end_bit, uint32_t* table,
-                      uint32_t* totals, uint32_t nchunks, const uint32_t* gather_src = nullptr,
+// n sizes the grids (upper bound); n_dev, if not NULL, is the device-side element count.
+// have_hist0: table[digit][chunk] of the first pass was already filled by the caller.
+bool radix_sort_pairs(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t* key_a,
+                      uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, bool vals_iota,
+                      int begin_bit, int end_bit, uint32_t* table, uint32_t* totals,
+                      uint32_t nchunks, bool have_hist0, const uint32_t* gather_src = nullptr,
                       uint32_t* gather_dst = nullptr);
 int radix_sort_num_passes(int begin_bit, int end_bit);
+int radix_sort_first_pass_bits(int begin_bit, int end_bit);
 
-// offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total (device) = sum.
-void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted,
-                         uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
-                         uint32_t* total_out, uint32_t* emit_win, uint32_t emit_win_cap);
+// Fat depth sort (sort.hip): result in (key_a, val_a), V visible pairs; see depth_sort_fat.
+void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
+                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
+                    const uint32_t* tiles, uint32_t* tiles_sorted, uint32_t* block_sums);
 
-void launch_emit(hipStream_t s, uint32_t P, uint32_t R, const uint32_t* sorted_gid,
-                 const uint32_t* offsets, const uint32_t* emit_win, uint32_t emit_win_cap,
-                 const RecView rec, int gx, int gy, uint32_t* tile_keys, uint32_t* vals);
-void launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint2* ranges,
-                        uint32_t T);
+// offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total_out (device) = sum, also stored
+// to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.
+void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
+                         const uint32_t* tiles_sorted, uint32_t* offsets, uint32_t* block_sums,
+                         uint32_t nblocks, bool have_block_sums, uint32_t* total_out,
+                         uint32_t* total_host, uint32_t* emit_win, uint32_t emit_win_cap);
+
+void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, uint32_t R_cap,
+                 const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
+                 uint32_t emit_win_cap, const RecView rec, int gx, int gy, uint32_t* tile_keys,
+                 uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks);
+void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
+                        const uint32_t* tile_keys, uint2* ranges, uint32_t T);
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
@@ -207,9 +243,14 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 float* dL_dmean3D, const float* dL_dcolor, const float* dL_ddepth,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
 
-void launch_write_headers(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t R,
-                          uint32_t W, uint32_t H, uint32_t S, uint2* ranges /* zeroed, may be NULL */,
-                          uint32_t T, uint32_t* work /* render counters zeroed, may be NULL */);
+void launch_frame_init(hipStream_t s, char* geom, char* bin /* may be NULL */, char* img, uint32_t P,
+                       uint32_t V_init, uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S,
+                       uint2* ranges /* zeroed, may be NULL */, uint32_t T,
+                       uint32_t* work /* render counters zeroed, may be NULL */, char* zero_begin,
+                       size_t zero_bytes);
+void launch_bin_header(hipStream_t s, char* bin, uint32_t P, uint32_t Rcap, uint32_t W, uint32_t H,
+                       uint32_t S, uint2* ranges /* zeroed, may be NULL */, uint32_t T,
+                       uint32_t* work /* zeroed, may be NULL */);
 void launch_pack_u8(hipStream_t s, const float* src, unsigned char* dst, size_t n);
 void launch_pack_hwc(hipStream_t s, const float* src, unsigned char* dst, size_t npix, int truncate);
 

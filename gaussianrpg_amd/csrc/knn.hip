@@ -292,8 +292,8 @@ void launch_knn(hipStream_t s, const int P, const float* points, float* mean_dis
   const int gb = (int)(gb_all < 2048 ? gb_all : 2048);
   knn_bounds_kernel<<<gb, 256, 0, s>>>(P, points, bounds);
   knn_morton_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, points, bounds, key_a);
-  const bool in_b = radix_sort_pairs(s, (uint32_t)P, key_a, val_a, key_b, val_b, true, 0, 30, table,
-                                     totals, (uint32_t)nchunks);
+  const bool in_b = radix_sort_pairs(s, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true, 0, 30,
+                                     table, totals, (uint32_t)nchunks, false);
   const uint32_t* order = in_b ? val_b : val_a;
   knn_gather_boxes_kernel<<<nboxes, 256, 0, s>>>(P, points, order, spts, boxes);
   knn_search_kernel<<<(P + KNN_TILE - 1) / KNN_TILE, KNN_TILE, 0, s>>>(P, spts, boxes, nboxes,

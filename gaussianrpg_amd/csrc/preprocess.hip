@@ -120,6 +120,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   const float tan_fovy, const float focal_x, const float focal_y,
                   int* __restrict__ radii, float4* __restrict__ rec,
                   uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
+                  uint32_t* __restrict__ ds_table0 /* [chunk][256] pass-0 counts of the fat depth sort, or NULL */,
                   const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
   // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
   // loads.  Stage the workgroup's 256 x 12 B = 3 KB per array through LDS with 16-byte loads
@@ -149,8 +150,14 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   // sectors, fully coalesced; a lane-per-record store would touch 64 sectors per instruction).
   // Culled Gaussians get an all-zero record (radius 0, opacity 0): nothing ever gathers it.
   __shared__ float4 s_out[256 * REC_STRIDE];
+  // Pass-0 digit histogram of the depth sort (sort.hip, fat passes): the low byte of the depth
+  // key of every VISIBLE Gaussian, aggregated per workgroup in LDS; the 256 Gaussians of a
+  // workgroup lie in one 8192-key chunk, so it costs one global atomic per non-empty digit.
+  __shared__ uint32_t s_dh[DS_RADIX];
+  s_dh[threadIdx.x] = 0u;
   const int idx = base + threadIdx.x;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+  uint32_t my_key = CULLED_KEY;
   if (idx < P) {
     const float mx = s_mean[3 * threadIdx.x], my = s_mean[3 * threadIdx.x + 1],
                 mz = s_mean[3 * threadIdx.x + 2];
@@ -189,6 +196,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
       radii[idx] = o.radius;
       tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
       depth_key[idx] = __float_as_uint(o.depth);
+      my_key = __float_as_uint(o.depth);
       r0 = make_float4(o.px, o.py, opacities[idx], __int_as_float(o.radius));
       r1 = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
       r2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
@@ -198,13 +206,20 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   s_out[REC_STRIDE * threadIdx.x + 1] = r1;
   s_out[REC_STRIDE * threadIdx.x + 2] = r2;
   s_out[REC_STRIDE * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
+  __syncthreads();   // also orders the zeroing of s_dh before the atomics below
+  if (ds_table0 != nullptr && my_key != CULLED_KEY) atomicAdd(&s_dh[my_key & (DS_RADIX - 1)], 1u);
   const int nrec4 = min(256, P - base) * REC_STRIDE;
   float4* dst = rec + (size_t)REC_STRIDE * base;
 #pragma unroll
   for (int k = 0; k < REC_STRIDE; k++) {
     const int e = k * 256 + threadIdx.x;
     if (e < nrec4) dst[e] = s_out[e];
+  }
+  if (ds_table0 != nullptr) {
+    __syncthreads();
+    const uint32_t cnt = s_dh[threadIdx.x];
+    if (cnt != 0u)
+      atomicAdd(&ds_table0[(size_t)(blockIdx.x / (DS_CHUNK / 256)) * DS_RADIX + threadIdx.x], cnt);
   }
 }
 
@@ -248,12 +263,12 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* rec, uint32_t* depth_key, uint32_t* tiles) {
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles, uint32_t* ds_table0) {
   if (P <= 0) return;
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
       colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
-      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles,
+      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, ds_table0,
       ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
 }
 

@@ -212,6 +212,9 @@ __device__ __forceinline__ void backward_rect(
       }
       in_hi = nxt;
     }
+    // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
+    // reordering the LDS accesses across this point (costs no instruction)
+    __builtin_amdgcn_wave_barrier();
     // ---- POP: next batch of up to 64 entries (deepest first), start its record gather ----
     const uint32_t nn = min(rcount, (uint32_t)WAVE);
     float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;

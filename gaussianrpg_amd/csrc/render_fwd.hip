@@ -460,6 +460,9 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
       if (TRACE) tr->batches++;
     }
 
+    // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
+    // reordering the LDS accesses across this point (costs no instruction)
+    __builtin_amdgcn_wave_barrier();
     // ---- POP: next batch of up to 64 survivors, start its record gather ----
     const uint32_t nn = min(count, (uint32_t)WAVE);
     float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
@@ -608,6 +611,9 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
       }
       in_pos = nxt;
     }
+    // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
+    // reordering the LDS accesses across this point (costs no instruction)
+    __builtin_amdgcn_wave_barrier();
     // ---- POP ----
     const uint32_t nn = min(count, (uint32_t)WAVE);
     float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;

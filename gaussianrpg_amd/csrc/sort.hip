@@ -6,13 +6,22 @@
 // HBM traffic by (1) sorting the P Gaussians once by their 32-bit depth key and (2) stably
 // partitioning the R instances by their <=16-bit tile id -- both use this sort.
 //
-// Per pass (<= 8 bits):
-//   radix_hist    : one workgroup per 4096-key chunk, LDS histogram  -> table[digit][chunk]
-//   radix_digit_scan : one workgroup per digit, exclusive scan across chunks (in place) + totals
-//   radix_scatter : wave64 match-any ranking (ballot per key bit, popcount prefix), per-wave
-//                   digit counters in LDS, LDS reorder of the chunk, then coalesced run writes.
-// Stability: a chunk is split wave-major (wave w owns keys [1024w, 1024w+1024)), each wave walks
-// its keys in 16 rounds of 64 consecutive keys, ranks are (digit, wave, round, lane)-ordered.
+// Two pass shapes:
+//  * classic (tile partition of the R instances; depth sort of very large P), per pass of <= 8 bits:
+//      radix_hist       : one workgroup per 2048-key chunk, LDS histogram -> table[digit][chunk]
+//                         (pass 0 of the tile partition gets it from emit_kernel instead)
+//      radix_digit_scan : one workgroup per digit, exclusive scan across chunks (in place) + totals
+//      radix_scatter    : wave64 match-any ranking (ballot per key bit, popcount prefix), per-wave
+//                         digit counters in LDS, LDS reorder of the chunk, coalesced run writes.
+//  * fat (depth sort of the P Gaussians, P <= 4 M): 1024-thread workgroups own 8192 keys, the count
+//    table is [chunk][digit] and so small (245 rows at P = 2 M) that every workgroup sweeps it
+//    itself for its digit bases: a pass is ONE scatter launch plus one small histogram launch for
+//    the next pass (pass 0's table comes from preprocess_kernel) -- 7 launches instead of 12, and
+//    pass 0 drops the culled Gaussians, so passes 1-3 move V instead of P pairs.
+// Element counts that only the device knows (V visible Gaussians, R instances) are read from
+// device memory; grids are sized by the host-side upper bound and surplus workgroups exit.
+// Stability: a chunk is split wave-major, each wave walks its keys in rounds of 64 consecutive
+// keys, ranks are (digit, wave, round, lane)-ordered.
 #include <cstdlib>
 
 #include "common.h"
@@ -45,12 +54,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 __global__ void __launch_bounds__(RS_THREADS)
-radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t n, const int shift,
+radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t n_cap,
+                  const uint32_t* __restrict__ n_dev, const int shift,
                   const uint32_t mask, uint32_t* __restrict__ table, const uint32_t nchunks) {
   __shared__ uint32_t h[RS_MAX_RADIX];
+  const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  const uint32_t base = blockIdx.x * RS_CHUNK;
+  if (base >= n) return;   // the digit scan never reads columns beyond ceil(n / RS_CHUNK)
   h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * RS_CHUNK;
   uint32_t kk[RS_ITEMS];   // all loads first: one memory round trip per workgroup
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; k++) {
@@ -68,10 +80,13 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t n, const int
 
 // One workgroup per digit: in-place exclusive scan of table[digit][0..nchunks) and totals[digit].
 __global__ void __launch_bounds__(256)
-radix_digit_scan_kernel(uint32_t* __restrict__ table, const uint32_t nchunks,
+radix_digit_scan_kernel(uint32_t* __restrict__ table, const uint32_t nchunks_cap,
+                        const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
                         uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_wave[4];
-  uint32_t* row = table + (size_t)blockIdx.x * nchunks;
+  const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  const uint32_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK;   // <= nchunks_cap (the row stride)
+  uint32_t* row = table + (size_t)blockIdx.x * nchunks_cap;
   uint32_t carry = 0;
   for (uint32_t base = 0; base < nchunks; base += 1024) {
     uint32_t v[4], s = 0;
@@ -101,10 +116,13 @@ template <int CBITS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                     const uint32_t n, const int shift, const int bits_rt,
+                     const uint32_t n_cap, const uint32_t* __restrict__ n_dev, const int shift,
+                     const int bits_rt,
                      const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
                      const uint32_t nchunks, const uint32_t* __restrict__ gather_src,
                      uint32_t* __restrict__ gather_dst) {
+  const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  if (blockIdx.x * RS_CHUNK >= n) return;
   __shared__ uint32_t s_cnt[RS_MAX_RADIX * 4];  // [digit][wave]
   __shared__ uint32_t s_gbase[RS_MAX_RADIX];    // global position of local slot 0 of each digit
   __shared__ uint32_t s_wave[4];
@@ -213,172 +231,245 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// Single-pass-per-digit variant ("onesweep"): the per-chunk histogram pass and the table scan are
-// replaced by a decoupled look-back between workgroups, so a pass reads the keys ONCE.
-//   radix_global_hist : one launch per sort, digit histograms of ALL passes (LDS atomics, one
-//                       global atomic per non-empty (workgroup, pass, digit)).
-//   radix_onesweep    : per pass.  A workgroup ranks its chunk exactly like radix_scatter, then
-//                       thread d publishes the chunk's count of digit d and walks back over the
-//                       predecessors' status words until it meets an inclusive prefix.
-// Inter-workgroup protocol (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed):
-// a status word is ONE naturally aligned 8-byte granule {count:32 | tag:30 | state:2} written with
-// a single relaxed agent-scope atomic store (sc1, write-through) and polled with relaxed
-// agent-scope atomic loads (sc1, L1-bypassing) -- the data travels inside the granule, so no
-// fence and no separate flag are needed (cdna_hip_programming.md G16 "R2").  The tag is the pass
-// number, so words of an earlier pass read as "empty" and the array is zeroed once per sort.
-// Forward progress: a workgroup only ever waits for LOWER-numbered workgroups of the same launch,
-// and workgroups are dispatched in index order, so whoever it waits for is resident or finished.
+// Fat depth sort (P <= DS_MAX_CHUNKS * 8192): one scatter launch per 8-bit pass.
+//
+// The count table of a pass is [chunk][digit] (u32).  A workgroup sweeps ALL rows itself
+// (245 rows x 1 KB at P = 2 M, L2-resident): per digit the sum over the earlier chunks (its base
+// inside the digit's region) and the grand total (exclusive scan over digits = start of the
+// region).  Pass 0 reads the P depth keys written by preprocess, whose workgroups also left
+// table 0 behind; culled Gaussians (CULLED_KEY) are dropped right there, so from pass 1 on the
+// arrays hold only the V visible ones.  V = sum of table 0, published by chunk 0 of pass 0.
+// The tables of passes 1-3 come from depth_hist_kernel, launched after the previous scatter.
+// The last pass also writes the per-Gaussian tile counts in sorted order and accumulates the
+// per-2048 block sums of the offsets scan (one atomic per wave when the wave's outputs fall in one
+// block, which they nearly always do: a wave stores a run of consecutive positions).
 // ------------------------------------------------------------------------------------------
-constexpr int GH_ITEMS = 32;                       // keys per thread in radix_global_hist
-constexpr int GH_CHUNK = 256 * GH_ITEMS;
-constexpr int OS_MAX_PASSES = 4;
-
-__global__ void __launch_bounds__(256)
-radix_global_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t n, const int begin_bit,
-                         const int passes, const int bits0, const int bits_rest,
-                         uint32_t* __restrict__ totals /* [passes][256] */) {
-  __shared__ uint32_t h[OS_MAX_PASSES][RS_MAX_RADIX];
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, const uint32_t lane) {
 #pragma unroll
-  for (int p = 0; p < OS_MAX_PASSES; p++) h[p][threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * GH_CHUNK;
-  for (int k = 0; k < GH_ITEMS; k++) {
-    const uint32_t idx = base + k * 256 + threadIdx.x;
-    if (idx < n) {
-      uint32_t key = keys[idx] >> begin_bit;
-      for (int p = 0; p < passes; p++) {
-        const int b = p == 0 ? bits0 : bits_rest;
-        atomicAdd(&h[p][key & ((1u << b) - 1u)], 1u);
-        key >>= b;
-      }
-    }
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= (uint32_t)d) v += t;
   }
-  __syncthreads();
-  for (int p = 0; p < passes; p++) {
-    const uint32_t c = h[p][threadIdx.x];
-    if (c) atomicAdd(&totals[p * RS_MAX_RADIX + threadIdx.x], c);
+  return v;
+}
+
+// ctr[idx] += v for every `active` lane: one atomic per wave when all active lanes name the same
+// counter, per-lane atomics otherwise.  Must be called by all lanes of the wave.
+__device__ __forceinline__ void wave_agg_add(uint32_t* __restrict__ ctr, const uint32_t idx,
+                                             const uint32_t v, const bool active) {
+  const uint64_t am = __builtin_amdgcn_ballot_w64(active);
+  if (am == 0ull) return;
+  const int first = __ffsll((unsigned long long)am) - 1;
+  const uint32_t f = (uint32_t)__shfl((int)idx, first, 64);
+  const uint64_t diff = __builtin_amdgcn_ballot_w64(active && idx != f);
+  if (diff == 0ull) {
+    uint32_t sum = active ? v : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    if ((int)(threadIdx.x & 63) == first) atomicAdd(&ctr[f], sum);
+  } else if (active) {
+    atomicAdd(&ctr[idx], v);
   }
 }
 
-constexpr uint32_t OS_AGG = 1u, OS_PFX = 2u;
+__global__ void __launch_bounds__(DS_THREADS)
+depth_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_dev,
+                  const int shift, uint32_t* __restrict__ table /* [chunk][256] of this pass */) {
+  __shared__ uint32_t h[DS_RADIX];
+  const uint32_t n = *n_dev;
+  const uint32_t base = blockIdx.x * DS_CHUNK;
+  if (base >= n) return;   // rows beyond the data stay zero (frame_init)
+  if (threadIdx.x < DS_RADIX) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t kk[DS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < DS_ITEMS; k++) {
+    const uint32_t idx = base + k * DS_THREADS + threadIdx.x;
+    kk[k] = idx < n ? keys[idx] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < DS_ITEMS; k++) {
+    const uint32_t idx = base + k * DS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(kk[k] >> shift) & (DS_RADIX - 1)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < DS_RADIX) table[(size_t)blockIdx.x * DS_RADIX + threadIdx.x] = h[threadIdx.x];
+}
 
-__global__ void __launch_bounds__(RS_THREADS)
-radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                      const uint32_t n, const int shift, const int bits,
-                      const uint32_t* __restrict__ totals /* this pass: [256] */,
-                      unsigned long long* __restrict__ status /* [nchunks][256] */,
-                      const uint32_t tag, const uint32_t* __restrict__ gather_src,
-                      uint32_t* __restrict__ gather_dst) {
-  __shared__ uint32_t s_cnt[RS_MAX_RADIX * 4];  // [digit][wave]
-  __shared__ uint32_t s_gbase[RS_MAX_RADIX];
-  __shared__ uint32_t s_wave[4];
-  __shared__ uint32_t s_keys[RS_CHUNK];
-  __shared__ uint32_t s_vals[RS_CHUNK];
+template <int PASS>
+__global__ void __launch_bounds__(DS_THREADS)
+depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                     const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][256] */,
+                     const uint32_t nchunks, uint32_t* __restrict__ V_out,
+                     const uint32_t* __restrict__ gather_src, uint32_t* __restrict__ gather_dst,
+                     uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t s_keys[DS_CHUNK];
+  __shared__ uint32_t s_vals[DS_CHUNK];
+  __shared__ uint32_t s_cnt[DS_RADIX * DS_WAVES];   // [digit][wave]
+  __shared__ uint32_t s_gbase[DS_RADIX];
+  __shared__ uint32_t s_pex[4][DS_RADIX];
+  __shared__ uint32_t s_ptot[4][DS_RADIX];
+  __shared__ uint32_t s_w[8];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t mask = (1u << bits) - 1u;
   const uint32_t chunk = blockIdx.x;
-  const uint32_t chunk_base = chunk * RS_CHUNK;
-  const uint32_t chunk_n = min((uint32_t)RS_CHUNK, n - chunk_base);
+  constexpr int shift = 8 * PASS;
 
+  // ---- sweep the count table: per digit, sum over earlier chunks and over all chunks ----
+  {
+    const uint32_t d = tid & (DS_RADIX - 1), g = tid >> 8;   // 4 row groups
+    uint32_t ex = 0, tot = 0;
+    for (uint32_t r = g; r < nchunks; r += 4) {
+      const uint32_t v = table[(size_t)r * DS_RADIX + d];
+      tot += v;
+      ex += r < chunk ? v : 0u;
+    }
+    s_pex[g][d] = ex;
+    s_ptot[g][d] = tot;
+  }
 #pragma unroll
-  for (int k = 0; k < 4; k++) s_cnt[tid * 4 + k] = 0;
+  for (int k = 0; k < (DS_RADIX * DS_WAVES) / DS_THREADS; k++) s_cnt[k * DS_THREADS + tid] = 0;
   __syncthreads();
+  uint32_t dex = 0, dtot = 0, inc = 0;
+  if (tid < DS_RADIX) {
+    dex = s_pex[0][tid] + s_pex[1][tid] + s_pex[2][tid] + s_pex[3][tid];
+    dtot = s_ptot[0][tid] + s_ptot[1][tid] + s_ptot[2][tid] + s_ptot[3][tid];
+    inc = wave_inclusive_sum(dtot, lane);
+    if (lane == 63) s_w[wave] = inc;
+  }
+  __syncthreads();
+  const uint32_t n_all = s_w[0] + s_w[1] + s_w[2] + s_w[3];   // elements this pass moves (= V)
+  if (tid < DS_RADIX) {
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < 3; w++) before += (uint32_t)w < wave ? s_w[w] : 0u;
+    s_gbase[tid] = before + inc - dtot + dex;   // first output position of (digit, this chunk)
+  }
+  if (PASS == 0 && chunk == 0 && tid == 0) *V_out = n_all;
+  const uint32_t n_in = PASS == 0 ? P : n_all;
+  const uint32_t chunk_base = chunk * DS_CHUNK;
+  if (chunk_base >= n_in) return;   // whole workgroup
+  const uint32_t chunk_n = min((uint32_t)DS_CHUNK, n_in - chunk_base);
 
-  uint32_t key[RS_ITEMS], val[RS_ITEMS], rnk[RS_ITEMS];
+  // ---- load + rank (wave w owns the 512 consecutive keys [512 w, 512 w + 512)) ----
+  uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
-    const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
+  for (int i = 0; i < DS_ITEMS; i++) {
+    const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
     const uint32_t idx = chunk_base + local;
-    const bool valid = local < chunk_n;
-    key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-    val[i] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
-    const uint32_t d = (key[i] >> shift) & mask;
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < bits; b++) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
+    const bool inb = local < chunk_n;
+    key[i] = inb ? keys_in[idx] : CULLED_KEY;
+    val[i] = PASS == 0 ? idx : (inb ? vals_in[idx] : 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < DS_ITEMS; i++) {
+    const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
+    // pass 0 drops culled Gaussians; later passes hold visible ones only (a visible depth key is
+    // the bit pattern of a float > 0.2, never CULLED_KEY)
+    const bool valid = local < chunk_n && (PASS > 0 || key[i] != CULLED_KEY);
+    const uint32_t d = (key[i] >> shift) & (DS_RADIX - 1);
+    uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(((d >> b) & 1u) != 0u);
+      const uint32_t mine = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+      peers &= ~(bal ^ (((uint64_t)mine << 32) | mine));
     }
     const uint32_t before = (uint32_t)__popcll(peers & lt);
-    const uint32_t prev = valid ? s_cnt[d * 4 + wave] : 0u;
-    rnk[i] = prev + before;
-    if (valid && before == 0) s_cnt[d * 4 + wave] = prev + (uint32_t)__popcll(peers);
+    const uint32_t prev = valid ? s_cnt[d * DS_WAVES + wave] : 0u;
+    rnk[i] = valid ? prev + before : 0xFFFFFFFFu;
+    if (valid && before == 0) s_cnt[d * DS_WAVES + wave] = prev + (uint32_t)__popcll(peers);
   }
   __syncthreads();
 
-  {
-    const uint32_t c0 = s_cnt[tid * 4 + 0], c1 = s_cnt[tid * 4 + 1], c2 = s_cnt[tid * 4 + 2],
-                   c3 = s_cnt[tid * 4 + 3];
-    const uint32_t dsum = c0 + c1 + c2 + c3;
-    // ---- decoupled look-back: exclusive count of digit `tid` over all earlier chunks ----
-    uint32_t excl = 0;
-    if (tid <= mask) {
-      unsigned long long* mine = status + (size_t)chunk * RS_MAX_RADIX + tid;
-      const unsigned long long tagw = (unsigned long long)(tag << 2) << 32;
-      if (chunk == 0) {
-        __hip_atomic_store(mine, tagw | ((unsigned long long)OS_PFX << 32) | dsum, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __hip_atomic_store(mine, tagw | ((unsigned long long)OS_AGG << 32) | dsum, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long* p = mine - RS_MAX_RADIX;
-        for (;;) {
-          const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t hi = (uint32_t)(w >> 32);
-          if ((hi >> 2) == tag && (hi & 3u) != 0u) {
-            excl += (uint32_t)w;
-            if ((hi & 3u) == OS_PFX) break;
-            p -= RS_MAX_RADIX;              // aggregate only: keep walking back (chunk 0 is a prefix)
-          } else {
-            __builtin_amdgcn_s_sleep(1);    // predecessor has not published yet
-          }
-        }
-        __hip_atomic_store(mine, tagw | ((unsigned long long)OS_PFX << 32) | (excl + dsum),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    uint32_t tot;
-    const uint32_t dstart = block_exclusive_scan_256(dsum, s_wave, &tot);
-    const uint32_t gtot = tid <= mask ? totals[tid] : 0u;
-    uint32_t tot2;
-    const uint32_t gstart = block_exclusive_scan_256(gtot, s_wave, &tot2);
-    s_cnt[tid * 4 + 0] = dstart;
-    s_cnt[tid * 4 + 1] = dstart + c0;
-    s_cnt[tid * 4 + 2] = dstart + c0 + c1;
-    s_cnt[tid * 4 + 3] = dstart + c0 + c1 + c2;
-    s_gbase[tid] = gstart + excl - dstart;  // wraps mod 2^32; only used as base + slot
-  }
-  __syncthreads();
-
+  // ---- thread d < 256 owns digit d: local start slots of its 16 (digit, wave) runs ----
+  uint32_t c[DS_WAVES], dsum = 0, inc2 = 0;
+  if (tid < DS_RADIX) {
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
-    const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
-    if (local < chunk_n) {
-      const uint32_t d = (key[i] >> shift) & mask;
-      const uint32_t slot = s_cnt[d * 4 + wave] + rnk[i];
+    for (int w = 0; w < DS_WAVES; w++) { c[w] = s_cnt[tid * DS_WAVES + w]; dsum += c[w]; }
+    inc2 = wave_inclusive_sum(dsum, lane);
+    if (lane == 63) s_w[4 + wave] = inc2;
+  }
+  __syncthreads();
+  const uint32_t nvalid = s_w[4] + s_w[5] + s_w[6] + s_w[7];
+  if (tid < DS_RADIX) {
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < 3; w++) before += (uint32_t)w < wave ? s_w[4 + w] : 0u;
+    const uint32_t dstart = before + inc2 - dsum;
+    uint32_t run = dstart;
+#pragma unroll
+    for (int w = 0; w < DS_WAVES; w++) { s_cnt[tid * DS_WAVES + w] = run; run += c[w]; }
+    s_gbase[tid] -= dstart;   // wraps mod 2^32; only used as base + local slot
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < DS_ITEMS; i++) {
+    if (rnk[i] != 0xFFFFFFFFu) {
+      const uint32_t d = (key[i] >> shift) & (DS_RADIX - 1);
+      const uint32_t slot = s_cnt[d * DS_WAVES + wave] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
     }
   }
   __syncthreads();
 
-  for (uint32_t j = tid; j < chunk_n; j += RS_THREADS) {
-    const uint32_t k = s_keys[j];
-    const uint32_t d = (k >> shift) & mask;
-    const uint32_t g = s_gbase[d] + j;
-    keys_out[g] = k;
-    const uint32_t v = s_vals[j];
-    vals_out[g] = v;
-    if (gather_src) gather_dst[g] = gather_src[v];
+  // ---- coalesced run writes ----
+  uint32_t gsrc[DS_ITEMS];
+  if (PASS == DS_PASSES - 1) {   // tile counts in sorted order: all gathers first, then the stores
+#pragma unroll
+    for (int i = 0; i < DS_ITEMS; i++) {
+      const uint32_t j = i * DS_THREADS + tid;
+      gsrc[i] = j < nvalid ? gather_src[s_vals[j]] : 0u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DS_ITEMS; i++) {
+    const uint32_t j = i * DS_THREADS + tid;
+    const bool on = j < nvalid;
+    uint32_t g = 0;
+    if (on) {
+      const uint32_t k = s_keys[j];
+      g = s_gbase[(k >> shift) & (DS_RADIX - 1)] + j;
+      keys_out[g] = k;
+      vals_out[g] = s_vals[j];
+      if (PASS == DS_PASSES - 1) gather_dst[g] = gsrc[i];
+    }
+    if (PASS == DS_PASSES - 1) wave_agg_add(block_sums, g / SC_CHUNK, gsrc[i], on);
   }
 }
 
-bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                      uint32_t* val_b, bool vals_iota, int begin_bit, int end_bit, uint32_t* table,
-                      uint32_t* totals, uint32_t nchunks, const uint32_t* gather_src,
+// Depth sort of the P (key, id) pairs; ids are implicit in pass 0.  Result: (key_a, val_a) hold
+// the V visible pairs in (depth_bits, id) order, tiles_sorted their tile counts, block_sums the
+// per-SC_CHUNK sums of tiles_sorted, *V_out = V.  ds_table must be zero except for the rows of
+// pass 0 (preprocess).  7 launches.
+void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
+                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
+                    const uint32_t* tiles, uint32_t* tiles_sorted, uint32_t* block_sums) {
+  if (P == 0) return;
+  const size_t tsz = (size_t)nchunks * DS_RADIX;
+#define DS_SCATTER(PASS, KI, VI, KO, VO)                                                        \
+  depth_scatter_kernel<PASS><<<nchunks, DS_THREADS, 0, s>>>(KI, VI, KO, VO, P, ds_table + PASS * tsz, \
+                                                            nchunks, V_out, tiles, tiles_sorted, block_sums)
+  DS_SCATTER(0, key_a, nullptr, key_b, val_b);
+  depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 8, ds_table + 1 * tsz);
+  DS_SCATTER(1, key_b, val_b, key_a, val_a);
+  depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_a, V_out, 16, ds_table + 2 * tsz);
+  DS_SCATTER(2, key_a, val_a, key_b, val_b);
+  depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 24, ds_table + 3 * tsz);
+  DS_SCATTER(3, key_b, val_b, key_a, val_a);
+#undef DS_SCATTER
+}
+
+// Classic passes.  n = host-side upper bound (sizes the grids), n_dev = device-side element count
+// (may be NULL: n is exact).  have_hist0: the caller already filled table[digit][chunk] for the
+// first pass (emit_kernel does, for the tile partition).
+bool radix_sort_pairs(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t* key_a,
+                      uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, bool vals_iota,
+                      int begin_bit, int end_bit, uint32_t* table, uint32_t* totals,
+                      uint32_t nchunks, bool have_hist0, const uint32_t* gather_src,
                       uint32_t* gather_dst) {
   bool in_b = false;
   if (n == 0) return in_b;
@@ -386,42 +477,6 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_
   if (nbits <= 0) return in_b;
   const int passes = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
   int shift = begin_bit;
-  // Default: the three-kernel reduce-then-scan pass.  The look-back variant is correct (parity
-  // tests pass with GRPG_SORT=onesweep) but measured SLOWER on MI355X (depth sort 0.164 vs 0.129 ms,
-  // tile partition 0.204 vs 0.140 ms): a status word crosses XCDs at ~1 us per hop, and with
-  // ~1800 resident workgroups publishing "aggregate" at once the walk-back is long.
-  static const bool onesweep = [] { const char* e = getenv("GRPG_SORT"); return e && e[0] == 'o'; }();
-  if (onesweep && passes <= OS_MAX_PASSES) {
-    // onesweep: `table` holds the status words (8 B x 256 x nchunks), `totals` the per-pass digit
-    // histograms ([4][256]); both are zeroed once per sort.
-    int bits_p[OS_MAX_PASSES];
-    {
-      int sh = begin_bit;
-      for (int p = 0; p < passes; p++) { bits_p[p] = (end_bit - sh + (passes - p) - 1) / (passes - p); sh += bits_p[p]; }
-    }
-    // the histogram kernel assumes pass 0 may be wider than the (equal) remaining passes
-    bool uniform_rest = true;
-    for (int p = 2; p < passes; p++) uniform_rest = uniform_rest && bits_p[p] == bits_p[1];
-    if (uniform_rest) {
-      (void)hipMemsetAsync(totals, 0, OS_MAX_PASSES * RS_MAX_RADIX * sizeof(uint32_t), s);
-      (void)hipMemsetAsync(table, 0, (size_t)nchunks * RS_MAX_RADIX * 8, s);
-      radix_global_hist_kernel<<<(n + GH_CHUNK - 1) / GH_CHUNK, 256, 0, s>>>(
-          key_a, n, begin_bit, passes, bits_p[0], passes > 1 ? bits_p[1] : bits_p[0], totals);
-      for (int p = 0; p < passes; p++) {
-        uint32_t* kin = in_b ? key_b : key_a;
-        uint32_t* vin = in_b ? val_b : val_a;
-        uint32_t* kout = in_b ? key_a : key_b;
-        uint32_t* vout = in_b ? val_a : val_b;
-        radix_onesweep_kernel<<<nchunks, RS_THREADS, 0, s>>>(
-            kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, shift, bits_p[p],
-            totals + p * RS_MAX_RADIX, (unsigned long long*)table, (uint32_t)(p + 1),
-            p == passes - 1 ? gather_src : nullptr, gather_dst);
-        in_b = !in_b;
-        shift += bits_p[p];
-      }
-      return in_b;
-    }
-  }
   for (int p = 0; p < passes; p++) {
     // spread the bits evenly over the passes (e.g. 14 bits -> 7 + 7)
     const int bits = (end_bit - shift + (passes - p) - 1) / (passes - p);
@@ -430,12 +485,13 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* key_a, uint32_t* val_
     uint32_t* vin = in_b ? val_b : val_a;
     uint32_t* kout = in_b ? key_a : key_b;
     uint32_t* vout = in_b ? val_a : val_b;
-    radix_hist_kernel<<<nchunks, RS_THREADS, 0, s>>>(kin, n, shift, mask, table, nchunks);
-    radix_digit_scan_kernel<<<1u << bits, 256, 0, s>>>(table, nchunks, totals);
+    if (!(p == 0 && have_hist0))
+      radix_hist_kernel<<<nchunks, RS_THREADS, 0, s>>>(kin, n, n_dev, shift, mask, table, nchunks);
+    radix_digit_scan_kernel<<<1u << bits, 256, 0, s>>>(table, nchunks, n, n_dev, totals);
 #define RS_SCATTER(CB)                                                                        \
   radix_scatter_kernel<CB><<<nchunks, RS_THREADS, 0, s>>>(                                    \
-      kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, shift, bits, table, totals,  \
-      nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst)
+      kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, n_dev, shift, bits, table,   \
+      totals, nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst)
     if (bits == 8) RS_SCATTER(8);        // depth sort
     else if (bits == 7) RS_SCATTER(7);   // tile partition of a 1920x1280 frame (14 bits)
     else RS_SCATTER(0);
@@ -450,11 +506,16 @@ int radix_sort_num_passes(int begin_bit, int end_bit) {
   const int nbits = end_bit - begin_bit;
   return nbits <= 0 ? 0 : (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
 }
+int radix_sort_first_pass_bits(int begin_bit, int end_bit) {
+  const int passes = radix_sort_num_passes(begin_bit, end_bit);
+  return passes == 0 ? 0 : (end_bit - begin_bit + passes - 1) / passes;
+}
 
 // ------------------------------------------------------------------------------------------
 // Exclusive scan of the per-Gaussian instance counts in depth-sorted order (written contiguously
 // by the last depth-sort pass) -> offsets[i]; replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:280).
-// Two launches: per-workgroup reduce, per-workgroup downsweep (which recomputes the spine).
+// The per-workgroup sums arrive from the fat depth sort (one launch here: the down-sweep, which
+// recomputes the spine) or from scan_reduce_kernel (classic depth sort: two launches).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SC_THREADS)
 scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
@@ -475,15 +536,18 @@ scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
 }
 
 __global__ void __launch_bounds__(SC_THREADS)
-scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
+scan_down_kernel(const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
+                 const uint32_t* __restrict__ tiles,
                  const uint32_t* __restrict__ block_sums, const uint32_t nblocks,
                  uint32_t* __restrict__ offsets, uint32_t* __restrict__ total_out,
-                 uint32_t* __restrict__ emit_win, const uint32_t emit_win_cap) {
+                 uint32_t* __restrict__ total_host, uint32_t* __restrict__ emit_win,
+                 const uint32_t emit_win_cap) {
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_spine[8];
+  const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
   // the spine (prefix of the workgroup sums before this workgroup, and the grand total) is
   // recomputed by every workgroup from the <= a few thousand L2-resident sums: cheaper than a
-  // third launch with a single workgroup
+  // third launch with a single workgroup.  Sums of workgroups beyond n are zero.
   {
     uint32_t pre = 0, tot = 0;
     for (uint32_t i = threadIdx.x; i < nblocks; i += SC_THREADS) {
@@ -501,7 +565,13 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
   }
   const uint32_t block_prefix = s_spine[0] + s_spine[2] + s_spine[4] + s_spine[6];
   const uint32_t total = s_spine[1] + s_spine[3] + s_spine[5] + s_spine[7];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *total_out = total;
+    // num_rendered for the host: a plain store into pinned, device-mapped host memory; the host
+    // reads it after the event recorded behind this kernel has fired (api.hip)
+    if (total_host) { total_host[0] = total; total_host[1] = n; }
+  }
+  if (blockIdx.x * SC_CHUNK >= n) return;
   // thread t owns SC_ITEMS consecutive elements so that the scan order is the array order
   const uint32_t base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
   uint32_t v[SC_ITEMS], s = 0;
@@ -518,7 +588,7 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
     const uint32_t i = base + k;
     if (i < n) offsets[i] = ex;
     // Element i owns instance slots [ex, ex + v): tell emit (binning.hip) which element owns the
-    // first slot of each of its 1024-slot blocks, and which element owns the very last slot.
+    // first slot of each of its 2048-slot blocks, and which element owns the very last slot.
     if (v[k] > 0) {
       const uint32_t end = ex + v[k];
       for (uint32_t b = (ex + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK; b * EMIT_PER_BLOCK < end; b++)
@@ -532,13 +602,14 @@ scan_down_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
   }
 }
 
-void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* tiles_sorted,
-                         uint32_t* offsets, uint32_t* block_sums, uint32_t nblocks,
-                         uint32_t* total_out, uint32_t* emit_win, uint32_t emit_win_cap) {
+void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
+                         const uint32_t* tiles_sorted, uint32_t* offsets, uint32_t* block_sums,
+                         uint32_t nblocks, bool have_block_sums, uint32_t* total_out,
+                         uint32_t* total_host, uint32_t* emit_win, uint32_t emit_win_cap) {
   if (n == 0) return;
-  scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums);
-  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums, nblocks, offsets,
-                                                   total_out, emit_win, emit_win_cap);
+  if (!have_block_sums) scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums);
+  scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, n_dev, tiles_sorted, block_sums, nblocks, offsets,
+                                                   total_out, total_host, emit_win, emit_win_cap);
 }
 
 }  // namespace grpg

@@ -153,6 +153,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   const int H = dL_dout_color.size(1);   // rasterize_points.cu:156-158
   const int W = dL_dout_color.size(2);
   const int S = dL_dout_semantic.size(0);
+  TORCH_CHECK(S <= GRPG_MAX_SEMANTIC_BACKWARD, "rasterize_gaussians_backward supports at most ",
+              GRPG_MAX_SEMANTIC_BACKWARD, " semantic channels, got ", S);
   int M = 0;
   if (sh.size(0) != 0) M = sh.size(1);
 
@@ -372,4 +374,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_stage_timing", [](int mode) { grpg_set_stage_timing(mode); });   // 0 off, 1 all, 2 render only
   m.def("stage_timing", &StageTiming);
   m.def("abi_version", []() { return grpg_abi_version(); });
+  // 0 = speculative binning capacity + deferred num_rendered wait (default), 1 = exact (reference-like)
+  m.def("set_binning_mode", [](int mode) {
+    if (grpg_set_binning_mode(mode) != GRPG_OK) raise_abi_error("grpg_set_binning_mode", -1);
+  });
+  m.def("reset_capacity_hints", []() { grpg_reset_capacity_hints(); });
 }

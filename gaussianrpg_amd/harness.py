@@ -184,3 +184,123 @@ def settings_kwargs(cam: CameraTensors, sh_degree: int, bg: Optional[torch.Tenso
                 tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=scale_modifier,
                 viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, sh_degree=sh_degree,
                 campos=cam.campos, prefiltered=False, debug=debug)
+
+
+# ----------------------------------------------------------------------------------------------
+# Callers of the op: build-owned counterparts of StreetGaussianRenderer
+# (lib/models/street_gaussian_renderer.py:13-274), of the evaluation timer of render.py:30-60 and
+# of the loss / densification reads of train.py:110-229 + street_gaussian_model.py:567-578.
+# They hand the op exactly what those callers hand it; model composition, sky, colour correction
+# and the dataset are outside the op (the scene arrives as flat tensors).
+# ----------------------------------------------------------------------------------------------
+def scene_subset(scene: Scene, mask: torch.Tensor) -> Scene:
+    """`pc.set_visibility(include_list)` + `pc.parse_camera` seen from the op: the flat tensors of
+    the included models (street_gaussian_renderer.py:50-51,66-67,99-100)."""
+    return Scene(*(t[mask].contiguous() if isinstance(t, torch.Tensor) else t for t in scene))
+
+
+def render_kernel(scene: Scene, cam: CameraTensors, *, mode: str = "evaluate",
+                  white_background: bool = False, semantics: Optional[torch.Tensor] = None,
+                  scale_modifier: float = 1.0) -> dict:
+    """StreetGaussianRenderer.render_kernel (street_gaussian_renderer.py:120-274): settings via
+    make_rasterizer, ``means2D`` = zeros[P,3] with grad in train mode and None otherwise, SHs handed
+    to the op, clamp outside train mode, the result dict the trainer reads."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = cam.viewmatrix.device
+    H, W = int(cam.image_height), int(cam.image_width)
+    P = scene.means3D.shape[0]
+    if P == 0:   # :131-144 -- the op is not called at all
+        fill = torch.ones if white_background else torch.zeros
+        return {"rgb": fill(3, H, W, device=dev), "acc": torch.zeros(1, H, W, device=dev),
+                "semantic": torch.zeros(0, H, W, device=dev)}
+    bg = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(
+        **settings_kwargs(cam, scene.sh_degree, bg=bg, scale_modifier=scale_modifier)))
+    if mode == "train":   # :157-162
+        screenspace_points = torch.zeros((P, 3), requires_grad=True).float().to(dev) + 0
+        screenspace_points.retain_grad()
+    else:
+        screenspace_points = None
+    color, radii, depth, acc, feat = rast(
+        means3D=scene.means3D, means2D=screenspace_points, opacities=scene.opacity, shs=scene.shs,
+        colors_precomp=None, scales=scene.scales, rotations=scene.rotations, cov3D_precomp=None,
+        semantics=semantics)
+    if mode != "train":
+        color = torch.clamp(color, 0.0, 1.0)   # :236-237
+    out = {"rgb": color, "acc": acc, "depth": depth, "viewspace_points": screenspace_points,
+           "visibility_filter": radii > 0, "radii": radii}
+    if feat.shape[0] > 0:
+        out["semantic"] = feat
+    return out
+
+
+def render(scene: Scene, cam: CameraTensors, *, mode: str = "evaluate", **kw) -> dict:
+    """StreetGaussianRenderer.render (:88-118) without sky / colour correction: one op call."""
+    res = render_kernel(scene, cam, mode=mode, **kw)
+    if mode != "train":
+        res["rgb"] = torch.clamp(res["rgb"], 0.0, 1.0)
+    return res
+
+
+def render_all(scene: Scene, cam: CameraTensors, obj_mask: torch.Tensor, *, mode: str = "evaluate") -> dict:
+    """StreetGaussianRenderer.render_all (:13-40), the non-lite evaluation path: THREE op calls per
+    frame -- the composition (black background), the background model alone and the object models
+    alone (both on white)."""
+    result = render(scene, cam, mode=mode)
+    bkgd = render_kernel(scene_subset(scene, ~obj_mask), cam, mode=mode, white_background=True)
+    obj = render_kernel(scene_subset(scene, obj_mask), cam, mode=mode, white_background=True)
+    result["rgb_background"] = bkgd["rgb"]
+    result["acc_background"] = bkgd["acc"]
+    result["rgb_object"] = obj["rgb"]
+    result["acc_object"] = obj["acc"]
+    return result
+
+
+def train_loss(render_pkg: dict, gt_image: torch.Tensor, lidar_depth: Optional[torch.Tensor] = None,
+               sky_mask: Optional[torch.Tensor] = None, lambda_l1: float = 1.0,
+               lambda_depth_lidar: float = 0.1, lambda_sky: float = 0.05) -> torch.Tensor:
+    """The loss mix of train.py:110-127,164-176 that reaches the op's four outputs: L1 on rgb
+    (loss_utils.l1_loss), the sky term on acc, the lidar term on depth / (acc + 1e-10) keeping the
+    smallest 95 % of the errors.  (SSIM, semantic and the regularisers do not change which output
+    gradients are non-zero.)"""
+    image, acc, depth = render_pkg["rgb"], render_pkg["acc"], render_pkg["depth"]
+    loss = lambda_l1 * torch.abs(image - gt_image).mean()
+    if sky_mask is not None and lambda_sky > 0:
+        a = torch.clamp(acc, min=1e-6, max=1.0 - 1e-6)
+        loss = loss + lambda_sky * torch.where(sky_mask, -torch.log(1 - a), -torch.log(a)).mean()
+    if lidar_depth is not None and lambda_depth_lidar > 0:
+        depth_mask = lidar_depth > 0.0
+        if bool(depth_mask.any()):
+            expected = depth / (acc + 1e-10)
+            err = torch.abs(expected[depth_mask] - lidar_depth[depth_mask])
+            err, _ = torch.topk(err, int(0.95 * err.size(0)), largest=False)
+            loss = loss + lambda_depth_lidar * err.mean()
+    return loss
+
+
+def densification_stats(viewspace_point_tensor: torch.Tensor, visibility_filter: torch.Tensor):
+    """street_gaussian_model.py:567-578: the two norms the densifier accumulates, read from the
+    gradient the op leaves on ``means2D`` -- [:, :2] is the NDC-scaled screen gradient, [:, 2:] the
+    accumulated |dx| + |dy| (backward.cu:625-628)."""
+    g = viewspace_point_tensor.grad
+    n_xy = torch.norm(g[visibility_filter, :2], dim=-1, keepdim=True)
+    n_abs = torch.norm(g[visibility_filter, 2:], dim=-1, keepdim=True)
+    return n_xy, n_abs
+
+
+def time_frames(render_one, num_frames: int, skip_first: int = 1) -> dict:
+    """render.py:30-60: per frame ``torch.cuda.synchronize(); t0; render; synchronize; t1`` in
+    milliseconds, the first frame excluded from the statistics (render.py:59-60 averages times[1:]).
+    Returns mean / median / p95 of the kept frames."""
+    import time
+    times = []
+    for k in range(num_frames):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        render_one(k)
+        torch.cuda.synchronize()
+        times.append((time.time() - t0) * 1000.0)
+    kept = sorted(times[skip_first:])
+    n = len(kept)
+    return {"frames": n, "mean_ms": sum(kept) / n, "median_ms": kept[n // 2],
+            "p95_ms": kept[min(n - 1, int(0.95 * n))], "first_frame_ms": times[0]}

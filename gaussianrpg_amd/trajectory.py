@@ -130,13 +130,15 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
     -- ``gather_batch=B`` -- one asynchronous gather per B frame slots, issued as soon as the batch
     is rendered so that it travels over xGMI while the next batch renders (only the last batch's
     transfer is exposed).  On a GPU the frame loop alternates over ``num_streams`` HIP streams:
-    frames are independent, so the VALU-bound render of frame k overlaps the HBM-bound binning of
-    frame k+1 and the op's one host round trip per frame (num_rendered) no longer idles the device.
+    frames are independent, so the VALU-bound render tail of frame k overlaps the HBM-bound
+    preprocess / binning of frame k+1.
     """
+    # checked identically on EVERY rank before any collective, so a mis-sized job fails on all
+    # ranks instead of leaving the others hanging in dist.gather
+    if num_frames < world:
+        raise ValueError("num_frames=%d < world=%d: every rank must own a frame" % (num_frames, world))
     mine = shard_frames(num_frames, rank, world)
     per_rank = (num_frames + world - 1) // world
-    if not mine:   # more ranks than frames
-        raise ValueError("rank %d owns no frame (num_frames=%d < world=%d)" % (rank, num_frames, world))
     batched = bool(gather and world > 1 and gather_batch and gather_batch > 0)
     local = None
     bufs = None
@@ -149,14 +151,18 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
             if streams is None and torch.cuda.is_available() and num_streams > 1:
                 streams = [torch.cuda.Stream() for _ in range(num_streams)]
             if streams:
-                with torch.cuda.stream(streams[j % len(streams)]):
+                st_j = streams[j % len(streams)]
+                with torch.cuda.stream(st_j):
                     color = render_frame(i)
-                    if local is None:
-                        on_gpu = color.is_cuda
-                        local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
-                                            device=color.device)
-                        for st in streams:      # the buffer must exist before any stream writes it
-                            st.wait_stream(torch.cuda.current_stream())
+                if local is None:
+                    # allocated on the CALLER's stream (it is returned to the caller and handed to
+                    # the collective there); the side streams wait for the zero-fill
+                    on_gpu = color.is_cuda
+                    local = torch.zeros((per_rank,) + tuple(color.shape), dtype=torch.uint8,
+                                        device=color.device)
+                    for st in streams:
+                        st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st_j):
                     pack_u8(color, out=local[j])   # packed straight into its gather-buffer slot
             else:
                 color = render_frame(i)

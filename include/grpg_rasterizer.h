@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRPG_ABI_VERSION 1
+#define GRPG_ABI_VERSION 2
 
 /* Exported symbol (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -44,6 +44,9 @@ extern "C" {
 #define GRPG_TILE_Y 16
 /* RGB only: cuda_rasterizer/config.h:15 (NUM_CHANNELS). */
 #define GRPG_NUM_CHANNELS 3
+/* Semantic channels grpg_backward accepts (the forward takes any S); the reference's backward
+ * silently stops at 20 (cuda_rasterizer/config.h:16). */
+#define GRPG_MAX_SEMANTIC_BACKWARD 32
 
 enum {
   GRPG_OK = 0,
@@ -56,7 +59,10 @@ enum {
 
 /* Replaces std::function<char*(size_t N)> (rasterizer.h:33-35, rasterize_points.cu:27-33):
  * must return a device pointer to at least `bytes` bytes that stays valid until the blob is
- * released by the caller; called at most once per blob per grpg_forward. */
+ * released by the caller.  Called once per blob per grpg_forward; the BINNING allocator alone may be
+ * called a second time in the same grpg_forward (with a larger size, when num_rendered outgrew
+ * the capacity the library had guessed) -- the pointer of the first call is dead from then on,
+ * exactly like a second resize_() of the reference's torch tensor (rasterize_points.cu:27-33). */
 typedef char* (*grpg_alloc_fn)(size_t bytes, void* user);
 
 /* ABI version of the loaded library (== GRPG_ABI_VERSION of the header it was built from). */
@@ -76,8 +82,12 @@ GRPG_API const char* grpg_last_error(void);
  *   out_alpha[H,W], out_semantic[S,H,W], radii[P] (may be NULL).  Every pixel of every output
  *   plane is written (the reference relies on pre-zeroed planes; this library does not).
  * Returns num_rendered (>= 0, the number of Gaussian/tile instances) or a negative GRPG_ERR_*.
- * Synchronises `stream` once (to size the binning blob), as the reference does
- * (rasterizer_impl.cu:284).
+ * Waits ONCE for the device (for num_rendered, which the reference also reads back,
+ * rasterizer_impl.cu:284): in GRPG_BINNING_EXACT mode in the middle of the frame, before the
+ * binning blob is sized, exactly like the reference; in GRPG_BINNING_SPECULATIVE mode (default)
+ * after the whole frame has been enqueued -- the binning blob is then sized from the high-water
+ * mark of earlier calls with the same (device, P, width, height), 25 % head room, and the rare
+ * overflow re-runs the tail of the frame.  Results are identical in both modes.
  */
 GRPG_API int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user,
                  grpg_alloc_fn binning_alloc, void* binning_user,
@@ -92,6 +102,15 @@ GRPG_API int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user,
                  float tan_fovx, float tan_fovy, int prefiltered,
                  float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                  int* radii, int debug, void* hip_stream);
+
+/* Binning-blob sizing policy of grpg_forward (process-wide; see above).  The environment variable
+ * GRPG_SYNC_R=1 selects GRPG_BINNING_EXACT at load time. */
+#define GRPG_BINNING_SPECULATIVE 0
+#define GRPG_BINNING_EXACT 1
+GRPG_API int grpg_set_binning_mode(int mode);
+/* Forget the remembered num_rendered high-water marks (the next grpg_forward of every shape waits
+ * for the count before it sizes the binning blob). */
+GRPG_API int grpg_reset_capacity_hints(void);
 
 /*
  * Rasterizer::backward  (rasterizer.h:60-96, rasterizer_impl.cu:396-505).
@@ -180,8 +199,8 @@ GRPG_API int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, 
  * grpg_forward on this thread records GRPG_NUM_STAGES+1 events and returns without waiting;
  * grpg_get_stage_timing() waits for the recorded calls, writes the per-stage SUM of milliseconds
  * over those calls into stage_ms_sum[GRPG_NUM_STAGES] and their count into *num_calls, then
- * forgets them.  Stages: 0 preprocess, 1 depth sort, 2 offsets scan (+ the num_rendered read-back
- * and binning-blob allocation), 3 instance emit, 4 tile sort, 5 tile ranges, 6 render,
+ * forgets them.  Stages: 0 frame init + preprocess, 1 depth sort, 2 offsets scan (+ in exact mode
+ * the wait for num_rendered and the binning-blob allocation), 3 instance emit, 4 tile sort, 5 tile ranges, 6 render,
  * 7 semantic render.  enabled == 2 records only the two events around the render stage (the
  * cheap mode for a timed region: 2 event records per call instead of 9).
  */

@@ -18,30 +18,51 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libgs_oracle.so")
+_LIB_OMP_PATH = os.path.join(_HERE, "libgs_oracle_omp.so")
 _lib = None
+_use_omp = False
 
 BLOCK_X = 16
 BLOCK_Y = 16
 
 
 def build(force=False):
-    """Compile gs_oracle.c -> libgs_oracle.so with gcc (see Makefile)."""
+    """Compile gs_oracle.c -> libgs_oracle.so (scalar) and libgs_oracle_omp.so (OpenMP over
+    Gaussians / pixel rows, same results) with gcc (see Makefile)."""
     src = os.path.join(_HERE, "gs_oracle.c")
-    if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
-        return _LIB_PATH
-    subprocess.check_call(
-        ["gcc", "-O2", "-fPIC", "-std=c99", "-ffp-contract=off", "-fno-fast-math",
-         "-shared", "-o", _LIB_PATH, src, "-lm"])
+    for path, extra in ((_LIB_PATH, []), (_LIB_OMP_PATH, ["-fopenmp"])):
+        if (not force and os.path.exists(path) and os.path.getmtime(path) >= os.path.getmtime(src)):
+            continue
+        subprocess.check_call(
+            ["gcc", "-O2", "-fPIC", "-std=c99", "-ffp-contract=off", "-fno-fast-math"] + extra +
+            ["-shared", "-o", path, src, "-lm"])
     return _LIB_PATH
+
+
+def use_openmp(flag=True):
+    """Select the OpenMP build of the C oracle for subsequent calls (bench.py's cpu_baseline leg;
+    results are identical to the scalar build, tests/test_oracle_golden.py checks it)."""
+    global _lib, _use_omp
+    if bool(flag) != _use_omp:
+        _use_omp = bool(flag)
+        _lib = None
+
+
+def num_threads():
+    lib = _load()
+    lib.gso_num_threads.restype = ctypes.c_int
+    return int(lib.gso_num_threads())
 
 
 def _load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = _LIB_OMP_PATH if _use_omp else _LIB_PATH
+        src = os.path.join(_HERE, "gs_oracle.c")
+        if not os.path.exists(path) or (os.path.exists(src)
+                                        and os.path.getmtime(path) < os.path.getmtime(src)):
             build()
-        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib = ctypes.CDLL(path)
         _lib.gso_preprocess.restype = ctypes.c_int64
         _lib.gso_higher_msb.restype = ctypes.c_uint32
     return _lib

@@ -34,6 +34,9 @@
  * against THIS arithmetic.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -239,6 +242,10 @@ int64_t gso_preprocess(int P, int D, int M, const float* means3D, const float* s
   const float focal_y = H / (2.0f * tan_fovy);
   const float focal_x = W / (2.0f * tan_fovx);
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+  /* Gaussians are independent: the OpenMP build (libgs_oracle_omp.so, bench.py's cpu_baseline
+   * leg) splits them over the host cores; results are identical, the pragma is a comment
+   * without -fopenmp. */
+#pragma omp parallel for schedule(static)
   for (int idx = 0; idx < P; idx++) {
     radii[idx] = 0;
     tiles_touched[idx] = 0;
@@ -394,6 +401,9 @@ void gso_render(int W, int H, int S, const uint32_t* ranges, const uint32_t* poi
                 uint32_t* n_contrib, uint8_t* fragile) {
   const int gx = (W + BLOCK_X - 1) / BLOCK_X;
   const size_t HW = (size_t)H * W;
+  /* pixels are independent: OpenMP build = parallel over pixel rows (dynamic: rows differ in
+   * overdraw), identical results */
+#pragma omp parallel for schedule(dynamic, 4)
   for (int py = 0; py < H; py++)
     for (int px = 0; px < W; px++) {
       const size_t pix_id = (size_t)W * py + px;
@@ -766,3 +776,12 @@ void gso_mark_visible(int P, const float* means3D, const float* view, const floa
 }
 
 uint32_t gso_higher_msb(uint32_t n) { return getHigherMsb(n); }
+
+/* threads the OpenMP build will use (1 for the scalar build) */
+int gso_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -14,6 +14,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a box without a ROCm device skips the GPU tests instead of
+    failing in their fixtures (the driver selects them with -m gpu on the MI355X box)."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no ROCm device visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity statistics of this run (share of ALL pixels beyond 1e-4 per compared plane, fragile
+    ones included) -> gpurun_out/parity_stats.json, for DESIGN.md §3."""
+    try:
+        import json
+        import helpers
+        if helpers.PARITY_STATS:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "parity_stats_%d.json" % os.getpid()), "w") as f:
+                json.dump(helpers.PARITY_STATS, f, indent=1)
+    except Exception:
+        pass

@@ -36,12 +36,22 @@ def fixture_oracle_inputs(fx):
                 sh_degree=int(fx["sh_degree"]), campos=fx["campos"])
 
 
+PARITY_STATS = []     # one record per compared image plane; dumped by conftest at session end
+
+
 def assert_image_close(name, got, ref, fragile=None, atol=ATOL, rtol=RTOL, max_fragile_frac=0.1):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err = np.abs(got - ref)
     tol = atol + rtol * np.abs(ref)
+    # what the exemption really hides: the share of ALL pixels (fragile ones included) beyond 1e-4
+    test_id = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    PARITY_STATS.append(dict(
+        test=test_id, plane=name, pixels=int(err.size), beyond_1e4=int((err > tol).sum()),
+        frac_beyond_1e4=float((err > tol).mean()) if err.size else 0.0,
+        max_rel_err=float((err / (1.0 + np.abs(ref))).max()) if err.size else 0.0,
+        fragile_frac=float(np.asarray(fragile, dtype=bool).mean()) if fragile is not None else None))
     if fragile is None:
         bad = err > tol
         assert not bad.any(), "%s: %d px beyond tol, max err %.3e" % (name, bad.sum(), err.max())

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def dev():
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X (no ROCm device visible)")
     return torch.device("cuda:0")
 
 

@@ -1,0 +1,294 @@
+"""GPU tests (-m gpu) of BASELINE.json's configurations at their stated sizes and of the callers'
+argument patterns:
+
+* configs[0]  10 k random Gaussians @256x256 (script/test_gaussian_rasterization.py:44-53),
+* configs[2]  scene-002-like, P = 2 M @1920x1280, frames 0 and 199: integer outputs exact against the
+              oracle's preprocess + binning, blend checked through conservation laws,
+* configs[3]  trajectory.render_sharded with the HIP op (side streams, in-place pack, gather),
+              world = 1 and a two-rank run on one GPU,
+* configs[4]  train forward + backward at P = 1 M: the train-mode argument pattern, the loss mix of
+              train.py and the densifier's read of means2D.grad,
+* the non-lite render_all pattern (three op calls per frame) and the render.py frame timer,
+* one DIRECT ctypes call of grpg_forward with torch-allocated device pointers.
+"""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gaussianrpg_amd import harness as hz
+from gaussianrpg_amd import trajectory as tj
+from helpers import assert_image_close, oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X (no ROCm device visible)")
+    return torch.device("cuda:0")
+
+
+def _raw_forward(dev, sc, cam, bg=None):
+    from gaussianrpg_amd.rasterizer import _C, debug_export
+    d = sc.to(dev)
+    P = d.means3D.shape[0]
+    kw = hz.settings_kwargs(hz.CameraTensors(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy,
+                                             cam.viewmatrix.to(dev), cam.projmatrix.to(dev),
+                                             cam.campos.to(dev)), sc.sh_degree,
+                            bg=None if bg is None else torch.as_tensor(bg, dtype=torch.float32).to(dev))
+    e = torch.Tensor([])
+    out = _C.rasterize_gaussians(kw["bg"], d.means3D, e, torch.zeros(P, 0, device=dev), d.opacity, d.scales,
+                                 d.rotations, 1.0, e, kw["viewmatrix"], kw["projmatrix"], kw["tanfovx"],
+                                 kw["tanfovy"], kw["image_height"], kw["image_width"], d.shs, sc.sh_degree,
+                                 kw["campos"], False, False)
+    R, color, depth, alpha, sem, radii, geom, binning, img = out
+    dbg = debug_export(geom, binning, img, P, R, kw["image_height"], kw["image_width"])
+    torch.cuda.synchronize()
+    return dict(R=R, color=color.cpu().numpy(), depth=depth.cpu().numpy(), alpha=alpha.cpu().numpy(),
+                radii=radii.cpu().numpy(), **{k: v.cpu().numpy() for k, v in dbg.items()})
+
+
+def test_config0_smoke_10k_at_256(dev):
+    """configs[0] at its stated size: V = 10 000, R = 2 359 552 (about 236 of the 256 tiles per
+    splat), an overdraw stress with thousands of layers per pixel."""
+    sc, cam = hz.smoke_scene(10000, seed=0), hz.smoke_camera(256, 256)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, 0))
+    assert int((o["radii"] > 0).sum()) == 10000 and o["num_rendered"] == 2359552
+    got = _raw_forward(dev, sc, cam)
+    assert got["R"] == o["num_rendered"]
+    np.testing.assert_array_equal(got["radii"], o["radii"])
+    np.testing.assert_array_equal(got["keys_sorted"].view(np.uint64), o["keys_sorted"])
+    np.testing.assert_array_equal(got["point_list"].view(np.uint32), o["point_list"])
+    np.testing.assert_array_equal(got["ranges"].view(np.uint32), o["ranges"])
+    for k in ("color", "depth", "alpha"):
+        assert_image_close(k, got[k], o[k], o["fragile"], max_fragile_frac=0.3)
+    nf = o["fragile"] == 0
+    np.testing.assert_array_equal(got["n_contrib"].view(np.uint32)[nf], o["n_contrib"][nf])
+
+
+@pytest.mark.parametrize("frame", [0, 199])
+def test_config2_full_size_integer_parity(dev, frame):
+    """configs[2] (bench workload: scene-002-like, P = 2 M, seed 2, 1920x1280), first and last pose
+    of the drive: everything integer is bit-exact against the oracle's preprocess + binning; the
+    blend is checked through conservation laws."""
+    sc, cam = hz.street_scene(2_000_000, seed=2), hz.trajectory_camera(frame)
+    got = _raw_forward(dev, sc, cam)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       render=False, **oracle_kwargs(cam, 1))
+    assert got["R"] == o["num_rendered"] == int(o["tiles_touched"].sum())
+    np.testing.assert_array_equal(got["radii"], o["radii"])
+    np.testing.assert_array_equal(got["tiles_touched"].view(np.uint32), o["tiles_touched"])
+    np.testing.assert_array_equal(got["keys_sorted"].view(np.uint64), o["keys_sorted"])
+    np.testing.assert_array_equal(got["point_list"].view(np.uint32), o["point_list"])
+    np.testing.assert_array_equal(got["ranges"].view(np.uint32), o["ranges"])
+    keys = got["keys_sorted"].view(np.uint64)
+    assert (keys[1:] >= keys[:-1]).all()
+    rg = got["ranges"].view(np.uint32).astype(np.int64)
+    assert int((rg[:, 1] - rg[:, 0]).sum()) == got["R"]
+    a = got["alpha"]
+    assert a.min() >= 0.0 and a.max() <= 1.0 + 1e-5
+    lens = np.repeat((rg[:, 1] - rg[:, 0]).reshape(80, 120), 16, 0).repeat(16, 1)
+    assert (got["n_contrib"].astype(np.int64) <= lens).all()
+    assert np.isfinite(got["color"]).all() and np.isfinite(got["depth"]).all()
+    # colour is a convex-ish combination: 0 <= C <= sum(alpha T) * max rgb, depth likewise
+    vis = o["radii"] > 0
+    assert got["color"].max() <= a.max() * float(o["rgb"][vis].max()) + 1e-3
+    assert got["depth"].max() <= float(o["depths"][vis].max()) * (1 + 1e-5)
+
+
+def test_config4_train_full_size(dev):
+    """configs[4]: P = 1 M @1920x1280 forward + backward through harness.render_kernel (train mode),
+    harness.train_loss and harness.densification_stats.  Size-independent properties:
+    finite gradients; culled Gaussians get exactly zero gradient; means2D.grad[:, 2] (sum of
+    |x term| + |y term|, backward.cu:627-628) dominates |grad[:, 0]| + |grad[:, 1]|."""
+    sc = hz.street_scene(1_000_000, seed=149).to(dev)
+    leaves = hz.Scene(*(t.clone().requires_grad_(True) if isinstance(t, torch.Tensor) else t for t in sc))
+    cam = hz.trajectory_camera(5, device=dev)
+    g = torch.Generator().manual_seed(11)
+    gt = torch.rand(3, hz.WAYMO_H, hz.WAYMO_W, generator=g).to(dev)
+    lidar = (torch.rand(1, hz.WAYMO_H, hz.WAYMO_W, generator=g) * 80.0).to(dev)
+    lidar[:, ::2] = 0.0
+    sky = (torch.rand(1, hz.WAYMO_H, hz.WAYMO_W, generator=g) < 0.25).to(dev)
+    pkg = hz.render_kernel(leaves, cam, mode="train")
+    assert pkg["viewspace_points"].requires_grad
+    loss = hz.train_loss(pkg, gt, lidar_depth=lidar, sky_mask=sky)
+    loss.backward()
+    torch.cuda.synchronize()
+    vis = pkg["visibility_filter"]
+    assert 0.3e6 < int(vis.sum()) < 1.0e6
+    g2d = pkg["viewspace_points"].grad
+    assert g2d.shape == (1_000_000, 3)
+    for name, t in (("means2D", g2d), ("means3D", leaves.means3D.grad), ("opacity", leaves.opacity.grad),
+                    ("shs", leaves.shs.grad), ("scales", leaves.scales.grad),
+                    ("rotations", leaves.rotations.grad)):
+        assert torch.isfinite(t).all(), name
+        assert float(t[~vis].abs().max()) == 0.0, name + ": culled Gaussians must get zero gradient"
+        assert float(t[vis].abs().max()) > 0.0, name
+    ax = g2d[:, 0].abs() + g2d[:, 1].abs()
+    assert bool((g2d[:, 2] >= ax * (1 - 1e-4) - 1e-12).all())
+    n_xy, n_abs = hz.densification_stats(pkg["viewspace_points"], vis)
+    assert n_xy.shape == (int(vis.sum()), 1) and bool((n_abs >= 0).all())
+
+
+def test_dl_dcolors_closed_form(dev):
+    """For a loss that is linear in the colour planes with constant weights g_c, the colour
+    gradients of all Gaussians sum to g_c * sum over pixels of out_alpha (each pixel distributes
+    sum_i alpha_i T_i = out_alpha over its contributors): a size-independent check of the blend
+    backward, run on a 200 k street scene at 960x640."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.street_scene(200_000, seed=31).to(dev)
+    cam = hz.trajectory_camera(2, W=960, H=640, device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
+    colors = torch.rand(200_000, 3, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_(True)
+    color, radii, depth, alpha, _ = rast(means3D=sc.means3D, means2D=None, opacities=sc.opacity,
+                                         colors_precomp=colors, scales=sc.scales, rotations=sc.rotations)
+    gc = torch.tensor([0.7, -1.3, 2.1], device=dev)
+    (color * gc[:, None, None]).sum().backward()
+    torch.cuda.synchronize()
+    total_alpha = float(alpha.double().sum())
+    got = colors.grad.double().sum(0).cpu().numpy()
+    ref = gc.double().cpu().numpy() * total_alpha
+    np.testing.assert_allclose(got, ref, rtol=2e-4)
+
+
+def test_render_all_three_calls_and_frame_timer(dev):
+    """Non-lite evaluation path (street_gaussian_renderer.py:13-40): composition + background +
+    objects = three op calls per frame; and render.py's synchronize-bracketed frame timer."""
+    sc = hz.street_scene(120_000, seed=12).to(dev)
+    obj = torch.zeros(120_000, dtype=torch.bool, device=dev)
+    obj[-6000:] = True                       # "the last Gaussians are the actor boxes" 
+    cam = hz.trajectory_camera(1, W=960, H=640, device=dev)
+    res = hz.render_all(sc, cam, obj)
+    for k in ("rgb", "rgb_background", "rgb_object"):
+        assert res[k].shape == (3, 640, 960) and float(res[k].min()) >= 0.0 and float(res[k].max()) <= 1.0
+    # the sub-renders are on white: where nothing was drawn the pixel is exactly 1
+    empty = res["acc_object"][0] == 0
+    assert bool(empty.any()) and bool((res["rgb_object"][:, empty] == 1.0).all())
+    # composition == direct op call on everything (black background, clamped)
+    direct = hz.render_kernel(sc, cam)["rgb"]
+    assert torch.equal(direct, res["rgb"])
+    # accumulated opacity of the parts never exceeds the composition's by more than rounding where
+    # the other part is absent
+    only_bg = (res["acc_object"][0] == 0)
+    assert torch.allclose(res["acc_background"][0][only_bg], res["acc"][0][only_bg], atol=1e-5)
+    stats = hz.time_frames(lambda k: hz.render(sc, hz.trajectory_camera(k, W=960, H=640, device=dev)), 12)
+    assert stats["frames"] == 11 and 0 < stats["median_ms"] <= stats["p95_ms"]
+    # empty model: the op is not called (street_gaussian_renderer.py:131-144)
+    none = hz.render_kernel(hz.scene_subset(sc, torch.zeros_like(obj)), cam, white_background=True)
+    assert float(none["rgb"].min()) == 1.0 and float(none["acc"].max()) == 0.0
+
+
+def _hip_frame_renderer(dev, nframes, Wd=480, Hd=320):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.street_scene(50_000, seed=77).to(dev)
+    tape = tj.make_tape(nframes)
+    rasts = [GaussianRasterizer(GaussianRasterizationSettings(
+        **hz.settings_kwargs(tj.camera_from_tape(e, W=Wd, H=Hd, device=dev), 1))) for e in tape]
+
+    def render(i):
+        with torch.no_grad():
+            return rasts[i](means3D=sc.means3D, means2D=None, opacities=sc.opacity, shs=sc.shs,
+                            scales=sc.scales, rotations=sc.rotations)[0]
+    return render
+
+
+def test_render_sharded_gpu_world1(dev):
+    """configs[3] on one GPU: render_sharded's GPU path (two side streams, frames packed in place
+    into the gather buffer) == per-frame direct renders, byte for byte."""
+    render = _hip_frame_renderer(dev, 8)
+    frames = tj.render_sharded(render, 8, 0, 1, num_streams=2)
+    torch.cuda.synchronize()
+    assert frames.shape == (8, 3, 320, 480) and frames.dtype == torch.uint8 and frames.is_cuda
+    for i in range(8):
+        assert torch.equal(frames[i], tj.pack_u8(render(i)))
+    assert not torch.equal(frames[0], frames[7])
+    one = tj.render_sharded(render, 8, 0, 1, num_streams=1)
+    assert torch.equal(one, frames)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")          # both ranks share the one GPU of the test box
+        torch.cuda.set_device(dev)
+        render = _hip_frame_renderer(dev, 7)
+        # gloo gathers host tensors: the HIP op renders, the uint8 frames are staged through the host
+        frames = tj.render_sharded(lambda i: render(i).cpu(), 7, rank, world, num_streams=1, gather_batch=2)
+        if rank == 0:
+            np.save(out_path, frames.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_render_sharded_two_ranks_one_gpu(dev, tmp_path):
+    """Two processes (gloo rendezvous on 127.0.0.1), both driving the HIP op on the single GPU of
+    the box, ragged shards (4 + 3 frames), batched gathers: rank 0's result == the world-1 result."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    render = _hip_frame_renderer(dev, 7)
+    ref = tj.render_sharded(render, 7, 0, 1, num_streams=2).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_direct_cabi_forward_call(dev):
+    """grpg_forward called straight through ctypes with torch-allocated device pointers (no _C):
+    the C ABI alone is a complete drop-in for Rasterizer::forward."""
+    from gaussianrpg_amd.build import LIB_PATH
+    lib = ctypes.CDLL(LIB_PATH)
+    sc, cam = hz.toy_scene(3000, seed=4, sh_degree=1), hz.trajectory_camera(0, W=200, H=136)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, 1))
+    d = sc.to(dev)
+    P, Hh, Ww = 3000, 136, 200
+    keep = []
+
+    ALLOC = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+    def alloc(nbytes, _user):
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        keep.append(t)
+        return t.data_ptr()
+    cb = ALLOC(alloc)
+    f32 = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    bg = torch.zeros(3, device=dev)
+    view, proj, campos = cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.campos.to(dev)
+    color = torch.empty(3, Hh, Ww, device=dev)
+    depth = torch.empty(1, Hh, Ww, device=dev)
+    alpha = torch.empty(1, Hh, Ww, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    lib.grpg_forward.restype = ctypes.c_int
+    lib.grpg_last_error.restype = ctypes.c_char_p
+    stream = torch.cuda.current_stream().cuda_stream
+    R = lib.grpg_forward(cb, None, cb, None, cb, None, P, 1, 4, 0, f32(bg), Ww, Hh, f32(d.means3D),
+                         f32(d.shs), None, None, f32(d.opacity), f32(d.scales), ctypes.c_float(1.0),
+                         f32(d.rotations), None, f32(view), f32(proj), f32(campos),
+                         ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), 0, f32(color),
+                         f32(depth), f32(alpha), None, ctypes.c_void_p(radii.data_ptr()), 0,
+                         ctypes.c_void_p(stream))
+    assert R >= 0, lib.grpg_last_error()
+    torch.cuda.synchronize()
+    assert R == o["num_rendered"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    assert_image_close("color", color.cpu().numpy(), o["color"], o["fragile"])
+    assert len(keep) == 3      # geometry, image and binning blobs, each requested once (no overflow here)
