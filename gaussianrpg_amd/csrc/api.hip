@@ -357,8 +357,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     uint32_t* tiles_sorted = (uint32_t*)(geom + GL.tiles_sorted);
     const uint32_t* sorted_gid;
     if (fat_sort) {   // drops the culled Gaussians: V pairs remain
-      depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
-                     tiles, tiles_sorted, block_sums);
+      depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V);
       sorted_gid = val_a;
     } else {          // culled keys sort last (tile count 0); V stays P
       const bool in_b = radix_sort_pairs(stream, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true,
@@ -369,8 +368,9 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     STAGE_CHECK("depth sort");
     tm.mark(2);
     uint32_t* emit_win = (uint32_t*)(geom + GL.emit_win);
-    launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, offsets, block_sums, GL.nblocks_scan,
-                        fat_sort, &gh->R, hw->dev_ptr, emit_win, GL.emit_win_cap);
+    launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, fat_sort ? sorted_gid : nullptr, tiles,
+                        offsets, block_sums, GL.nblocks_scan, &gh->R, hw->dev_ptr, emit_win,
+                        GL.emit_win_cap);
     STAGE_CHECK("offsets scan");
     HIP_TRY(hipEventRecord(hw->ev, stream));   // fires when num_rendered sits in the pinned word
 

@@ -96,7 +96,7 @@ struct GeomLayout {
   size_t total;
   size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
-  size_t zero_begin, zero_end;   // region frame_init clears: ds_table + block_sums
+  size_t zero_begin, zero_end;   // region frame_init clears: ds_table
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
 struct BinLayout {
@@ -127,8 +127,8 @@ inline GeomLayout geom_layout(size_t P) {
   L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);   // u32 table or u64 status words
   L.totals = take(4 * RS_MAX_RADIX * 4);
   L.nchunks_ds = (uint32_t)((P + DS_CHUNK - 1) / DS_CHUNK);
-  L.zero_begin = o;
   L.block_sums = take(((size_t)L.nblocks_scan + 1) * 4);
+  L.zero_begin = o;
   L.ds_table = take((size_t)DS_PASSES * (L.nchunks_ds ? L.nchunks_ds : 1) * DS_RADIX * 4);
   L.zero_end = o;
   // owner (depth-sorted Gaussian index) of the first slot of every 2048-slot emit block, written by
@@ -200,15 +200,16 @@ int radix_sort_first_pass_bits(int begin_bit, int end_bit);
 
 // Fat depth sort (sort.hip): result in (key_a, val_a), V visible pairs; see depth_sort_fat.
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
-                    const uint32_t* tiles, uint32_t* tiles_sorted, uint32_t* block_sums);
+                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out);
 
 // offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total_out (device) = sum, also stored
-// to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.
+// to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.  gather_gid != NULL:
+// tiles_sorted is first filled with tiles_by_id[gather_gid[i]].
 void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
-                         const uint32_t* tiles_sorted, uint32_t* offsets, uint32_t* block_sums,
-                         uint32_t nblocks, bool have_block_sums, uint32_t* total_out,
-                         uint32_t* total_host, uint32_t* emit_win, uint32_t emit_win_cap);
+                         uint32_t* tiles_sorted, const uint32_t* gather_gid,
+                         const uint32_t* tiles_by_id, uint32_t* offsets, uint32_t* block_sums,
+                         uint32_t nblocks, uint32_t* total_out, uint32_t* total_host,
+                         uint32_t* emit_win, uint32_t emit_win_cap);
 
 void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, uint32_t R_cap,
                  const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,

@@ -112,7 +112,10 @@ radix_digit_scan_kernel(uint32_t* __restrict__ table, const uint32_t nchunks_cap
 // CBITS > 0: digit width known at compile time (the match-any loop unrolls into straight-line
 // code: one bit test + ballot, one sign-extended bit, two xor, two and per key bit, no branch);
 // CBITS == 0: width taken from `bits_rt`.
-template <int CBITS>
+// ITEMS keys per thread: a workgroup owns ITEMS / 8 consecutive 2048-key chunks of the count
+// table (ITEMS = 16: twice as long output runs per digit; the table keeps its 2048-key columns,
+// the workgroup takes the column of its first chunk as base and ranks all its keys itself).
+template <int CBITS, int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -122,38 +125,42 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                      const uint32_t nchunks, const uint32_t* __restrict__ gather_src,
                      uint32_t* __restrict__ gather_dst) {
   const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
-  if (blockIdx.x * RS_CHUNK >= n) return;
-  __shared__ uint32_t s_cnt[RS_MAX_RADIX * 4];  // [digit][wave]
+  constexpr int CHUNK = RS_THREADS * ITEMS;
+  constexpr int COLS = ITEMS / RS_ITEMS;   // table columns (2048-key chunks) per workgroup
+  if (blockIdx.x * CHUNK >= n) return;
+  // [wave][digit]: in the ranking loop the lanes of a wave index by digit -> distinct LDS banks
+  // ([digit][wave] put every access of a wave on 16 of the 64 banks)
+  __shared__ uint32_t s_cnt[4 * RS_MAX_RADIX];
   __shared__ uint32_t s_gbase[RS_MAX_RADIX];    // global position of local slot 0 of each digit
   __shared__ uint32_t s_wave[4];
-  __shared__ uint32_t s_keys[RS_CHUNK];
-  __shared__ uint32_t s_vals[RS_CHUNK];
+  __shared__ uint32_t s_keys[CHUNK];
+  __shared__ uint32_t s_vals[CHUNK];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bits = CBITS > 0 ? CBITS : bits_rt;
   const uint32_t mask = (1u << bits) - 1u;
   const uint32_t chunk = blockIdx.x;
-  const uint32_t chunk_base = chunk * RS_CHUNK;
-  const uint32_t chunk_n = min((uint32_t)RS_CHUNK, n - chunk_base);
+  const uint32_t chunk_base = chunk * CHUNK;
+  const uint32_t chunk_n = min((uint32_t)CHUNK, n - chunk_base);
 
 #pragma unroll
-  for (int k = 0; k < 4; k++) s_cnt[tid * 4 + k] = 0;
+  for (int k = 0; k < 4; k++) s_cnt[k * RS_MAX_RADIX + tid] = 0;
   __syncthreads();
 
-  uint32_t key[RS_ITEMS], val[RS_ITEMS], rnk[RS_ITEMS];
+  uint32_t key[ITEMS], val[ITEMS], rnk[ITEMS];
   const uint64_t lt = (1ull << lane) - 1ull;
   // all of the wave's loads first (one memory round trip per workgroup instead of RS_ITEMS)
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
-    const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t local = wave * (ITEMS * 64) + i * 64 + lane;
     const uint32_t idx = chunk_base + local;
     const bool valid = local < chunk_n;
     key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
     val[i] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
   }
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
-    const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t local = wave * (ITEMS * 64) + i * 64 + lane;
     const bool valid = local < chunk_n;
     const uint32_t d = (key[i] >> shift) & mask;
     // match-any over the wave: lanes holding the same digit
@@ -167,38 +174,38 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       peers &= ~(bal ^ (((uint64_t)mine << 32) | mine));
     }
     const uint32_t before = (uint32_t)__popcll(peers & lt);
-    const uint32_t prev = valid ? s_cnt[d * 4 + wave] : 0u;
+    const uint32_t prev = valid ? s_cnt[wave * RS_MAX_RADIX + d] : 0u;
     rnk[i] = prev + before;
-    if (valid && before == 0) s_cnt[d * 4 + wave] = prev + (uint32_t)__popcll(peers);
+    if (valid && before == 0) s_cnt[wave * RS_MAX_RADIX + d] = prev + (uint32_t)__popcll(peers);
   }
   __syncthreads();
 
   // Thread d owns digit d: turn per-(digit,wave) counts into local start slots, and compute the
   // global base of the digit for this chunk.
   {
-    const uint32_t c0 = s_cnt[tid * 4 + 0], c1 = s_cnt[tid * 4 + 1], c2 = s_cnt[tid * 4 + 2],
-                   c3 = s_cnt[tid * 4 + 3];
+    const uint32_t c0 = s_cnt[tid], c1 = s_cnt[RS_MAX_RADIX + tid], c2 = s_cnt[2 * RS_MAX_RADIX + tid],
+                   c3 = s_cnt[3 * RS_MAX_RADIX + tid];
     const uint32_t dsum = c0 + c1 + c2 + c3;
     uint32_t tot;
     const uint32_t dstart = block_exclusive_scan_256(dsum, s_wave, &tot);
     const uint32_t gtot = tid <= mask ? totals[tid] : 0u;
     uint32_t tot2;
     const uint32_t gstart = block_exclusive_scan_256(gtot, s_wave, &tot2);
-    s_cnt[tid * 4 + 0] = dstart;
-    s_cnt[tid * 4 + 1] = dstart + c0;
-    s_cnt[tid * 4 + 2] = dstart + c0 + c1;
-    s_cnt[tid * 4 + 3] = dstart + c0 + c1 + c2;
-    const uint32_t tb = tid <= mask ? table[(size_t)tid * nchunks + chunk] : 0u;
+    s_cnt[tid] = dstart;
+    s_cnt[RS_MAX_RADIX + tid] = dstart + c0;
+    s_cnt[2 * RS_MAX_RADIX + tid] = dstart + c0 + c1;
+    s_cnt[3 * RS_MAX_RADIX + tid] = dstart + c0 + c1 + c2;
+    const uint32_t tb = tid <= mask ? table[(size_t)tid * nchunks + chunk * COLS] : 0u;
     s_gbase[tid] = gstart + tb - dstart;  // wraps mod 2^32; only used as base + slot
   }
   __syncthreads();
 
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
-    const uint32_t local = wave * (RS_ITEMS * 64) + i * 64 + lane;
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t local = wave * (ITEMS * 64) + i * 64 + lane;
     if (local < chunk_n) {
       const uint32_t d = (key[i] >> shift) & mask;
-      const uint32_t slot = s_cnt[d * 4 + wave] + rnk[i];
+      const uint32_t slot = s_cnt[wave * RS_MAX_RADIX + d] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
     }
@@ -208,16 +215,16 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   // last pass of the depth sort: also emit the per-Gaussian tile count in sorted order, so the
   // offsets scan streams a contiguous array instead of gathering tiles[gid[i]].  The gather loads
   // are issued for all of the thread's items before the first store (one round trip, not 8).
-  uint32_t gsrc[RS_ITEMS];
+  uint32_t gsrc[ITEMS];
   if (gather_src) {
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
+    for (int i = 0; i < ITEMS; i++) {
       const uint32_t j = i * RS_THREADS + tid;
       gsrc[i] = j < chunk_n ? gather_src[s_vals[j]] : 0u;
     }
   }
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
+  for (int i = 0; i < ITEMS; i++) {
     const uint32_t j = i * RS_THREADS + tid;
     if (j < chunk_n) {
       const uint32_t k = s_keys[j];
@@ -240,9 +247,11 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 // table 0 behind; culled Gaussians (CULLED_KEY) are dropped right there, so from pass 1 on the
 // arrays hold only the V visible ones.  V = sum of table 0, published by chunk 0 of pass 0.
 // The tables of passes 1-3 come from depth_hist_kernel, launched after the previous scatter.
-// The last pass also writes the per-Gaussian tile counts in sorted order and accumulates the
-// per-2048 block sums of the offsets scan (one atomic per wave when the wave's outputs fall in one
-// block, which they nearly always do: a wave stores a run of consecutive positions).
+// Measured dead ends: accumulating the offsets scan's per-2048 block sums in the last pass with one
+// global atomic per wave (23 k agent-scope atomics on ~45 cache lines: 175 us; the separate reduce
+// launch costs 5), and gathering the tile counts into sorted order in the last pass (one
+// 1024-thread workgroup per CU keeps too few random loads in flight: +38 us; the reduce launch of
+// the offsets scan does it instead).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, const uint32_t lane) {
 #pragma unroll
@@ -251,25 +260,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, const uint32_
     if (lane >= (uint32_t)d) v += t;
   }
   return v;
-}
-
-// ctr[idx] += v for every `active` lane: one atomic per wave when all active lanes name the same
-// counter, per-lane atomics otherwise.  Must be called by all lanes of the wave.
-__device__ __forceinline__ void wave_agg_add(uint32_t* __restrict__ ctr, const uint32_t idx,
-                                             const uint32_t v, const bool active) {
-  const uint64_t am = __builtin_amdgcn_ballot_w64(active);
-  if (am == 0ull) return;
-  const int first = __ffsll((unsigned long long)am) - 1;
-  const uint32_t f = (uint32_t)__shfl((int)idx, first, 64);
-  const uint64_t diff = __builtin_amdgcn_ballot_w64(active && idx != f);
-  if (diff == 0ull) {
-    uint32_t sum = active ? v : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
-    if ((int)(threadIdx.x & 63) == first) atomicAdd(&ctr[f], sum);
-  } else if (active) {
-    atomicAdd(&ctr[idx], v);
-  }
 }
 
 __global__ void __launch_bounds__(DS_THREADS)
@@ -301,40 +291,67 @@ __global__ void __launch_bounds__(DS_THREADS)
 depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                      const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][256] */,
-                     const uint32_t nchunks, uint32_t* __restrict__ V_out,
-                     const uint32_t* __restrict__ gather_src, uint32_t* __restrict__ gather_dst,
-                     uint32_t* __restrict__ block_sums) {
+                     const uint32_t nchunks, uint32_t* __restrict__ V_out) {
   __shared__ uint32_t s_keys[DS_CHUNK];
   __shared__ uint32_t s_vals[DS_CHUNK];
-  __shared__ uint32_t s_cnt[DS_RADIX * DS_WAVES];   // [digit][wave]
+  __shared__ uint32_t s_cnt[DS_WAVES * DS_RADIX];   // [wave][digit]: bank-conflict-free ranking
   __shared__ uint32_t s_gbase[DS_RADIX];
-  __shared__ uint32_t s_pex[4][DS_RADIX];
-  __shared__ uint32_t s_ptot[4][DS_RADIX];
   __shared__ uint32_t s_w[8];
+  // per-wave partial column sums of the table sweep live in s_keys until the keys are staged
+  uint32_t* s_pex = s_keys;                          // [DS_WAVES][DS_RADIX]
+  uint32_t* s_ptot = s_keys + DS_WAVES * DS_RADIX;   // [DS_WAVES][DS_RADIX]
+  static_assert(2 * DS_WAVES * DS_RADIX <= DS_CHUNK, "sweep partials must fit in s_keys");
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t chunk = blockIdx.x;
   constexpr int shift = 8 * PASS;
 
+  // ---- the chunk's own loads go out first: they overlap the table sweep below.  Pass 0 moves
+  // P keys; later passes move the V visible ones (published by chunk 0 of pass 0). ----
+  const uint32_t n_in = PASS == 0 ? P : *V_out;
+  const uint32_t chunk_base = chunk * DS_CHUNK;
+  const uint32_t chunk_n = chunk_base < n_in ? min((uint32_t)DS_CHUNK, n_in - chunk_base) : 0u;
+  uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < DS_ITEMS; i++) {
+    const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
+    const uint32_t idx = chunk_base + local;
+    const bool inb = local < chunk_n;
+    key[i] = inb ? keys_in[idx] : CULLED_KEY;
+    val[i] = PASS == 0 ? idx : (inb ? vals_in[idx] : 0u);
+  }
+
   // ---- sweep the count table: per digit, sum over earlier chunks and over all chunks ----
+  // A wave reads whole 1 KB rows (lane l: digits 4l..4l+3, one 16-byte load); wave w owns rows
+  // w, w+16, ...; 8 rows are in flight per wave, so 245 rows cost two memory round trips.
   {
-    const uint32_t d = tid & (DS_RADIX - 1), g = tid >> 8;   // 4 row groups
-    uint32_t ex = 0, tot = 0;
-    for (uint32_t r = g; r < nchunks; r += 4) {
-      const uint32_t v = table[(size_t)r * DS_RADIX + d];
-      tot += v;
-      ex += r < chunk ? v : 0u;
+    const uint4* t4 = reinterpret_cast<const uint4*>(table);
+    uint4 ex = make_uint4(0u, 0u, 0u, 0u), tot = ex;
+    constexpr int SW = 8;
+    for (uint32_t r0 = wave; r0 < nchunks; r0 += DS_WAVES * SW) {
+      uint4 v[SW];
+#pragma unroll
+      for (int k = 0; k < SW; k++) {
+        const uint32_t r = r0 + (uint32_t)k * DS_WAVES;
+        v[k] = r < nchunks ? t4[(size_t)r * (DS_RADIX / 4) + lane] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < SW; k++) {
+        const uint32_t r = r0 + (uint32_t)k * DS_WAVES;
+        tot.x += v[k].x; tot.y += v[k].y; tot.z += v[k].z; tot.w += v[k].w;
+        if (r < chunk) { ex.x += v[k].x; ex.y += v[k].y; ex.z += v[k].z; ex.w += v[k].w; }
+      }
     }
-    s_pex[g][d] = ex;
-    s_ptot[g][d] = tot;
+    reinterpret_cast<uint4*>(s_pex + wave * DS_RADIX)[lane] = ex;
+    reinterpret_cast<uint4*>(s_ptot + wave * DS_RADIX)[lane] = tot;
   }
 #pragma unroll
   for (int k = 0; k < (DS_RADIX * DS_WAVES) / DS_THREADS; k++) s_cnt[k * DS_THREADS + tid] = 0;
   __syncthreads();
   uint32_t dex = 0, dtot = 0, inc = 0;
   if (tid < DS_RADIX) {
-    dex = s_pex[0][tid] + s_pex[1][tid] + s_pex[2][tid] + s_pex[3][tid];
-    dtot = s_ptot[0][tid] + s_ptot[1][tid] + s_ptot[2][tid] + s_ptot[3][tid];
+#pragma unroll
+    for (int w = 0; w < DS_WAVES; w++) { dex += s_pex[w * DS_RADIX + tid]; dtot += s_ptot[w * DS_RADIX + tid]; }
     inc = wave_inclusive_sum(dtot, lane);
     if (lane == 63) s_w[wave] = inc;
   }
@@ -347,22 +364,10 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     s_gbase[tid] = before + inc - dtot + dex;   // first output position of (digit, this chunk)
   }
   if (PASS == 0 && chunk == 0 && tid == 0) *V_out = n_all;
-  const uint32_t n_in = PASS == 0 ? P : n_all;
-  const uint32_t chunk_base = chunk * DS_CHUNK;
-  if (chunk_base >= n_in) return;   // whole workgroup
-  const uint32_t chunk_n = min((uint32_t)DS_CHUNK, n_in - chunk_base);
+  if (chunk_n == 0u) return;   // whole workgroup (a chunk beyond the data)
 
-  // ---- load + rank (wave w owns the 512 consecutive keys [512 w, 512 w + 512)) ----
-  uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS];
+  // ---- rank (wave w owns the 512 consecutive keys [512 w, 512 w + 512)) ----
   const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int i = 0; i < DS_ITEMS; i++) {
-    const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
-    const uint32_t idx = chunk_base + local;
-    const bool inb = local < chunk_n;
-    key[i] = inb ? keys_in[idx] : CULLED_KEY;
-    val[i] = PASS == 0 ? idx : (inb ? vals_in[idx] : 0u);
-  }
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
     const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
@@ -378,9 +383,9 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       peers &= ~(bal ^ (((uint64_t)mine << 32) | mine));
     }
     const uint32_t before = (uint32_t)__popcll(peers & lt);
-    const uint32_t prev = valid ? s_cnt[d * DS_WAVES + wave] : 0u;
+    const uint32_t prev = valid ? s_cnt[wave * DS_RADIX + d] : 0u;
     rnk[i] = valid ? prev + before : 0xFFFFFFFFu;
-    if (valid && before == 0) s_cnt[d * DS_WAVES + wave] = prev + (uint32_t)__popcll(peers);
+    if (valid && before == 0) s_cnt[wave * DS_RADIX + d] = prev + (uint32_t)__popcll(peers);
   }
   __syncthreads();
 
@@ -388,7 +393,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   uint32_t c[DS_WAVES], dsum = 0, inc2 = 0;
   if (tid < DS_RADIX) {
 #pragma unroll
-    for (int w = 0; w < DS_WAVES; w++) { c[w] = s_cnt[tid * DS_WAVES + w]; dsum += c[w]; }
+    for (int w = 0; w < DS_WAVES; w++) { c[w] = s_cnt[w * DS_RADIX + tid]; dsum += c[w]; }
     inc2 = wave_inclusive_sum(dsum, lane);
     if (lane == 63) s_w[4 + wave] = inc2;
   }
@@ -401,7 +406,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const uint32_t dstart = before + inc2 - dsum;
     uint32_t run = dstart;
 #pragma unroll
-    for (int w = 0; w < DS_WAVES; w++) { s_cnt[tid * DS_WAVES + w] = run; run += c[w]; }
+    for (int w = 0; w < DS_WAVES; w++) { s_cnt[w * DS_RADIX + tid] = run; run += c[w]; }
     s_gbase[tid] -= dstart;   // wraps mod 2^32; only used as base + local slot
   }
   __syncthreads();
@@ -409,7 +414,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   for (int i = 0; i < DS_ITEMS; i++) {
     if (rnk[i] != 0xFFFFFFFFu) {
       const uint32_t d = (key[i] >> shift) & (DS_RADIX - 1);
-      const uint32_t slot = s_cnt[d * DS_WAVES + wave] + rnk[i];
+      const uint32_t slot = s_cnt[wave * DS_RADIX + d] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
     }
@@ -417,42 +422,29 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   __syncthreads();
 
   // ---- coalesced run writes ----
-  uint32_t gsrc[DS_ITEMS];
-  if (PASS == DS_PASSES - 1) {   // tile counts in sorted order: all gathers first, then the stores
-#pragma unroll
-    for (int i = 0; i < DS_ITEMS; i++) {
-      const uint32_t j = i * DS_THREADS + tid;
-      gsrc[i] = j < nvalid ? gather_src[s_vals[j]] : 0u;
-    }
-  }
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
     const uint32_t j = i * DS_THREADS + tid;
-    const bool on = j < nvalid;
-    uint32_t g = 0;
-    if (on) {
+    if (j < nvalid) {
       const uint32_t k = s_keys[j];
-      g = s_gbase[(k >> shift) & (DS_RADIX - 1)] + j;
+      const uint32_t g = s_gbase[(k >> shift) & (DS_RADIX - 1)] + j;
       keys_out[g] = k;
       vals_out[g] = s_vals[j];
-      if (PASS == DS_PASSES - 1) gather_dst[g] = gsrc[i];
     }
-    if (PASS == DS_PASSES - 1) wave_agg_add(block_sums, g / SC_CHUNK, gsrc[i], on);
   }
 }
 
 // Depth sort of the P (key, id) pairs; ids are implicit in pass 0.  Result: (key_a, val_a) hold
-// the V visible pairs in (depth_bits, id) order, tiles_sorted their tile counts, block_sums the
-// per-SC_CHUNK sums of tiles_sorted, *V_out = V.  ds_table must be zero except for the rows of
-// pass 0 (preprocess).  7 launches.
+// the V visible pairs in (depth_bits, id) order, *V_out = V (the per-Gaussian tile counts are
+// brought into sorted order by the offsets scan's reduce launch).  ds_table must be zero except
+// for the rows of pass 0 (preprocess).  7 launches.
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
-                    const uint32_t* tiles, uint32_t* tiles_sorted, uint32_t* block_sums) {
+                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out) {
   if (P == 0) return;
   const size_t tsz = (size_t)nchunks * DS_RADIX;
 #define DS_SCATTER(PASS, KI, VI, KO, VO)                                                        \
   depth_scatter_kernel<PASS><<<nchunks, DS_THREADS, 0, s>>>(KI, VI, KO, VO, P, ds_table + PASS * tsz, \
-                                                            nchunks, V_out, tiles, tiles_sorted, block_sums)
+                                                            nchunks, V_out)
   DS_SCATTER(0, key_a, nullptr, key_b, val_b);
   depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 8, ds_table + 1 * tsz);
   DS_SCATTER(1, key_b, val_b, key_a, val_a);
@@ -462,6 +454,8 @@ void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a,
   DS_SCATTER(3, key_b, val_b, key_a, val_a);
 #undef DS_SCATTER
 }
+
+int radix_pass_bits(int begin_bit, int end_bit, int p);
 
 // Classic passes.  n = host-side upper bound (sizes the grids), n_dev = device-side element count
 // (may be NULL: n is exact).  have_hist0: the caller already filled table[digit][chunk] for the
@@ -478,8 +472,7 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t
   const int passes = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
   int shift = begin_bit;
   for (int p = 0; p < passes; p++) {
-    // spread the bits evenly over the passes (e.g. 14 bits -> 7 + 7)
-    const int bits = (end_bit - shift + (passes - p) - 1) / (passes - p);
+    const int bits = radix_pass_bits(begin_bit, end_bit, p);
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t* kin = in_b ? key_b : key_a;
     uint32_t* vin = in_b ? val_b : val_a;
@@ -488,13 +481,17 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t
     if (!(p == 0 && have_hist0))
       radix_hist_kernel<<<nchunks, RS_THREADS, 0, s>>>(kin, n, n_dev, shift, mask, table, nchunks);
     radix_digit_scan_kernel<<<1u << bits, 256, 0, s>>>(table, nchunks, n, n_dev, totals);
-#define RS_SCATTER(CB)                                                                        \
-  radix_scatter_kernel<CB><<<nchunks, RS_THREADS, 0, s>>>(                                    \
+#define RS_SCATTER(CB, IT)                                                                    \
+  radix_scatter_kernel<CB, IT><<<(nchunks + (IT / RS_ITEMS) - 1) / (IT / RS_ITEMS), RS_THREADS, 0, s>>>( \
       kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, n_dev, shift, bits, table,   \
       totals, nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst)
-    if (bits == 8) RS_SCATTER(8);        // depth sort
-    else if (bits == 7) RS_SCATTER(7);   // tile partition of a 1920x1280 frame (14 bits)
-    else RS_SCATTER(0);
+    // GRPG_RS_WIDE=m (experiment): bit p of m set = pass p of a 7-bit tile partition ranks 4096 keys
+    // per workgroup (16 per thread)
+    static const int wide = [] { const char* e = getenv("GRPG_RS_WIDE"); return e ? atoi(e) : 0; }();
+    if (bits == 8) RS_SCATTER(8, 8);        // depth sort
+    else if (bits == 7 && ((wide >> p) & 1)) RS_SCATTER(7, 16);
+    else if (bits == 7) RS_SCATTER(7, 8);   // tile partition of a 1920x1280 frame (14 bits)
+    else RS_SCATTER(0, 8);
 #undef RS_SCATTER
     in_b = !in_b;
     shift += bits;
@@ -506,27 +503,71 @@ int radix_sort_num_passes(int begin_bit, int end_bit) {
   const int nbits = end_bit - begin_bit;
   return nbits <= 0 ? 0 : (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
 }
-int radix_sort_first_pass_bits(int begin_bit, int end_bit) {
+// Digit width of pass p: the bits are spread evenly over the passes (14 bits -> 7 + 7).
+// GRPG_RADIX_FIRST_BITS=b (experiment): a two-pass sort takes b bits first and the rest second
+// (a narrower first digit on unordered input scatters longer runs).
+int radix_pass_bits(int begin_bit, int end_bit, int p) {
   const int passes = radix_sort_num_passes(begin_bit, end_bit);
-  return passes == 0 ? 0 : (end_bit - begin_bit + passes - 1) / passes;
+  const int nbits = end_bit - begin_bit;
+  static const int first = [] { const char* e = getenv("GRPG_RADIX_FIRST_BITS"); return e ? atoi(e) : 0; }();
+  if (passes == 2 && first > 0 && first < nbits && nbits - first <= RS_MAX_BITS && first <= RS_MAX_BITS)
+    return p == 0 ? first : nbits - first;
+  int shift = 0;
+  int bits = 0;
+  for (int q = 0; q <= p; q++) {
+    bits = (nbits - shift + (passes - q) - 1) / (passes - q);
+    shift += bits;
+  }
+  return bits;
+}
+int radix_sort_first_pass_bits(int begin_bit, int end_bit) {
+  return radix_sort_num_passes(begin_bit, end_bit) == 0 ? 0 : radix_pass_bits(begin_bit, end_bit, 0);
 }
 
 // ------------------------------------------------------------------------------------------
 // Exclusive scan of the per-Gaussian instance counts in depth-sorted order (written contiguously
 // by the last depth-sort pass) -> offsets[i]; replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:280).
-// The per-workgroup sums arrive from the fat depth sort (one launch here: the down-sweep, which
-// recomputes the spine) or from scan_reduce_kernel (classic depth sort: two launches).
+// Two launches: per-workgroup reduce, per-workgroup down-sweep (which recomputes the spine).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SC_THREADS)
-scan_reduce_kernel(const uint32_t n, const uint32_t* __restrict__ tiles,
-                   uint32_t* __restrict__ block_sums) {
+scan_reduce_kernel(const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
+                   const uint32_t* __restrict__ tiles, uint32_t* __restrict__ block_sums,
+                   const uint32_t* __restrict__ gid, const uint32_t* __restrict__ tiles_by_id,
+                   uint32_t* __restrict__ tiles_out) {
   __shared__ uint32_t s_wave[4];
+  const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
   const uint32_t base = blockIdx.x * SC_CHUNK;
+  if (base >= n) {   // the down-sweep sums all nblocks entries
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = 0u;
+    return;
+  }
   uint32_t v[SC_ITEMS], s = 0;   // all loads in flight together
+  if (gid != nullptr) {
+    // fat depth sort: the tile counts are still in id order.  Gather them here (this launch has
+    // several times the memory parallelism of the sort's 1024-thread workgroups) and leave them
+    // behind in sorted order for the down-sweep.
+    uint32_t g[SC_ITEMS];
 #pragma unroll
-  for (int k = 0; k < SC_ITEMS; k++) {
-    const uint32_t i = base + k * SC_THREADS + threadIdx.x;
-    v[k] = i < n ? tiles[i] : 0u;
+    for (int k = 0; k < SC_ITEMS; k++) {
+      const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+      g[k] = i < n ? gid[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+      const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+      v[k] = i < n ? tiles_by_id[g[k]] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+      const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+      if (i < n) tiles_out[i] = v[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+      const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+      v[k] = i < n ? tiles[i] : 0u;
+    }
   }
 #pragma unroll
   for (int k = 0; k < SC_ITEMS; k++) s += v[k];
@@ -603,11 +644,13 @@ scan_down_kernel(const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
 }
 
 void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
-                         const uint32_t* tiles_sorted, uint32_t* offsets, uint32_t* block_sums,
-                         uint32_t nblocks, bool have_block_sums, uint32_t* total_out,
-                         uint32_t* total_host, uint32_t* emit_win, uint32_t emit_win_cap) {
+                         uint32_t* tiles_sorted, const uint32_t* gather_gid,
+                         const uint32_t* tiles_by_id, uint32_t* offsets, uint32_t* block_sums,
+                         uint32_t nblocks, uint32_t* total_out, uint32_t* total_host,
+                         uint32_t* emit_win, uint32_t emit_win_cap) {
   if (n == 0) return;
-  if (!have_block_sums) scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, tiles_sorted, block_sums);
+  scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, n_dev, tiles_sorted, block_sums, gather_gid,
+                                                     tiles_by_id, tiles_sorted);
   scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, n_dev, tiles_sorted, block_sums, nblocks, offsets,
                                                    total_out, total_host, emit_win, emit_win_cap);
 }
