@@ -260,17 +260,26 @@ int grpg_reset_capacity_hints(void) {
   return GRPG_OK;
 }
 
-int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+}  // extern "C"
+
+namespace {
+
+// Pinned staging for the composed forward's segment table (thread-local; the frame's one host wait
+// guarantees the previous upload has been consumed before the buffer is reused).
+thread_local SegmentDev* g_seg_staging = nullptr;
+
+// Shared body of grpg_forward (segs == NULL: flat input tensors) and grpg_forward_composed (segs:
+// per-model raw parameters, P = sum of their counts, the flat pointers are NULL).
+int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
                  void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D,
                  int M, int S, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* semantics, const float* opacities, const float* scales,
                  float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                 float tan_fovx, float tan_fovy, float* out_color,
                  float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
-                 void* hip_stream) {
-  (void)prefiltered;  // reference: __trap() on a culled point when set; always False in practice
+                 void* hip_stream, const grpg_model_segment* segs, int nseg) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
@@ -280,7 +289,7 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth || !out_alpha)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL camera/background/output pointer");
   if ((unsigned)P > ID_MASK) return fail(GRPG_ERR_INVALID_ARGUMENT, "P must be < 2^28");
-  if (P > 0) {
+  if (P > 0 && segs == nullptr) {
     if (!means3D || !opacities) return fail(GRPG_ERR_INVALID_ARGUMENT, "means3D/opacities NULL");
     if (!cov3D_precomp && (!scales || !rotations))
       return fail(GRPG_ERR_INVALID_ARGUMENT, "need scales+rotations or cov3D_precomp");
@@ -348,9 +357,34 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
                       (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
                       geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
-    launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                      cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles,
-                      fat_sort ? ds_table : nullptr);
+    if (segs == nullptr) {
+      launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                        cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles,
+                        fat_sort ? ds_table : nullptr);
+    } else {
+      // segment table: host structs -> pinned staging -> the geometry blob (asynchronous copy)
+      if (!g_seg_staging)
+        HIP_TRY(hipHostMalloc((void**)&g_seg_staging, sizeof(SegmentDev) * MAX_SEGMENTS, hipHostMallocDefault));
+      uint32_t start = 0;
+      for (int i = 0; i < nseg; i++) {
+        SegmentDev& d = g_seg_staging[i];
+        const grpg_model_segment& g = segs[i];
+        d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
+        d.fdc = g.features_dc; d.frest = g.features_rest;
+        d.start = start; d.count = (uint32_t)g.count;
+        d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
+        for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];
+        for (int k = 0; k < 3; k++) d.trans[k] = g.obj_trans[k];
+        d.pad0 = 0.f;
+        for (int k = 0; k < MAX_FOURIER; k++) d.idft[k] = g.idft[k];
+        start += (uint32_t)g.count;
+      }
+      SegmentDev* seg_dev = (SegmentDev*)(geom + GL.seg_table);
+      HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)nseg,
+                             hipMemcpyHostToDevice, stream));
+      launch_preprocess_composed(stream, P, D, M, seg_dev, nseg, scale_modifier, cam, radii_int, rec_w,
+                                 key_a, tiles, fat_sort ? ds_table : nullptr);
+    }
     STAGE_CHECK("preprocess");
     tm.mark(1);
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key.
@@ -458,6 +492,108 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                       (uint32_t)S, ranges, T, work, geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
   }
   return (int)R;
+}
+
+int check_segments(const grpg_model_segment* segs, int nseg, int M, long long* P_out) {
+  if (!segs || nseg <= 0 || nseg > GRPG_MAX_SEGMENTS)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "need 1..GRPG_MAX_SEGMENTS segments");
+  long long P = 0;
+  for (int i = 0; i < nseg; i++) {
+    const grpg_model_segment& g = segs[i];
+    if (g.count <= 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "segment with count <= 0");
+    if (!g.xyz || !g.scaling || !g.rotation || !g.opacity || !g.features_dc || (M > 1 && !g.features_rest))
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "segment with a NULL parameter array");
+    if (g.fourier_dim < 1 || g.fourier_dim > GRPG_MAX_FOURIER)
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "fourier_dim must be in 1..GRPG_MAX_FOURIER");
+    P += g.count;
+  }
+  if (P > (long long)ID_MASK) return fail(GRPG_ERR_INVALID_ARGUMENT, "P must be < 2^28");
+  *P_out = P;
+  return GRPG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                 void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D,
+                 int M, int S, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* semantics, const float* opacities, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                 float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
+                 void* hip_stream) {
+  (void)prefiltered;  // reference: __trap() on a culled point when set; always False in practice
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                      image_user, P, D, M, S, background, width, height, means3D, shs, colors_precomp,
+                      semantics, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                      viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth,
+                      out_alpha, out_semantic, radii, debug, hip_stream, nullptr, 0);
+}
+
+int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                          grpg_alloc_fn binning_alloc, void* binning_user,
+                          grpg_alloc_fn image_alloc, void* image_user,
+                          const grpg_model_segment* segments, int num_segments, int D, int M,
+                          const float* background, int width, int height, float scale_modifier,
+                          const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                          float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
+                          float* out_alpha, int* radii, int debug, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  long long P = 0;
+  if (int rc = check_segments(segments, num_segments, M, &P)) return rc;
+  if (M < 1 || M > 16 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M <= 16");
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                      image_user, (int)P, D, M, 0, background, width, height, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
+                      projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
+                      radii, debug, hip_stream, segments, num_segments);
+}
+
+int grpg_compose(const grpg_model_segment* segments, int num_segments, int M, float* means3D,
+                 float* scales, float* rotations, float* opacities, float* shs, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  long long P = 0;
+  if (int rc = check_segments(segments, num_segments, M, &P)) return rc;
+  if (M < 1 || M > 16) return fail(GRPG_ERR_INVALID_ARGUMENT, "M must be in 1..16");
+  if (!means3D || !scales || !rotations || !opacities || !shs)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL output pointer");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  // standalone call: the table travels through a temporary device buffer (stream-ordered free)
+  std::vector<SegmentDev> host((size_t)num_segments);
+  uint32_t start = 0;
+  for (int i = 0; i < num_segments; i++) {
+    SegmentDev& d = host[(size_t)i];
+    const grpg_model_segment& g = segments[i];
+    d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
+    d.fdc = g.features_dc; d.frest = g.features_rest;
+    d.start = start; d.count = (uint32_t)g.count;
+    d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
+    for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];
+    for (int k = 0; k < 3; k++) d.trans[k] = g.obj_trans[k];
+    d.pad0 = 0.f;
+    for (int k = 0; k < MAX_FOURIER; k++) d.idft[k] = g.idft[k];
+    start += (uint32_t)g.count;
+  }
+  SegmentDev* dev_tab = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev_tab, sizeof(SegmentDev) * host.size()));
+  hipError_t e = hipMemcpyAsync(dev_tab, host.data(), sizeof(SegmentDev) * host.size(),
+                                hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);   // pageable source: copy must finish before `host` dies
+  if (e == hipSuccess) {
+    launch_compose(stream, (int)P, M, dev_tab, num_segments, means3D, scales, rotations, opacities, shs);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  (void)hipFree(dev_tab);
+  if (e != hipSuccess) return fail(GRPG_ERR_HIP, std::string("grpg_compose: ") + hipGetErrorString(e));
+  return GRPG_OK;
 }
 
 int grpg_backward(int P, int D, int M, int R, int S, const float* background, int width,

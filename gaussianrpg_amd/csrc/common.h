@@ -92,10 +92,30 @@ constexpr int DS_PASSES = 4;
 constexpr uint32_t DS_MAX_CHUNKS = 512;           // beyond (P > 4 M) the table sweep per workgroup grows
                                                   // quadratically: classic three-kernel passes instead
 
+// One model of a composed scene as the kernels see it (device copy of grpg_model_segment).
+constexpr int MAX_FOURIER = 8;
+constexpr int MAX_SEGMENTS = 1024;
+struct SegmentDev {
+  const float* xyz;
+  const float* scaling;
+  const float* rotation;
+  const float* opacity;
+  const float* fdc;
+  const float* frest;
+  uint32_t start, count;     // index range [start, start + count) in concatenation order
+  int fourier_dim, rigid;
+  float rot[4];
+  float trans[3];
+  float pad0;
+  float idft[MAX_FOURIER];
+};
+static_assert(sizeof(SegmentDev) % 16 == 0, "segment table entries are read as 16-byte pieces");
+
 struct GeomLayout {
   size_t total;
   size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
+  size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
   size_t zero_begin, zero_end;   // region frame_init clears: ds_table
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
@@ -135,6 +155,7 @@ inline GeomLayout geom_layout(size_t P) {
   // the offsets scan; blocks beyond the cap (R > 256 P, pathological) fall back to a binary search
   L.emit_win_cap = (uint32_t)(P / 8 + 1024);
   L.emit_win = take(((size_t)L.emit_win_cap + 2) * 4);
+  L.seg_table = take((size_t)MAX_SEGMENTS * sizeof(SegmentDev));
   L.total = o;
   return L;
 }
@@ -178,6 +199,12 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles,
                        uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */);
+// Composed variants (preprocess.hip): raw per-model parameters + actor poses instead of flat tensors.
+void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
+                                float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
+                                uint32_t* depth_key, uint32_t* tiles, uint32_t* ds_table0);
+void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
+                    float* scales, float* rotations, float* opacities, float* shs);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations,
                            const float* cov3D_precomp, const CameraArgs& cam, int* radii,

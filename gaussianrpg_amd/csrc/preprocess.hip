@@ -36,7 +36,8 @@ __device__ __forceinline__ bool project_and_bound(const int idx, const float mx,
                                                   const int H, const int gx, const int gy,
                                                   const float tan_fovx, const float tan_fovy,
                                                   const float focal_x, const float focal_y,
-                                                  Projected& o) {
+                                                  Projected& o, const bool q_given = false,
+                                                  const float4 q_val = make_float4(1.f, 0.f, 0.f, 0.f)) {
   // in_frustum, auxiliary.h:139-164
   const float hx = proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12];
   const float hy = proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13];
@@ -49,7 +50,7 @@ __device__ __forceinline__ bool project_and_bound(const int idx, const float mx,
 #pragma unroll
     for (int i = 0; i < 6; i++) o.cov3d[i] = cov3D_precomp[6 * idx + i];
   } else {
-    const float4 q = load_quat(rotations, idx);
+    const float4 q = q_given ? q_val : load_quat(rotations, idx);
     cov3d_from_scale_rot(s0, s1, s2, scale_modifier, q, o.cov3d);
   }
   Cov2D cv;
@@ -257,6 +258,214 @@ mark_visible_kernel(const int P, const float* __restrict__ means3D,
   const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
   const float vz = view[2] * mx + view[6] * my + view[10] * mz + view[14];
   present[idx] = (vz <= 0.2f) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused scene-graph composition.  compose_one() restates what the
+// reference's properties compute in PyTorch for one Gaussian of one model:
+//   get_scaling  = exp(_scaling)                         lib/models/gaussian_model.py:224-226
+//   get_rotation = F.normalize(_rotation)                 :228-230  (x / max(|x|, 1e-12))
+//   get_opacity  = sigmoid(_opacity)                      :248-250
+//   actor means  = quaternion_to_matrix(obj_rots) x + obj_trans
+//                                                        lib/models/street_gaussian_model.py:341-365,
+//                                                        lib/utils/general_utils.py:125-146
+//   actor rots   = F.normalize(quaternion_raw_multiply(obj_rots, get_rotation))
+//                                                        street_gaussian_model.py:318-336,
+//                                                        general_utils.py:220-238
+//   actor colour = cat(sum_c _features_dc[:, c] * IDFT(time)[c], _features_rest)
+//                                                        lib/models/gaussian_model_actor.py:73-82
+// (the training-time flip augmentation, street_gaussian_model.py:286-293, is not part of
+// evaluation: flip_prob applies in train mode only).  One rounding per operation, no contraction:
+// grpg_compose and grpg_forward_composed see bit-identical values.
+// ------------------------------------------------------------------------------------------
+struct Activated {
+  float mx, my, mz, s0, s1, s2, opacity;
+  float4 q;
+  float dc[3];
+};
+
+__device__ __forceinline__ const SegmentDev* find_segment(const SegmentDev* __restrict__ segs,
+                                                          const int nseg, const uint32_t idx) {
+  int lo = 0, hi = nseg - 1;   // last segment with start <= idx (segments are non-empty)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].start <= idx) lo = mid; else hi = mid - 1;
+  }
+  return segs + lo;
+}
+
+__device__ __forceinline__ Activated compose_one(const SegmentDev& sg, const uint32_t j) {
+  Activated a;
+  const float x = sg.xyz[3 * j], y = sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
+  a.s0 = expf(sg.scaling[3 * j]);
+  a.s1 = expf(sg.scaling[3 * j + 1]);
+  a.s2 = expf(sg.scaling[3 * j + 2]);
+  a.opacity = 1.0f / (1.0f + expf(-sg.opacity[j]));
+  const float4 rq = load_quat(sg.rotation, (int)j);
+  const float rn = fmaxf(sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w), 1e-12f);
+  const float4 ql = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+  if (sg.rigid) {
+    // quaternion_to_matrix normalises obj_rots first (general_utils.py:126-128)
+    const float on = sqrtf(sg.rot[0] * sg.rot[0] + sg.rot[1] * sg.rot[1] + sg.rot[2] * sg.rot[2] +
+                           sg.rot[3] * sg.rot[3]);
+    const float r = sg.rot[0] / on, qx = sg.rot[1] / on, qy = sg.rot[2] / on, qz = sg.rot[3] / on;
+    const float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - r * qz), R02 = 2.f * (qx * qz + r * qy);
+    const float R10 = 2.f * (qx * qy + r * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - r * qx);
+    const float R20 = 2.f * (qx * qz - r * qy), R21 = 2.f * (qy * qz + r * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
+    a.mx = (R00 * x + R01 * y + R02 * z) + sg.trans[0];
+    a.my = (R10 * x + R11 * y + R12 * z) + sg.trans[1];
+    a.mz = (R20 * x + R21 * y + R22 * z) + sg.trans[2];
+    // quaternion_raw_multiply(obj_rots, rotations_local): obj_rots as given (not normalised)
+    const float aw = sg.rot[0], ax = sg.rot[1], ay = sg.rot[2], az = sg.rot[3];
+    const float ow = aw * ql.x - ax * ql.y - ay * ql.z - az * ql.w;
+    const float ox = aw * ql.y + ax * ql.x + ay * ql.w - az * ql.z;
+    const float oy = aw * ql.z - ax * ql.w + ay * ql.x + az * ql.y;
+    const float oz = aw * ql.w + ax * ql.z - ay * ql.y + az * ql.x;
+    const float qn = fmaxf(sqrtf(ow * ow + ox * ox + oy * oy + oz * oz), 1e-12f);
+    a.q = make_float4(ow / qn, ox / qn, oy / qn, oz / qn);
+  } else {
+    a.mx = x; a.my = y; a.mz = z;
+    a.q = ql;
+  }
+  const int F = sg.fourier_dim;
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) {
+    float acc = sg.fdc[(size_t)j * F * 3 + ch] * sg.idft[0];
+    for (int c = 1; c < F; c++) acc = acc + sg.fdc[((size_t)j * F + c) * 3 + ch] * sg.idft[c];
+    a.dc[ch] = acc;
+  }
+  return a;
+}
+
+// All M coefficients of Gaussian j of a segment into sh[3*M] (DC first, then _features_rest).
+__device__ __forceinline__ void compose_features(const SegmentDev& sg, const uint32_t j,
+                                                 const Activated& a, const int M, float* sh) {
+  sh[0] = a.dc[0]; sh[1] = a.dc[1]; sh[2] = a.dc[2];
+  const float* fr = sg.frest + (size_t)j * (M - 1) * 3;
+  for (int k = 0; k < (M - 1) * 3; k++) sh[3 + k] = fr[k];
+}
+
+__global__ void __launch_bounds__(256)
+compose_kernel(const int P, const int M, const SegmentDev* __restrict__ segs, const int nseg,
+               float* __restrict__ means3D, float* __restrict__ scales,
+               float* __restrict__ rotations, float* __restrict__ opacities,
+               float* __restrict__ shs) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const SegmentDev& sg = *find_segment(segs, nseg, (uint32_t)idx);
+  const uint32_t j = (uint32_t)idx - sg.start;
+  const Activated a = compose_one(sg, j);
+  means3D[3 * idx] = a.mx; means3D[3 * idx + 1] = a.my; means3D[3 * idx + 2] = a.mz;
+  scales[3 * idx] = a.s0; scales[3 * idx + 1] = a.s1; scales[3 * idx + 2] = a.s2;
+  rotations[4 * idx] = a.q.x; rotations[4 * idx + 1] = a.q.y; rotations[4 * idx + 2] = a.q.z;
+  rotations[4 * idx + 3] = a.q.w;
+  opacities[idx] = a.opacity;
+  float* o = shs + (size_t)idx * M * 3;
+  o[0] = a.dc[0]; o[1] = a.dc[1]; o[2] = a.dc[2];
+  if (M > 1) {
+    const float* fr = sg.frest + (size_t)j * (M - 1) * 3;
+    for (int k = 0; k < (M - 1) * 3; k++) o[3 + k] = fr[k];
+  }
+}
+
+// preprocess_kernel on composed inputs: same projection / EWA / SH / record code, the activated
+// per-Gaussian values come out of compose_one() instead of the flat tensors.  M4: four SH
+// coefficients per Gaussian (degree <= 1, every shipped config) stay in registers; the generic
+// variant stages up to 16 in a per-lane array.
+template <bool M4>
+__global__ void __launch_bounds__(256)
+preprocess_composed_kernel(const int P, const int D, const int M,
+                           const SegmentDev* __restrict__ segs, const int nseg,
+                           const float scale_modifier, const float* __restrict__ view,
+                           const float* __restrict__ proj, const float* __restrict__ campos,
+                           const int W, const int H, const int gx, const int gy,
+                           const float tan_fovx, const float tan_fovy, const float focal_x,
+                           const float focal_y, int* __restrict__ radii, float4* __restrict__ rec,
+                           uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
+                           uint32_t* __restrict__ ds_table0) {
+  __shared__ float4 s_out[256 * REC_STRIDE];
+  __shared__ uint32_t s_dh[DS_RADIX];
+  s_dh[threadIdx.x] = 0u;
+  const int base = blockIdx.x * 256;
+  const int idx = base + threadIdx.x;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+  uint32_t my_key = CULLED_KEY;
+  if (idx < P) {
+    const SegmentDev& sg = *find_segment(segs, nseg, (uint32_t)idx);
+    const uint32_t j = (uint32_t)idx - sg.start;
+    const Activated a = compose_one(sg, j);
+    Projected o;
+    const bool vis = project_and_bound(idx, a.mx, a.my, a.mz, a.s0, a.s1, a.s2, scale_modifier,
+                                       nullptr, nullptr, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
+                                       focal_x, focal_y, o, true, a.q);
+    if (!vis) {
+      radii[idx] = 0;
+      tiles[idx] = 0;
+      depth_key[idx] = CULLED_KEY;
+    } else {
+      float rgb[3];
+      uint32_t clamped = 0;
+      const float dx = a.mx - campos[0];
+      const float dy = a.my - campos[1];
+      const float dz = a.mz - campos[2];
+      if (M4) {
+        const float* fr = sg.frest + (size_t)j * 9;
+        const float sh12[12] = {a.dc[0], a.dc[1], a.dc[2], fr[0], fr[1], fr[2], fr[3], fr[4], fr[5],
+                                fr[6], fr[7], fr[8]};
+        sh_to_rgb(D > 1 ? 1 : D, sh12, dx, dy, dz, rgb, clamped);
+      } else {
+        float sh[48];
+        compose_features(sg, j, a, M, sh);
+        sh_to_rgb(D, sh, dx, dy, dz, rgb, clamped);
+      }
+      radii[idx] = o.radius;
+      tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
+      depth_key[idx] = __float_as_uint(o.depth);
+      my_key = __float_as_uint(o.depth);
+      r0 = make_float4(o.px, o.py, a.opacity, __int_as_float(o.radius));
+      r1 = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
+      r2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
+    }
+  }
+  s_out[REC_STRIDE * threadIdx.x + 0] = r0;
+  s_out[REC_STRIDE * threadIdx.x + 1] = r1;
+  s_out[REC_STRIDE * threadIdx.x + 2] = r2;
+  s_out[REC_STRIDE * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  if (ds_table0 != nullptr && my_key != CULLED_KEY) atomicAdd(&s_dh[my_key & (DS_RADIX - 1)], 1u);
+  const int nrec4 = min(256, P - base) * REC_STRIDE;
+  float4* dst = rec + (size_t)REC_STRIDE * base;
+#pragma unroll
+  for (int k = 0; k < REC_STRIDE; k++) {
+    const int e = k * 256 + threadIdx.x;
+    if (e < nrec4) dst[e] = s_out[e];
+  }
+  if (ds_table0 != nullptr) {
+    __syncthreads();
+    const uint32_t cnt = s_dh[threadIdx.x];
+    if (cnt != 0u)
+      atomicAdd(&ds_table0[(size_t)(blockIdx.x / (DS_CHUNK / 256)) * DS_RADIX + threadIdx.x], cnt);
+  }
+}
+
+void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
+                                float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
+                                uint32_t* depth_key, uint32_t* tiles, uint32_t* ds_table0) {
+  if (P <= 0) return;
+#define PC_LAUNCH(M4)                                                                           \
+  preprocess_composed_kernel<M4><<<(P + 255) / 256, 256, 0, s>>>(                                \
+      P, D, M, segs, nseg, scale_modifier, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx,  \
+      cam.gy, cam.tan_fovx, cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, \
+      ds_table0)
+  if (M == 4) PC_LAUNCH(true); else PC_LAUNCH(false);
+#undef PC_LAUNCH
+}
+
+void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
+                    float* scales, float* rotations, float* opacities, float* shs) {
+  if (P <= 0) return;
+  compose_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, M, segs, nseg, means3D, scales, rotations,
+                                                  opacities, shs);
 }
 
 void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,

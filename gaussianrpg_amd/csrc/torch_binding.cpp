@@ -12,6 +12,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/grpg_rasterizer.h"
 
@@ -263,6 +264,147 @@ std::tuple<torch::Tensor, torch::Tensor> RasterizeGaussiansFilter(
   return std::make_tuple(radii, means2D);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Fused scene-graph composition (additive; include/grpg_rasterizer.h: grpg_forward_composed).
+// Per model one tensor each of the RAW parameters, in the reference's concatenation order
+// (background first, then the visible actors); `poses` is a CPU float tensor [nseg, 8] =
+// (rigid flag, obj_rot w x y z, obj_trans x y z), `idft` a CPU float tensor [nseg, GRPG_MAX_FOURIER].
+// ----------------------------------------------------------------------------------------------
+namespace {
+
+struct SegmentPack {
+  std::vector<grpg_model_segment> segs;
+  std::vector<torch::Tensor> keep;
+  int64_t P = 0;
+  int M = 0;
+};
+
+SegmentPack pack_segments(const std::vector<torch::Tensor>& xyz, const std::vector<torch::Tensor>& scaling,
+                          const std::vector<torch::Tensor>& rotation,
+                          const std::vector<torch::Tensor>& opacity,
+                          const std::vector<torch::Tensor>& features_dc,
+                          const std::vector<torch::Tensor>& features_rest,
+                          const torch::Tensor& poses, const torch::Tensor& idft) {
+  const size_t n = xyz.size();
+  TORCH_CHECK(n > 0 && n <= GRPG_MAX_SEGMENTS, "need 1..", GRPG_MAX_SEGMENTS, " models");
+  TORCH_CHECK(scaling.size() == n && rotation.size() == n && opacity.size() == n &&
+                  features_dc.size() == n && features_rest.size() == n,
+              "one tensor per model in every parameter list");
+  TORCH_CHECK(!poses.is_cuda() && poses.scalar_type() == torch::kFloat32 && poses.dim() == 2 &&
+                  poses.size(0) == (int64_t)n && poses.size(1) == 8,
+              "poses must be a CPU float tensor [num_models, 8]");
+  TORCH_CHECK(!idft.is_cuda() && idft.scalar_type() == torch::kFloat32 && idft.dim() == 2 &&
+                  idft.size(0) == (int64_t)n && idft.size(1) == GRPG_MAX_FOURIER,
+              "idft must be a CPU float tensor [num_models, ", GRPG_MAX_FOURIER, "]");
+  const torch::Tensor pc = poses.contiguous(), ic = idft.contiguous();
+  SegmentPack pk;
+  pk.segs.resize(n);
+  const torch::Tensor& like = xyz[0];
+  require_device(like);
+  for (size_t i = 0; i < n; i++) {
+    grpg_model_segment& g = pk.segs[i];
+    const int64_t cnt = xyz[i].size(0);
+    TORCH_CHECK(cnt > 0, "model ", i, " is empty: leave it out of the lists");
+    TORCH_CHECK(xyz[i].dim() == 2 && xyz[i].size(1) == 3 && scaling[i].numel() == cnt * 3 &&
+                    rotation[i].numel() == cnt * 4 && opacity[i].numel() == cnt,
+                "model ", i, ": xyz [N,3], scaling [N,3], rotation [N,4], opacity [N,1]");
+    TORCH_CHECK(features_dc[i].dim() == 3 && features_dc[i].size(0) == cnt && features_dc[i].size(2) == 3,
+                "model ", i, ": features_dc must be [N, fourier_dim, 3]");
+    const int F = features_dc[i].size(1);
+    const int Mi = 1 + (features_rest[i].numel() > 0 ? (int)features_rest[i].size(1) : 0);
+    if (i == 0) pk.M = Mi;
+    TORCH_CHECK(Mi == pk.M, "all models must carry the same number of SH coefficients");
+    torch::Tensor k[6];
+    g.xyz = fptr(xyz[i], like, "xyz", k[0]);
+    g.scaling = fptr(scaling[i], like, "scaling", k[1]);
+    g.rotation = fptr(rotation[i], like, "rotation", k[2]);
+    g.opacity = fptr(opacity[i], like, "opacity", k[3]);
+    g.features_dc = fptr(features_dc[i], like, "features_dc", k[4]);
+    g.features_rest = fptr(features_rest[i], like, "features_rest", k[5]);
+    for (auto& t : k) pk.keep.push_back(t);
+    g.count = (int)cnt;
+    g.fourier_dim = F;
+    const float* pr = pc.data_ptr<float>() + 8 * i;
+    g.rigid = pr[0] != 0.0f ? 1 : 0;
+    for (int q = 0; q < 4; q++) g.obj_rot[q] = pr[1 + q];
+    for (int q = 0; q < 3; q++) g.obj_trans[q] = pr[5 + q];
+    for (int q = 0; q < GRPG_MAX_FOURIER; q++) g.idft[q] = ic.data_ptr<float>()[GRPG_MAX_FOURIER * i + q];
+    pk.P += cnt;
+  }
+  return pk;
+}
+
+}  // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor>
+RasterizeGaussiansComposed(const torch::Tensor& background, const std::vector<torch::Tensor>& xyz,
+                           const std::vector<torch::Tensor>& scaling,
+                           const std::vector<torch::Tensor>& rotation,
+                           const std::vector<torch::Tensor>& opacity,
+                           const std::vector<torch::Tensor>& features_dc,
+                           const std::vector<torch::Tensor>& features_rest,
+                           const torch::Tensor& poses, const torch::Tensor& idft,
+                           const float scale_modifier, const torch::Tensor& viewmatrix,
+                           const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                           const int image_height, const int image_width, const int degree,
+                           const torch::Tensor& campos, const bool debug) {
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
+  const torch::Tensor& like = xyz[0];
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
+  const int H = image_height, W = image_width;
+  auto float_opts = like.options().dtype(torch::kFloat32);
+  torch::Tensor out_color = torch::empty({GRPG_NUM_CHANNELS, H, W}, float_opts);
+  torch::Tensor out_depth = torch::empty({1, H, W}, float_opts);
+  torch::Tensor out_alpha = torch::empty({1, H, W}, float_opts);
+  torch::Tensor radii = torch::empty({pk.P}, like.options().dtype(torch::kInt32));
+  auto byte_opts = like.options().dtype(torch::kByte);
+  torch::Tensor geomBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor binningBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor k_bg, k_view, k_proj, k_cam;
+  const float* p_bg = fptr(background, like, "background", k_bg);
+  const float* p_view = fptr(viewmatrix, like, "viewmatrix", k_view);
+  const float* p_proj = fptr(projmatrix, like, "projmatrix", k_proj);
+  const float* p_cam = fptr(campos, like, "campos", k_cam);
+  TORCH_CHECK(p_bg && p_view && p_proj && p_cam, "bg/viewmatrix/projmatrix/campos must be non-empty");
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  int rendered;
+  {
+    pybind11::gil_scoped_release nogil;
+    rendered = grpg_forward_composed(
+        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, pk.segs.data(),
+        (int)pk.segs.size(), degree, pk.M, p_bg, W, H, scale_modifier, p_view, p_proj, p_cam, tan_fovx,
+        tan_fovy, out_color.data_ptr<float>(), out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
+        radii.data_ptr<int>(), debug ? 1 : 0, (void*)stream);
+  }
+  if (rendered < 0) raise_abi_error("grpg_forward_composed", rendered);
+  return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, geomBuffer, binningBuffer,
+                         imgBuffer);
+}
+
+// (means3D [P,3], scales [P,3], rotations [P,4], opacity [P,1], shs [P,M,3]): what the reference's
+// get_xyz / get_scaling / get_rotation / get_opacity / get_features return for the same models
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+Compose(const std::vector<torch::Tensor>& xyz, const std::vector<torch::Tensor>& scaling,
+        const std::vector<torch::Tensor>& rotation, const std::vector<torch::Tensor>& opacity,
+        const std::vector<torch::Tensor>& features_dc, const std::vector<torch::Tensor>& features_rest,
+        const torch::Tensor& poses, const torch::Tensor& idft) {
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
+  const torch::Tensor& like = xyz[0];
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
+  auto o = like.options().dtype(torch::kFloat32);
+  torch::Tensor means = torch::empty({pk.P, 3}, o), scales = torch::empty({pk.P, 3}, o),
+                rots = torch::empty({pk.P, 4}, o), opac = torch::empty({pk.P, 1}, o),
+                shs = torch::empty({pk.P, pk.M, 3}, o);
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_compose(pk.segs.data(), (int)pk.segs.size(), pk.M, means.data_ptr<float>(),
+                              scales.data_ptr<float>(), rots.data_ptr<float>(), opac.data_ptr<float>(),
+                              shs.data_ptr<float>(), (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_compose", rc);
+  return std::make_tuple(means, scales, rots, opac, shs);
+}
+
 // Parity/debug accessor (no reference counterpart): decode the private blobs of a
 // forward call into the reference's intermediate arrays.
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -369,6 +511,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);
   // additions (not in the reference module)
   m.def("debug_export", &DebugExport);
+  m.def("rasterize_gaussians_composed", &RasterizeGaussiansComposed);
+  m.def("compose", &Compose);
   m.def("pack_u8", &PackU8, pybind11::arg("color"), pybind11::arg("out") = pybind11::none());
   m.def("pack_hwc", &PackHWC);
   m.def("set_stage_timing", [](int mode) { grpg_set_stage_timing(mode); });   // 0 off, 1 all, 2 render only

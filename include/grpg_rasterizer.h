@@ -103,6 +103,60 @@ GRPG_API int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user,
                  float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                  int* radii, int debug, void* hip_stream);
 
+/*
+ * Fused scene-graph composition (additive, no counterpart in the
+ * reference's extension).  The reference's callers rebuild the op's flat inputs every frame in
+ * PyTorch: per model sigmoid / exp / normalize of the raw parameters, per actor a rigid transform
+ * of the means, a quaternion product for the rotations and an inverse DFT of the Fourier colour
+ * coefficients, then torch.cat over the models (lib/models/street_gaussian_model.py:296-453,
+ * gaussian_model.py:224-251, gaussian_model_actor.py:73-82) -- about 20 small kernels and two
+ * extra passes over the op's whole input.  grpg_forward_composed takes the models' RAW parameter
+ * arrays and the per-frame actor poses instead and does that arithmetic inside preprocess; the
+ * concatenated tensors never exist.  Forward only (eval / trajectory rendering, S = 0); training
+ * keeps composing in PyTorch, where autograd needs the intermediates.
+ *
+ * A segment describes one model, in the order the reference concatenates them (background first,
+ * then the visible actors, street_gaussian_model.py:232-262).  All pointers are device pointers to
+ * fp32 data; the array of segments itself is HOST memory.
+ */
+#define GRPG_MAX_FOURIER 8
+#define GRPG_MAX_SEGMENTS 1024
+typedef struct grpg_model_segment {
+  const float* xyz;            /* [count,3]  _xyz (object-local for an actor) */
+  const float* scaling;        /* [count,3]  _scaling, activated with exp (gaussian_model.py:224-226) */
+  const float* rotation;       /* [count,4]  _rotation, activated with F.normalize (:228-230) */
+  const float* opacity;        /* [count]    _opacity, activated with sigmoid (:248-250) */
+  const float* features_dc;    /* [count,fourier_dim,3]  _features_dc */
+  const float* features_rest;  /* [count,M-1,3]          _features_rest (NULL when M == 1) */
+  int count;
+  int fourier_dim;             /* 1 for the background; idft[0..fourier_dim) weights the DC terms */
+  int rigid;                   /* 0: world == local.  1: actor -- means  = R(obj_rot) x + obj_trans,
+                                  rotations = normalize(obj_rot (x) normalize(_rotation))
+                                  (street_gaussian_model.py:318-336, :341-365) */
+  float obj_rot[4];            /* (w,x,y,z), ego pose already applied (:268-273) */
+  float obj_trans[3];
+  float idft[GRPG_MAX_FOURIER];/* IDFT(time, fourier_dim), lib/utils/sh_utils.py:120-130 */
+} grpg_model_segment;
+
+/* Same outputs, blobs and return value as grpg_forward on the concatenation of the segments
+ * (P = sum of counts), with D = SH degree and M = (coefficients per Gaussian) of ALL models. */
+GRPG_API int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 const grpg_model_segment* segments, int num_segments, int D, int M,
+                 const float* background, int width, int height, float scale_modifier,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy,
+                 float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
+                 void* hip_stream);
+
+/* The composition alone: writes the activated, concatenated tensors the reference's properties
+ * return (get_xyz [P,3], get_scaling [P,3], get_rotation [P,4], get_opacity [P], get_features
+ * [P,M,3]) with exactly the arithmetic grpg_forward_composed uses internally. */
+GRPG_API int grpg_compose(const grpg_model_segment* segments, int num_segments, int M,
+                 float* means3D, float* scales, float* rotations, float* opacities, float* shs,
+                 void* hip_stream);
+
 /* Binning-blob sizing policy of grpg_forward (process-wide; see above).  The environment variable
  * GRPG_SYNC_R=1 selects GRPG_BINNING_EXACT at load time. */
 #define GRPG_BINNING_SPECULATIVE 0

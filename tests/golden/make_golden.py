@@ -11,7 +11,8 @@ only) -- by file path and records inputs + outputs of
                                            (graphics_utils.py:38-100)
 
 These are the only parts of the path the reference itself can execute in this image (the
-rasterizer proper is CUDA-only), so they are what pins the oracle.  Files: ref_sh.npz, ref_camera.npz.
+rasterizer proper is CUDA-only), so they are what pins the oracle.  Files: ref_sh.npz, ref_camera.npz;
+plus IDFT (sh_utils.py:120-130) -> ref_idft.npz for the fused scene-graph composition.
 
 Part B (oracle-generated regression vectors, NOT reference-derived -- "parity unpinned"):
 small scenes run through oracle/gs_oracle.c; they catch regressions in either the oracle or the
@@ -80,6 +81,18 @@ def part_a():
     print("part A written (reference-derived)")
 
 
+def part_a_idft():
+    """IDFT(time, dim) of lib/utils/sh_utils.py:120-130 (the inverse-DFT weights of an actor's
+    Fourier colour coefficients, gaussian_model_actor.py:73-82) -> ref_idft.npz.  Pins
+    gaussianrpg_amd.composed.idft_weights and oracle/compose_torch.idft."""
+    sh_utils = _load(os.path.join(REF, "lib/utils/sh_utils.py"), "ref_sh_utils_idft")
+    times = [0.0, 0.1, 0.25, 0.5, 0.73, 1.0, 1.9]
+    out = {}
+    for d in (1, 2, 3, 5, 8):
+        out["dim%d" % d] = np.stack([sh_utils.IDFT(t, d)[0].numpy() for t in times])
+    np.savez(os.path.join(HERE, "ref_idft.npz"), times=np.array(times, np.float64), **out)
+
+
 def scenes():
     """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
     from gaussianrpg_amd import harness as hz
@@ -138,6 +151,7 @@ def part_b():
 if __name__ == "__main__":
     if os.path.isdir(REF):
         part_a()
+        part_a_idft()
     else:
         print("no /root/reference here: skipping part A (reference-derived vectors)")
     part_b()

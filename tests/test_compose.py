@@ -1,0 +1,129 @@
+"""Fused scene-graph composition.
+
+CPU part (-m "not gpu"): the IDFT weights against the reference-derived fixture.
+GPU part (-m gpu): (1) grpg_compose == the torch restatement of the reference's getters within
+float tolerance; (2) the fused ComposedRasterizer == the classic GaussianRasterizer fed with
+grpg_compose's own output, BIT FOR BIT on every output (the composition feeds a discontinuous
+function -- ceil of the 3-sigma radius, tile rectangles -- so integer parity is only meaningful
+against the very same activated values).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianrpg_amd import harness as hz
+from helpers import GOLDEN
+
+
+def test_idft_weights_match_reference_fixture():
+    from gaussianrpg_amd.composed import idft_weights
+    from oracle import compose_torch as ct
+    z = np.load(os.path.join(GOLDEN, "ref_idft.npz"))
+    for d in (1, 2, 3, 5, 8):
+        for i, t in enumerate(z["times"]):
+            ref = z["dim%d" % d][i]
+            np.testing.assert_array_equal(np.array(idft_weights(float(t), d), np.float32), ref)
+            np.testing.assert_array_equal(ct.idft(float(t), d)[0].numpy(), ref)
+
+
+def _logit(p):
+    return torch.log(p / (1 - p))
+
+
+def _scene_graph(sh_degree=1, nb=60_000, actors=((4000, 5), (2500, 3), (6000, 1)), seed=5):
+    """Background = a street scene expressed in RAW parameters; actors = boxes of Gaussians in
+    object-local coordinates with tracked poses."""
+    from gaussianrpg_amd.composed import ActorPose, ModelParams
+    g = torch.Generator().manual_seed(seed)
+    sc = hz.street_scene(nb, seed=seed, sh_degree=sh_degree)
+    M = (sh_degree + 1) ** 2
+    models = [ModelParams(sc.means3D, torch.log(sc.scales), sc.rotations * (0.5 + torch.rand(nb, 1, generator=g)),
+                          _logit(sc.opacity.clamp(1e-4, 1 - 1e-4)), sc.shs[:, :1].contiguous(),
+                          sc.shs[:, 1:].contiguous())]
+    poses = [None]
+    for k, (n, F) in enumerate(actors):
+        xyz = (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([4.5, 1.6, 2.0])
+        scaling = math.log(0.05) + 0.5 * torch.randn(n, 3, generator=g)
+        rotation = torch.randn(n, 4, generator=g)
+        opacity = 1.0 + 2.0 * torch.randn(n, 1, generator=g)
+        fdc = 0.5 * torch.randn(n, F, 3, generator=g)
+        frest = 0.15 * torch.randn(n, M - 1, 3, generator=g)
+        models.append(ModelParams(xyz, scaling, rotation, opacity, fdc, frest))
+        q = torch.randn(4, generator=g)
+        q = q / q.norm() * (1.0 + 0.01 * k)        # obj_rot is not exactly unit in practice
+        trans = torch.tensor([-6.0 + 5.0 * k, 0.8, 12.0 + 9.0 * k])
+        poses.append(ActorPose(q.tolist(), trans.tolist(), 0.2 + 0.3 * k))
+    return models, poses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sh_degree", [1, 2, 0])
+def test_compose_matches_torch_restatement(sh_degree):
+    from gaussianrpg_amd.composed import compose
+    from oracle import compose_torch as ct
+    dev = torch.device("cuda:0")
+    models, poses = _scene_graph(sh_degree)
+    got = compose([type(m)(*(t.to(dev) for t in m)) for m in models], poses)
+    ref = ct.compose(models, [None if p is None else (p.obj_rot, p.obj_trans, p.fourier_time) for p in poses])
+    names = ("means3D", "scales", "rotations", "opacity", "shs")
+    P = sum(m.xyz.shape[0] for m in models)
+    for n, a, b in zip(names, got, ref):
+        a = a.cpu()
+        assert a.shape == b.shape and a.shape[0] == P, (n, a.shape, b.shape)
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-6, msg=lambda m, n=n: n + ": " + m)
+    # the background passes through exactly where no arithmetic is involved
+    nb = models[0].xyz.shape[0]
+    assert torch.equal(got[0][:nb].cpu(), models[0].xyz)
+    assert torch.equal(got[4][:nb, 1:].cpu(), models[0].features_rest)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sh_degree", [1, 2])
+def test_fused_forward_equals_classic_on_composed_tensors(sh_degree):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianrpg_amd.composed import ComposedRasterizer, compose
+    dev = torch.device("cuda:0")
+    models, poses = _scene_graph(sh_degree)
+    models = [type(m)(*(t.to(dev) for t in m)) for m in models]
+    cam = hz.trajectory_camera(2, W=960, H=640, device=dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    rs = GaussianRasterizationSettings(**hz.settings_kwargs(cam, sh_degree, bg=bg))
+    fused = ComposedRasterizer(rs)
+    c1, r1, d1, a1 = fused(models, poses)
+    means, scales, rots, opac, shs = compose(models, poses)
+    c2, r2, d2, a2, _ = GaussianRasterizer(rs)(means3D=means, means2D=None, opacities=opac, shs=shs,
+                                               scales=scales, rotations=rots)
+    torch.cuda.synchronize()
+    assert int((r1 > 0).sum()) > 10_000
+    nb = models[0].xyz.shape[0]
+    assert int((r1[nb:] > 0).sum()) > 1000, "the actors must be in view for this test to mean anything"
+    assert torch.equal(r1, r2)
+    assert torch.equal(c1, c2) and torch.equal(d1, d2) and torch.equal(a1, a2)
+    # a second frame with other poses through the same module (capacity hint path)
+    from gaussianrpg_amd.composed import ActorPose
+    poses2 = [None] + [ActorPose(p.obj_rot, [p.obj_trans[0] + 0.5, p.obj_trans[1], p.obj_trans[2] - 1.0],
+                                 p.fourier_time + 0.1) for p in poses[1:]]
+    c3, r3, d3, a3 = fused(models, poses2)
+    m3 = compose(models, poses2)
+    c4, r4, d4, a4, _ = GaussianRasterizer(rs)(means3D=m3[0], means2D=None, opacities=m3[3], shs=m3[4],
+                                               scales=m3[1], rotations=m3[2])
+    assert torch.equal(c3, c4) and torch.equal(r3, r4) and not torch.equal(c1, c3)
+
+
+@pytest.mark.gpu
+def test_composed_argument_errors():
+    from gaussianrpg_amd.composed import ComposedRasterizer
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    dev = torch.device("cuda:0")
+    models, poses = _scene_graph(1, nb=2000, actors=((300, 2),))
+    models = [type(m)(*(t.to(dev) for t in m)) for m in models]
+    cam = hz.trajectory_camera(0, W=128, H=96, device=dev)
+    fused = ComposedRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
+    with pytest.raises(ValueError):
+        fused(models, poses[:1])
+    bad = [models[0], models[1]._replace(features_rest=models[1].features_rest[:, :1])]
+    with pytest.raises(RuntimeError, match="same number of SH coefficients"):
+        fused(bad, poses)
