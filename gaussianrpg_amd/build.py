@@ -35,6 +35,8 @@ HIP_UNITS = {
     "render_bwd.hip": ["-munsafe-fp-atomics"],
     # bit-identical to oracle/knn_oracle.py: one rounding per operation
     "knn.hip": ["-ffp-contract=off"],
+    # hardware float atomics for the cube-map gradient
+    "sky.hip": ["-munsafe-fp-atomics"],
     "api.hip": [],
 }
 HEADERS = ["common.h", "gaussian_math.h", "blend_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]

@@ -716,6 +716,35 @@ int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, int heigh
   return GRPG_OK;
 }
 
+int grpg_sky_composite(const float* cube, int res, const float* ray_matrix, float fill,
+                       int clamp_out, int width, int height, const float* rgb_in, const float* acc,
+                       float* rgb_out, float* sky_out, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (!cube || !ray_matrix || res <= 0 || width <= 0 || height <= 0)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "bad cube / ray matrix / size");
+  if ((rgb_in == nullptr) != (rgb_out == nullptr))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "rgb_in and rgb_out go together");
+  if (!rgb_out && !sky_out) return fail(GRPG_ERR_INVALID_ARGUMENT, "nothing to write");
+  launch_sky_composite((hipStream_t)hip_stream, cube, res, ray_matrix, fill, clamp_out, width, height,
+                       rgb_in, acc, rgb_out, sky_out);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
+int grpg_sky_backward(const float* cube, int res, const float* ray_matrix, float fill, int width,
+                      int height, const float* acc, const float* grad_rgb, float* grad_cube,
+                      float* grad_acc, void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (!cube || !ray_matrix || !grad_rgb || res <= 0 || width <= 0 || height <= 0)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "bad cube / ray matrix / gradient / size");
+  launch_sky_backward((hipStream_t)hip_stream, cube, res, ray_matrix, fill, width, height, acc,
+                      grad_rgb, grad_cube, grad_acc);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
 size_t grpg_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
 
 int grpg_knn_mean_dist2(int P, const float* points, float* mean_dists,

@@ -309,6 +309,14 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 }
 #endif
 
+// sky cube map (sky.hip)
+void launch_sky_composite(hipStream_t st, const float* cube, int res, const float* m9, float fill,
+                          int clamp_out, int W, int H, const float* rgb_in, const float* acc,
+                          float* rgb_out, float* sky_out);
+void launch_sky_backward(hipStream_t st, const float* cube, int res, const float* m9, float fill,
+                         int W, int H, const float* acc, const float* grad_rgb, float* grad_cube,
+                         float* grad_acc);
+
 // distCUDA2 (knn.hip): mean squared distance to the 3 nearest other points.
 size_t knn_workspace_bytes(int P);
 void launch_knn(hipStream_t s, int P, const float* points, float* mean_dists, char* workspace);

@@ -405,6 +405,71 @@ Compose(const std::vector<torch::Tensor>& xyz, const std::vector<torch::Tensor>&
   return std::make_tuple(means, scales, rots, opac, shs);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Sky cube map (additive; include/grpg_rasterizer.h: grpg_sky_composite / grpg_sky_backward).
+// ray_matrix: CPU float tensor [3,3] = R^T K^-1.
+// ----------------------------------------------------------------------------------------------
+std::tuple<torch::Tensor, torch::Tensor>
+SkyComposite(const torch::Tensor& cube, const torch::Tensor& ray_matrix, const float fill,
+             const bool clamp_out, const c10::optional<torch::Tensor>& rgb_opt,
+             const c10::optional<torch::Tensor>& acc_opt, const int height, const int width,
+             const bool want_sky) {
+  TORCH_CHECK(cube.is_cuda() && cube.scalar_type() == torch::kFloat32 && cube.dim() == 4 &&
+                  cube.size(0) == 6 && cube.size(1) == cube.size(2) && cube.size(3) == 3,
+              "sky cube map must be a float32 device tensor [6,res,res,3]");
+  TORCH_CHECK(!ray_matrix.is_cuda() && ray_matrix.scalar_type() == torch::kFloat32 && ray_matrix.numel() == 9,
+              "ray_matrix must be a CPU float32 tensor [3,3]");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(cube.device());
+  torch::Tensor cu = cube.contiguous(), rm = ray_matrix.contiguous(), rgb, acc, out, sky;
+  const float* p_rgb = nullptr;
+  const float* p_acc = nullptr;
+  if (rgb_opt.has_value() && rgb_opt->defined()) {
+    TORCH_CHECK(rgb_opt->is_cuda() && rgb_opt->scalar_type() == torch::kFloat32 && rgb_opt->dim() == 3 &&
+                    rgb_opt->size(0) == 3 && rgb_opt->size(1) == height && rgb_opt->size(2) == width,
+                "rgb must be a float32 device tensor [3,H,W]");
+    rgb = rgb_opt->contiguous();
+    p_rgb = rgb.data_ptr<float>();
+    out = torch::empty_like(rgb);
+  }
+  if (acc_opt.has_value() && acc_opt->defined()) {
+    TORCH_CHECK(acc_opt->is_cuda() && acc_opt->scalar_type() == torch::kFloat32 &&
+                    acc_opt->numel() == (int64_t)height * width, "acc must be a float32 device tensor [1,H,W]");
+    acc = acc_opt->contiguous();
+    p_acc = acc.data_ptr<float>();
+  }
+  if (want_sky || !p_rgb) sky = torch::empty({3, height, width}, cu.options());
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_sky_composite(cu.data_ptr<float>(), (int)cu.size(1), rm.data_ptr<float>(), fill,
+                                    clamp_out ? 1 : 0, width, height, p_rgb, p_acc,
+                                    p_rgb ? out.data_ptr<float>() : nullptr,
+                                    sky.defined() ? sky.data_ptr<float>() : nullptr, (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_sky_composite", rc);
+  return std::make_tuple(out, sky);
+}
+
+std::tuple<torch::Tensor, torch::Tensor>
+SkyBackward(const torch::Tensor& cube, const torch::Tensor& ray_matrix, const float fill,
+            const c10::optional<torch::Tensor>& acc_opt, const torch::Tensor& grad_rgb) {
+  TORCH_CHECK(cube.is_cuda() && grad_rgb.is_cuda() && grad_rgb.dim() == 3 && grad_rgb.size(0) == 3,
+              "grad_rgb must be a device tensor [3,H,W]");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(cube.device());
+  const int H = grad_rgb.size(1), W = grad_rgb.size(2);
+  torch::Tensor cu = cube.contiguous(), rm = ray_matrix.contiguous(), g = grad_rgb.contiguous(), acc;
+  const float* p_acc = nullptr;
+  if (acc_opt.has_value() && acc_opt->defined()) {
+    acc = acc_opt->contiguous();
+    p_acc = acc.data_ptr<float>();
+  }
+  torch::Tensor grad_cube = torch::zeros_like(cu);
+  torch::Tensor grad_acc = torch::empty({1, H, W}, cu.options());
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_sky_backward(cu.data_ptr<float>(), (int)cu.size(1), rm.data_ptr<float>(), fill, W, H,
+                                   p_acc, g.data_ptr<float>(), grad_cube.data_ptr<float>(),
+                                   grad_acc.data_ptr<float>(), (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_sky_backward", rc);
+  return std::make_tuple(grad_cube, grad_acc);
+}
+
 // Parity/debug accessor (no reference counterpart): decode the private blobs of a
 // forward call into the reference's intermediate arrays.
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -513,6 +578,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("debug_export", &DebugExport);
   m.def("rasterize_gaussians_composed", &RasterizeGaussiansComposed);
   m.def("compose", &Compose);
+  m.def("sky_composite", &SkyComposite);
+  m.def("sky_backward", &SkyBackward);
   m.def("pack_u8", &PackU8, pybind11::arg("color"), pybind11::arg("out") = pybind11::none());
   m.def("pack_hwc", &PackHWC);
   m.def("set_stage_timing", [](int mode) { grpg_set_stage_timing(mode); });   // 0 off, 1 all, 2 render only

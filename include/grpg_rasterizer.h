@@ -157,6 +157,34 @@ GRPG_API int grpg_compose(const grpg_model_segment* segments, int num_segments, 
                  float* means3D, float* scales, float* rotations, float* opacities, float* shs,
                  void* hip_stream);
 
+/*
+ * Sky cube map without nvdiffrast (additive).  Replaces
+ * SkyCubeMap.forward (lib/models/sky_cubemap.py:77-122: get_rays_torch + mask + dr.texture(...,
+ * filter_mode='linear', boundary_mode='cube') + clamp) and the composite of
+ * StreetGaussianRenderer.render (lib/models/street_gaussian_renderer.py:106-116:
+ * rgb + sky * (1 - acc), clamp outside train mode) by one launch.
+ *   cube        device [6,res,res,3] fp32, faces in nvdiffrast order (+x -x +y -y +z -z; the
+ *               reference's cube_to_dir, sky_cubemap.py:139-146, is the inverse mapping)
+ *   ray_matrix  HOST float[9], row-major R^T K^-1 with R = w2c[:3,:3], K the intrinsics:
+ *               ray(x, y) = normalize(ray_matrix * (x + 0.5, y + 0.5, 1))  (graphics_utils.py:186-207)
+ *   acc         device [H,W] accumulated opacity; the texture is fetched where (1 - acc) > 1e-3 and
+ *               `fill` (0, or 1 for a white background) is used elsewhere; NULL = fetch everywhere
+ *   rgb_in/out  device [3,H,W]; rgb_out = rgb_in + clamp(sky,0,1) * (1 - acc), clamped to [0,1] when
+ *               clamp_out != 0; rgb_out may alias rgb_in; both NULL = only sky_out is produced
+ *   sky_out     optional device [3,H,W]: the clamped sky colour plane (what SkyCubeMap.forward returns)
+ * Filtering semantics are documented in csrc/sky.hip (bilinear, seamless across edges, corner taps
+ * dropped and renormalised).
+ */
+GRPG_API int grpg_sky_composite(const float* cube, int res, const float* ray_matrix, float fill,
+                                int clamp_out, int width, int height, const float* rgb_in,
+                                const float* acc, float* rgb_out, float* sky_out, void* hip_stream);
+/* Backward of the UNclamped composite (train mode): grad_cube [6,res,res,3] must arrive zero-filled
+ * (accumulated with atomics), grad_acc [H,W] is overwritten with -sum_c sky_c * grad_rgb_c; either
+ * may be NULL. */
+GRPG_API int grpg_sky_backward(const float* cube, int res, const float* ray_matrix, float fill,
+                               int width, int height, const float* acc, const float* grad_rgb,
+                               float* grad_cube, float* grad_acc, void* hip_stream);
+
 /* Binning-blob sizing policy of grpg_forward (process-wide; see above).  The environment variable
  * GRPG_SYNC_R=1 selects GRPG_BINNING_EXACT at load time. */
 #define GRPG_BINNING_SPECULATIVE 0

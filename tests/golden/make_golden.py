@@ -93,6 +93,36 @@ def part_a_idft():
     np.savez(os.path.join(HERE, "ref_idft.npz"), times=np.array(times, np.float64), **out)
 
 
+def part_a_sky():
+    """Sky path: get_rays_torch (lib/utils/graphics_utils.py:186-207, importable) -> ref_rays.npz, and
+    the face convention cube_to_dir (lib/models/sky_cubemap.py:139-146; the module itself needs
+    nvdiffrast / cv2, so the function's source is extracted with ast and executed here, in the build
+    container only -- the fixture holds inputs and outputs, no source text) -> ref_cube_dir.npz."""
+    import ast
+    gu = _load(os.path.join(REF, "lib/utils/graphics_utils.py"), "ref_gu_sky")
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    for n, (H, W) in enumerate([(5, 7), (12, 20)]):
+        K = torch.tensor([[30.0 + n, 0.0, W / 2 + 0.3], [0.0, 28.0, H / 2 - 0.2], [0.0, 0.0, 1.0]])
+        A = torch.randn(3, 3, generator=g)
+        Q, _ = torch.linalg.qr(A)
+        if torch.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        T = torch.randn(3, generator=g)
+        ro, rd = gu.get_rays_torch(H, W, K, Q, T, perturb=False)
+        out.update({"K%d" % n: K.numpy(), "R%d" % n: Q.numpy(), "T%d" % n: T.numpy(),
+                    "rays_o%d" % n: ro.numpy(), "rays_d%d" % n: rd.numpy(), "HW%d" % n: np.array([H, W])})
+    np.savez(os.path.join(HERE, "ref_rays.npz"), **out)
+    src = open(os.path.join(REF, "lib/models/sky_cubemap.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "cube_to_dir"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module([fn], []), "cube_to_dir", "exec"), ns)
+    gx, gy = torch.linspace(-0.9, 0.9, 7), torch.linspace(-0.8, 0.95, 6)
+    yy, xx = torch.meshgrid(gy, gx, indexing='ij')
+    dirs = np.stack([ns["cube_to_dir"](s, xx, yy).numpy() for s in range(6)])
+    np.savez(os.path.join(HERE, "ref_cube_dir.npz"), x=xx.numpy(), y=yy.numpy(), dirs=dirs)
+
+
 def scenes():
     """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
     from gaussianrpg_amd import harness as hz
@@ -152,6 +182,7 @@ if __name__ == "__main__":
     if os.path.isdir(REF):
         part_a()
         part_a_idft()
+        part_a_sky()
     else:
         print("no /root/reference here: skipping part A (reference-derived vectors)")
     part_b()

@@ -13,8 +13,15 @@ ATOL = 1e-4
 RTOL = 1e-4
 # A pixel the oracle flags "fragile" had an accept/reject decision within a few ulp of its
 # threshold (alpha~1/255, T~1e-4, power~0): an implementation whose exp() differs in the last
-# bits may take the other branch; one flipped contribution is worth at most ~alpha*T.
-FRAGILE_ATOL = 5e-2
+# bits may take the other branch.  One flipped contribution at the alpha threshold is worth at
+# most alpha*T*c <= (1/255)(1+|ref|) ~= 4e-3 (1+|ref|); that is the bound a
+# fragile pixel must meet (measured worst case over the GPU suite: 1.3e-3).
+FRAGILE_ATOL = 4e-3
+# North-star bar for the whole image, fragile pixels INCLUDED: at least 99.99 % of the pixels
+# within 1e-4 (SURVEY.md section 7 budgets "a handful of pixels per frame" for threshold flips);
+# images smaller than 30 k pixels may have 3 such pixels.
+MAX_BEYOND_FRAC = 1e-4
+MAX_BEYOND_MIN_PIXELS = 3
 
 
 def oracle_kwargs(cam, sh_degree, bg=None, scale_modifier=1.0):
@@ -39,7 +46,8 @@ def fixture_oracle_inputs(fx):
 PARITY_STATS = []     # one record per compared image plane; dumped by conftest at session end
 
 
-def assert_image_close(name, got, ref, fragile=None, atol=ATOL, rtol=RTOL, max_fragile_frac=0.1):
+def assert_image_close(name, got, ref, fragile=None, atol=ATOL, rtol=RTOL, max_fragile_frac=0.1,
+                       fragile_atol=None, max_beyond_frac=MAX_BEYOND_FRAC):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
@@ -56,11 +64,16 @@ def assert_image_close(name, got, ref, fragile=None, atol=ATOL, rtol=RTOL, max_f
         bad = err > tol
         assert not bad.any(), "%s: %d px beyond tol, max err %.3e" % (name, bad.sum(), err.max())
         return
+    nbad = int((err > tol).sum())
+    assert nbad <= max(MAX_BEYOND_MIN_PIXELS, max_beyond_frac * err.size), (
+        "%s: %d of %d values beyond 1e-4 (%.2e of the image; bar %.0e)" % (
+            name, nbad, err.size, nbad / err.size, max_beyond_frac))
     frag = np.broadcast_to(np.asarray(fragile, dtype=bool), ref.shape[-2:])
     bad = (err > tol) & ~frag[None]
     assert not bad.any(), "%s: %d non-fragile px beyond tol, max err %.3e" % (
         name, bad.sum(), (err * ~frag[None]).max())
     assert frag.mean() <= max_fragile_frac, "%s: fragile fraction %.4f" % (name, frag.mean())
     scale = 1.0 + np.abs(ref)
-    assert ((err / scale) * frag[None]).max() <= FRAGILE_ATOL, "%s: fragile px err %.3e" % (
-        name, ((err / scale) * frag[None]).max())
+    fa = FRAGILE_ATOL if fragile_atol is None else fragile_atol
+    assert ((err / scale) * frag[None]).max() <= fa, "%s: fragile px err %.3e (bound %.1e)" % (
+        name, ((err / scale) * frag[None]).max(), fa)

@@ -152,7 +152,7 @@ def test_dl_dcolors_closed_form(dev):
     gc = torch.tensor([0.7, -1.3, 2.1], device=dev)
     (color * gc[:, None, None]).sum().backward()
     torch.cuda.synchronize()
-    total_alpha = float(alpha.double().sum())
+    total_alpha = float(alpha.detach().double().sum())
     got = colors.grad.double().sum(0).cpu().numpy()
     ref = gc.double().cpu().numpy() * total_alpha
     np.testing.assert_allclose(got, ref, rtol=2e-4)

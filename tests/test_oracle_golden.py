@@ -131,7 +131,10 @@ def test_oracle_vs_torch_splat(case):
     np.testing.assert_array_equal(o["ranges"].astype(np.int64), r["binning"]["ranges"].numpy())
     for k in ["color", "depth", "alpha", "semantic"]:
         if o[k].size:
-            assert_image_close(k, r[k].numpy(), o[k], o["fragile"], max_fragile_frac=0.2)
+            # two CPU restatements with different exp / summation order; a flipped far splat moves
+            # the alpha-weighted depth SUM by up to alpha*T*z, hence the wider fragile bound here
+            assert_image_close(k, r[k].numpy(), o[k], o["fragile"], max_fragile_frac=0.2,
+                               fragile_atol=2e-2)
     nf = o["fragile"] == 0
     assert np.array_equal(o["n_contrib"][nf].astype(np.int64), r["n_contrib"].numpy()[nf].astype(np.int64))
 
