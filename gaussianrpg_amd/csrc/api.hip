@@ -279,7 +279,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                  float tan_fovx, float tan_fovy, float* out_color,
                  float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
-                 void* hip_stream, const grpg_model_segment* segs, int nseg) {
+                 void* hip_stream, const grpg_model_segment* segs, int nseg, unsigned flags = 0u) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
@@ -443,7 +443,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       STAGE_CHECK("tile ranges");
       tm.mark(6);
       launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
-                            out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap);
+                            out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
+                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
       STAGE_CHECK("render");
       tm.mark(7);
       if (S > 0) {
@@ -534,6 +535,24 @@ int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                       out_alpha, out_semantic, radii, debug, hip_stream, nullptr, 0);
 }
 
+int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                       void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D,
+                       int M, int S, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* semantics, const float* opacities, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                       float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
+                       void* hip_stream, unsigned flags) {
+  (void)prefiltered;
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                      image_user, P, D, M, S, background, width, height, means3D, shs, colors_precomp,
+                      semantics, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                      viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth,
+                      out_alpha, out_semantic, radii, debug, hip_stream, nullptr, 0, flags);
+}
+
 int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
                           grpg_alloc_fn binning_alloc, void* binning_user,
                           grpg_alloc_fn image_alloc, void* image_user,
@@ -552,7 +571,7 @@ int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
                       image_user, (int)P, D, M, 0, background, width, height, nullptr, nullptr, nullptr,
                       nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
                       projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
-                      radii, debug, hip_stream, segments, num_segments);
+                      radii, debug, hip_stream, segments, num_segments, GRPG_FORWARD_NO_BACKWARD);
 }
 
 int grpg_compose(const grpg_model_segment* segments, int num_segments, int M, float* means3D,

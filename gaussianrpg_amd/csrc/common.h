@@ -249,7 +249,8 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
-                           uint32_t heavy_min, uint32_t R /* num_rendered */);
+                           uint32_t heavy_min, uint32_t R /* num_rendered */,
+                           bool aux /* track + write n_contrib (needed by the backward only) */);
 uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min);   // render_fwd.hip
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const RecView rec, const float* semantics, int S, int W, int H, int gx,

@@ -91,14 +91,14 @@ __device__ __forceinline__ bool in_mask(const uint64_t m) { return __builtin_amd
 
 template <int PX>
 struct WavePix {   // per-lane blending state of PX pixels
-  float T[PX], Wt[PX];
+  float T[PX];   // out_alpha = sum of alpha_i T_i = 1 - T (telescoping): no separate accumulator
   v2f CrCg[PX], CbD[PX];   // (red, green) and (blue, depth) accumulators: one v_pk_fma_f32 each
   uint32_t last[PX];
   uint64_t done[PX];       // lane masks: pixel k of the lane is saturated / outside the image
 };
 
 // In-order blend of one splat into pixel k (forward.cu:425-440); ok_m = lanes that accept it.
-template <int PX>
+template <int PX, bool AUX = true>
 __device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uint64_t ok_m,
                                           const float alpha, const float4 col, const uint32_t pos) {
   const v2f tw = (v2f){1.0f - alpha, alpha} * (v2f){s.T[k], s.T[k]};   // T (1 - alpha), alpha T
@@ -117,9 +117,8 @@ __device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uin
     s.CbD[k].x = fmaf(col.z, w, s.CbD[k].x);
     s.CbD[k].y = fmaf(col.w, w, s.CbD[k].y);
   }
-  s.Wt[k] += w;
   s.T[k] = cont ? tw.x : s.T[k];
-  s.last[k] = cont ? pos : s.last[k];
+  if (AUX) s.last[k] = cont ? pos : s.last[k];   // n_contrib: only a later backward needs it
 }
 
 // LDS slot of a compacted survivor, light path (REC_F4 = 3 float4):
@@ -136,7 +135,7 @@ __device__ __forceinline__ void store_slot(float4* __restrict__ my, const int sl
 // Evaluate G consecutive compacted survivors (LDS slots j0 .. j0+G-1, all present) for the lane's
 // PX pixels: G*PX independent power/exp/alpha chains, then the in-order blend.  Returns true if
 // the blend part ran (some lane accepted some splat).
-template <int PX, int G>
+template <int PX, int G, bool AUX = true>
 __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __restrict__ my,
                                             const int j0, const float pxf, const int py0) {
   float4 ra[G], rq[G], rc[G];
@@ -167,7 +166,7 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
   for (int g = 0; g < G; g++) {
 #pragma unroll
     for (int k = 0; k < PX; k++)
-      blend_one<PX>(s, k, ok[g][k], alpha[g][k], rc[g], __float_as_uint(ra[g].w));
+      blend_one<PX, AUX>(s, k, ok[g][k], alpha[g][k], rc[g], __float_as_uint(ra[g].w));
   }
   return true;
 }
@@ -190,6 +189,7 @@ __device__ __forceinline__ void store_pair_half(float4* __restrict__ my, const i
 }
 
 // Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
+template <bool AUX = true>
 __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
                                            const int j0, const float pxf, const float pyf) {
   const float4* blk = my + (j0 >> 1) * PAIR_F4;
@@ -214,8 +214,8 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
     // (skipping the blend of a splat no live lane accepts -- 1 in 6 survivors -- with a scalar
     // branch per splat was measured: 0.253 -> 0.272 ms; the branches cost more than the 9 VALU)
     const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4], pp = blk[h * PAIR_F4 + 5];
-    blend_one<1>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x));
-    blend_one<1>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y));
+    blend_one<1, AUX>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x));
+    blend_one<1, AUX>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y));
   }
   return true;
 }
@@ -245,7 +245,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
   WavePix<PX> st;
 #pragma unroll
   for (int k = 0; k < PX; k++) {
-    st.T[k] = 1.0f; st.CrCg[k] = (v2f){0.f, 0.f}; st.CbD[k] = (v2f){0.f, 0.f}; st.Wt[k] = 0.f;
+    st.T[k] = 1.0f; st.CrCg[k] = (v2f){0.f, 0.f}; st.CbD[k] = (v2f){0.f, 0.f};
     st.last[k] = 0;
     st.done[k] = lanes(!(px < W && (py0 + k) < H));
   }
@@ -328,12 +328,12 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
       // full groups of GPI survivors, then the remainder one by one: no dummy slots are evaluated
       int j0 = (TRACE && (ablate & 1)) ? cnt : 0;
       for (; j0 + GPI <= cnt; j0 += GPI) {
-        const bool blended = blend_group<PX, GPI>(st, my, j0, pxf, py0);
+        const bool blended = blend_group<PX, GPI, WRITE_AUX>(st, my, j0, pxf, py0);
         if (TRACE && blended) tr->blends++;
       }
       if (GPI > 1) {
         for (; j0 < cnt; j0++) {
-          const bool blended = blend_group<PX, 1>(st, my, j0, pxf, py0);
+          const bool blended = blend_group<PX, 1, WRITE_AUX>(st, my, j0, pxf, py0);
           if (TRACE && blended) tr->blends++;
         }
       }
@@ -352,7 +352,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
       out_color[pix] = st.CrCg[k].x + st.T[k] * bg0;
       out_color[HW + pix] = st.CrCg[k].y + st.T[k] * bg1;
       out_color[2 * HW + pix] = st.CbD[k].x + st.T[k] * bg2;
-      out_alpha[pix] = st.Wt[k];
+      out_alpha[pix] = 1.0f - st.T[k];
       out_depth[pix] = st.CbD[k].y;
       if (WRITE_AUX) n_contrib[pix] = st.last[k];
     }
@@ -379,7 +379,7 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
 constexpr int QCAP = 512;            // ring capacity in entries (>= 64 + 256), power of two
 constexpr int FILL_Q = 4;            // list entries per lane per FILL step
 
-template <bool TRACE>
+template <bool TRACE, bool AUX = true>
 __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
                                             uint32_t* __restrict__ qpos, const int lane,
                                             const int quarter, const uint32_t r_begin,
@@ -401,7 +401,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   const uint64_t lt = lanemask_lt();
 
   WavePix<1> st;
-  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f}; st.Wt[0] = 0.f;
+  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f};
   st.last[0] = 0;
   st.done[0] = lanes(!(px < W && py < H));
 
@@ -497,7 +497,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
       const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
       if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
       for (int j0 = 0; j0 < cnt; j0 += 4) {
-        const bool blended = blend_quad(st, my, j0, pxf, (float)py);
+        const bool blended = blend_quad<AUX>(st, my, j0, pxf, (float)py);
         if (TRACE && blended) tr->blends++;
       }
       if (TRACE) {
@@ -520,9 +520,9 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
     out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
     out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
-    out_alpha[pix] = st.Wt[0];
+    out_alpha[pix] = 1.0f - st.T[0];
     out_depth[pix] = st.CbD[0].y;
-    n_contrib[pix] = st.last[0];
+    if (AUX) n_contrib[pix] = st.last[0];
   }
 }
 
@@ -667,6 +667,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   }
 }
 
+template <bool AUX = true>
 __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             const float4* __restrict__ buf1,
                                             PCCtrl* __restrict__ ctl, const int lane,
@@ -679,7 +680,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
   const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
   const float pxf = (float)px;
   WavePix<1> st;
-  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f}; st.Wt[0] = 0.f;
+  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f};
   st.last[0] = 0;
   st.done[0] = lanes(!(px < W && py < H));
   uint64_t prev_alive = ~0ull;
@@ -694,7 +695,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     if (f == PC_DONE) break;
     const int cnt = (int)(f - 1u);
     const float4* my = cur ? buf1 : buf0;
-    for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad(st, my, j0, pxf, (float)py);
+    for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad<AUX>(st, my, j0, pxf, (float)py);
     pc_store(&ctl->flag[cur], 0u);   // hand the buffer back
     cur ^= 1;
     const uint64_t alive = ~st.done[0];
@@ -721,9 +722,9 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
     out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
     out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
-    out_alpha[pix] = st.Wt[0];
+    out_alpha[pix] = 1.0f - st.T[0];
     out_depth[pix] = st.CbD[0].y;
-    n_contrib[pix] = st.last[0];
+    if (AUX) n_contrib[pix] = st.last[0];
   }
 }
 
@@ -773,7 +774,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     }
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
     if (wave < 2)
-      pc_consumer(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
+      pc_consumer<WRITE_AUX>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
                   out_depth, out_alpha, n_contrib);
     else
       pc_producer(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
@@ -799,7 +800,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
     tr_tile = tile; tr_len = re - rb;
-    blend_heavy<TRACE>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
+    blend_heavy<TRACE, WRITE_AUX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
                        ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
                        out_alpha, n_contrib, &tr);
   } else {
@@ -934,7 +935,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
-                           uint32_t heavy_min, uint32_t R) {
+                           uint32_t heavy_min, uint32_t R, bool aux) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   // work[0..3] were zeroed by write_headers_kernel (same stream, earlier in the frame)
@@ -944,10 +945,18 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
                                                             pc ? pc_mul : 8u, pc ? 8u : 2u, work);
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
+  // aux == false (no backward will follow): n_contrib is neither tracked nor written
 #define RF_LAUNCH(GL)                                                                          \
-  render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, 0, s>>>(                            \
-      ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,      \
-      out_alpha, n_contrib, pc_slots)
+  do {                                                                                         \
+    if (aux)                                                                                   \
+      render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, 0, s>>>(                        \
+          ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
+          out_alpha, n_contrib, pc_slots);                                                      \
+    else                                                                                       \
+      render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, 0, s>>>(                       \
+          ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
+          out_alpha, n_contrib, pc_slots);                                                      \
+  } while (0)
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
   if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
     uint32_t* d_trace = nullptr;

@@ -60,7 +60,7 @@ void require_device(const torch::Tensor& means3D) {
 
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor, torch::Tensor, torch::Tensor>
-RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D,
+RasterizeGaussiansImpl(const unsigned flags, const torch::Tensor& background, const torch::Tensor& means3D,
                    const torch::Tensor& colors, const torch::Tensor& semantics,
                    const torch::Tensor& opacity, const torch::Tensor& scales,
                    const torch::Tensor& rotations, const float scale_modifier,
@@ -121,15 +121,34 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
     // The call blocks once on the stream (num_rendered read-back): let other Python threads drive
     // their own streams meanwhile.  The blob callbacks only touch ATen, never Python objects.
     pybind11::gil_scoped_release nogil;
-    rendered = grpg_forward(
+    rendered = grpg_forward_flags(
         resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree,
         M, S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov,
         p_view, p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, p_out_color, p_out_depth,
-        p_out_alpha, p_out_sem, p_radii, debug ? 1 : 0, (void*)stream);
+        p_out_alpha, p_out_sem, p_radii, debug ? 1 : 0, (void*)stream, flags);
   }
   if (rendered < 0) raise_abi_error("grpg_forward", rendered);
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, out_semantic, radii,
                          geomBuffer, binningBuffer, imgBuffer);
+}
+
+#define GRPG_RASTERIZE_ARGS                                                                        \
+  const torch::Tensor &background, const torch::Tensor &means3D, const torch::Tensor &colors,      \
+      const torch::Tensor &semantics, const torch::Tensor &opacity, const torch::Tensor &scales,   \
+      const torch::Tensor &rotations, const float scale_modifier, const torch::Tensor &cov3D_precomp, \
+      const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix, const float tan_fovx,      \
+      const float tan_fovy, const int image_height, const int image_width, const torch::Tensor &sh, \
+      const int degree, const torch::Tensor &campos, const bool prefiltered, const bool debug
+#define GRPG_RASTERIZE_PASS                                                                        \
+  background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp, \
+      viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,   \
+      prefiltered, debug
+
+// the reference's entry point (rasterize_points.cu:35-124): blobs valid for the backward
+auto RasterizeGaussians(GRPG_RASTERIZE_ARGS) { return RasterizeGaussiansImpl(0u, GRPG_RASTERIZE_PASS); }
+// same call when no backward can follow (additive): n_contrib is not produced
+auto RasterizeGaussiansEval(GRPG_RASTERIZE_ARGS) {
+  return RasterizeGaussiansImpl(GRPG_FORWARD_NO_BACKWARD, GRPG_RASTERIZE_PASS);
 }
 
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -570,6 +589,7 @@ torch::Tensor distCUDA2(const torch::Tensor& points) {
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians", &RasterizeGaussians);
+  m.def("rasterize_gaussians_eval", &RasterizeGaussiansEval);
   m.def("distCUDA2", &distCUDA2);
   m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
   m.def("mark_visible", &markVisible);

@@ -102,6 +102,30 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opacities, scales,
                         rotations, cov3Ds_precomp, raster_settings):
+    tensors = (means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
+               cov3Ds_precomp)
+    if not (torch.is_grad_enabled() and
+            any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)):
+        # No gradient can ever be asked of this call (torch.no_grad(), or no input requires grad:
+        # render.py / render_lite.py / the simulator).  Same outputs through the entry point that
+        # skips what only the backward needs (n_contrib); nothing is saved for autograd.
+        rs = raster_settings
+        call = (rs.bg, means3D, colors_precomp, semantics, opacities, scales, rotations,
+                rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+                rs.prefiltered, rs.debug)
+        if rs.debug:
+            saved = _snapshot(call)
+            try:
+                out = _C.rasterize_gaussians_eval(*call)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians_eval(*call)
+        num_rendered, color, depth, alpha, semantic, radii = out[:6]
+        return color, radii, depth, alpha, semantic
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities,
                                      scales, rotations, cov3Ds_precomp, raster_settings)
 

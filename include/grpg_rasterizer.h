@@ -104,6 +104,27 @@ GRPG_API int grpg_forward(grpg_alloc_fn geometry_alloc, void* geometry_user,
                  int* radii, int debug, void* hip_stream);
 
 /*
+ * grpg_forward with option flags (additive).  GRPG_FORWARD_NO_BACKWARD: the caller guarantees that
+ * grpg_backward will not be called on the blobs of this call (evaluation / trajectory rendering):
+ * the blend then neither tracks nor writes n_contrib (one instruction per pixel-splat pair and
+ * 4 bytes per pixel less).  Every output is identical to grpg_forward's.
+ */
+#define GRPG_FORWARD_NO_BACKWARD 1u
+GRPG_API int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 int P, int D, int M, int S,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* semantics, const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, int prefiltered,
+                 float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
+                 int* radii, int debug, void* hip_stream, unsigned flags);
+
+/*
  * Fused scene-graph composition (additive, no counterpart in the
  * reference's extension).  The reference's callers rebuild the op's flat inputs every frame in
  * PyTorch: per model sigmoid / exp / normalize of the raw parameters, per actor a rigid transform

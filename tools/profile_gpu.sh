@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 STEPS=${STEPS:-20}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- \
-    python $ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
+    python $ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
 echo "stats rc=$?"
 i=0
 for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
@@ -20,8 +20,19 @@ for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/prof_pmc$i -o pmc -- \
-      python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stage-timing > /dev/null 2> $OUT/prof_pmc$i.err
+      python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stage-timing --no-train --no-strong --no-delivery > /dev/null 2> $OUT/prof_pmc$i.err
   echo "pmc$i rc=$?"
+done
+# config 5 (train forward + backward): kernel stats + HBM counters of the backward kernels
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_stats -o stats -- \
+    python $ROOT/tools/bench_train.py --steps 10 --warmup 3 > $OUT/prof_train_bench.json 2> $OUT/prof_train_stats.err
+echo "train stats rc=$?"
+j=0
+for ctrs in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_COUNT WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  j=$((j+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/prof_train_pmc$j -o pmc -- \
+      python $ROOT/tools/bench_train.py --steps 3 --warmup 1 > /dev/null 2> $OUT/prof_train_pmc$j.err
+  echo "train pmc$j rc=$?"
 done
 find $OUT -name "*.csv" | head -40
 du -sh $OUT

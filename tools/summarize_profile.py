@@ -21,7 +21,7 @@ open(os.path.join(dst, "%s_bench_under_rocprof.json" % tag), "w").write(bench + 
 
 rows = list(csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_stats.csv"))))
 nf = [int(r["Calls"]) for r in rows if "render_forward" in r["Name"]][0]
-lines = ["# rocprofv3 --kernel-trace --stats of `python bench.py --steps N --warmup 3 --no-cpu-baseline`",
+lines = ["# rocprofv3 --kernel-trace --stats of `python bench.py --steps N --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery`",
          "# (%d forward calls: timed frames + warm-up + the untimed V/R statistics pass)" % nf,
          "# per-frame = TotalDurationNs / forward calls", "",
          "%10s %8s %10s  %s" % ("us/frame", "calls/fr", "avg us", "kernel")]
@@ -44,7 +44,8 @@ lines += ["", "# PMC (separate rocprofv3 --pmc passes, mean per dispatch).",
           "# coalesced reads by 2x on gfx950 (reported raw here, corrected in DESIGN.md)."]
 for k in sorted(agg):
     if not any(x in k for x in ("render_forward", "preprocess_kernel", "radix_scatter", "emit_kernel",
-                                "radix_hist", "scan_down", "tile_ranges")):
+                                "radix_hist", "scan_down", "scan_reduce", "tile_ranges", "depth_scatter",
+                                "depth_hist", "frame_init", "pack_u8")):
         continue
     lines.append("== %s" % k)
     for c, v in sorted(agg[k].items()):
@@ -60,7 +61,41 @@ for k in agg:
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         f = sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"]) * 1024.0
         w = sum(agg[k]["WRITE_SIZE"]) / len(agg[k]["WRITE_SIZE"]) * 1024.0
-        traffic[k.split("<")[0]] = {"fetch_bytes_raw": f, "write_bytes": w,
-                                    "hbm_bytes_corrected": 2.0 * f + w}
+        # template arguments stay in the key (radix_scatter_kernel<7, 8> and <8, 8> are different
+        # launches); the render kernel is additionally listed under its bare name for bench.py
+        entry = {"fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_corrected": 2.0 * f + w,
+                 "launches_sampled": len(agg[k]["FETCH_SIZE"])}
+        traffic[k] = entry
+        if k.startswith("render_forward_kernel"):
+            traffic["render_forward_kernel"] = entry
 json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
+
+# ---- config 5 (train): backward kernels ----
+tstats = os.path.join(OUT, "prof_train_stats", "stats_kernel_stats.csv")
+if os.path.exists(tstats):
+    shutil.copy(tstats, os.path.join(dst, "%s_train_kernel_stats.csv" % tag))
+    trows = list(csv.DictReader(open(tstats)))
+    nb = [int(r["Calls"]) for r in trows if "render_backward" in r["Name"]]
+    tl = ["# rocprofv3 --kernel-trace --stats of `python tools/bench_train.py --steps 10 --warmup 3`",
+          "# (config 5: scene-149-like P = 1 M, 1920x1280, forward + backward; %d backward calls)" % (nb[0] if nb else 0),
+          "", "%10s %8s  %s" % ("avg us", "calls", "kernel")]
+    for r in sorted(trows, key=lambda r: -float(r["TotalDurationNs"]))[:24]:
+        tl.append("%10.1f %8s  %s" % (float(r["AverageNs"]) / 1000, r["Calls"], r["Name"].split("(")[0][-80:]))
+    tagg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(OUT, "prof_train_pmc*", "pmc_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("grpg::", "")
+            tagg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    tl += ["", "# PMC, mean per dispatch (FETCH_SIZE / WRITE_SIZE in KiB, raw)"]
+    for k in sorted(tagg):
+        if "backward" in k:
+            tl.append("== %s" % k)
+            for c, v in sorted(tagg[k].items()):
+                tl.append("   %-24s %16.1f   (n=%d)" % (c, sum(v) / len(v), len(v)))
+    open(os.path.join(dst, "%s_train_summary.txt" % tag), "w").write("\n".join(tl) + "\n")
+    try:
+        tb = open(os.path.join(OUT, "prof_train_bench.json")).read().strip().splitlines()[-1]
+        open(os.path.join(dst, "%s_train_under_rocprof.json" % tag), "w").write(tb + "\n")
+    except Exception:
+        pass
 print("\n".join(lines[:30]))
