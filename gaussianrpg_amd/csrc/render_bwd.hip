@@ -120,10 +120,15 @@ __device__ __forceinline__ void backward_rect(
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-  float T[PX], T_final[PX], dLr[PX], dLg[PX], dLb[PX], dLd[PX], dLa[PX], bgdot[PX];
-  float acc_r[PX], acc_g[PX], acc_b[PX], acc_d[PX], acc_a[PX], last_alpha[PX], last_r[PX],
-      last_g[PX], last_b[PX], last_d[PX];
-  float dLs[PX][SM], acc_s[PX][SM], last_s[PX][SM];
+  // Per-pixel state.  The reference carries (last_alpha, last_color) and forms
+  //   accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec        (backward.cu:556-561)
+  // at the NEXT contributor; the same value is obtained by blending the current contributor into
+  // the accumulator right after it has been used (acc = alpha c + (1 - alpha) acc), which needs no
+  // copy of the previous splat's colour per pixel.  Channels are kept in pairs (r,g) / (b,depth)
+  // so that the updates are v_pk_* instructions.
+  float T[PX], T_final[PX], dLa[PX], bgdot[PX], acc_a[PX];
+  v2f dL_rg[PX], dL_bd[PX], acc_rg[PX], acc_bd[PX];
+  float dLs[PX][SM], acc_s[PX][SM];
   uint32_t lastc[PX];
   uint32_t maxlast = 0;
 #pragma unroll
@@ -134,19 +139,21 @@ __device__ __forceinline__ void backward_rect(
     T_final[k] = inside ? 1.0f - alphas[pix] : 0.f;
     T[k] = T_final[k];
     lastc[k] = inside ? n_contrib[pix] : 0u;
-    dLr[k] = inside ? dL_dpix[pix] : 0.f;
-    dLg[k] = inside ? dL_dpix[HW + pix] : 0.f;
-    dLb[k] = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    dLd[k] = inside ? dL_dpix_depth[pix] : 0.f;
+    const float dLr = inside ? dL_dpix[pix] : 0.f;
+    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
+    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    const float dLd = inside ? dL_dpix_depth[pix] : 0.f;
+    dL_rg[k] = (v2f){dLr, dLg};
+    dL_bd[k] = (v2f){dLb, dLd};
     dLa[k] = inside ? dL_dalphas[pix] : 0.f;
-    bgdot[k] = bg0 * dLr[k] + bg1 * dLg[k] + bg2 * dLb[k];
-    acc_r[k] = acc_g[k] = acc_b[k] = acc_d[k] = acc_a[k] = 0.f;
-    last_alpha[k] = last_r[k] = last_g[k] = last_b[k] = last_d[k] = 0.f;
+    bgdot[k] = bg0 * dLr + bg1 * dLg + bg2 * dLb;
+    acc_rg[k] = (v2f){0.f, 0.f};
+    acc_bd[k] = (v2f){0.f, 0.f};
+    acc_a[k] = 0.f;
 #pragma unroll
     for (int c = 0; c < SM; c++) {
       dLs[k][c] = (SMAX > 0 && c < S && inside) ? dL_dpix_semantic[(size_t)c * HW + pix] : 0.f;
       acc_s[k][c] = 0.f;
-      last_s[k][c] = 0.f;
     }
     maxlast = max(maxlast, lastc[k]);
   }
@@ -281,11 +288,15 @@ __device__ __forceinline__ void backward_rect(
       const uint32_t gid = __float_as_uint(c.w);
       const float dx = a.x - pxf;
       const SplatTerms st = splat_terms(dx, b.x, b.y, b.z);
-      float g_mx = 0.f, g_my = 0.f, g_mabs = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f;
-      float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
+      // packed accumulators: (mean2D x, y), (conic xx, yy), (colour r, g), (colour b, depth)
+      v2f g_mxy = {0.f, 0.f}, g_cxw = {0.f, 0.f}, g_rg = {0.f, 0.f}, g_bd = {0.f, 0.f};
+      float g_mabs = 0.f, g_cy = 0.f, g_op = 0.f;
       float g_s[SM];
 #pragma unroll
       for (int cc = 0; cc < SM; cc++) g_s[cc] = 0.f;
+      const v2f col_rg = {b.w, c.x}, col_bd = {c.y, a.z};
+      const v2f con_xz = {b.x, b.z}, ncy2 = {-b.y, -b.y};
+      const v2f ddel = {ddelx_dx, ddely_dy};
       bool any = false;
 #pragma unroll
       for (int k = 0; k < PX; k++) {
@@ -297,62 +308,54 @@ __device__ __forceinline__ void backward_rect(
           any = true;
           // one reciprocal serves both divisions of backward.cu:547,596 (1 ulp: the recovered T is
           // the inverse of a rounded product chain anyway)
-          const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+          const float om = 1.f - alpha;
+          const float inv_1ma = __builtin_amdgcn_rcpf(om);
           T[k] = T[k] * inv_1ma;
           const float dch = alpha * T[k];
-          float dL_dopa = 0.f;
-          acc_r[k] = last_alpha[k] * last_r[k] + (1.f - last_alpha[k]) * acc_r[k];
-          last_r[k] = b.w;
-          dL_dopa += (b.w - acc_r[k]) * dLr[k];
-          g_r += dch * dLr[k];
-          acc_g[k] = last_alpha[k] * last_g[k] + (1.f - last_alpha[k]) * acc_g[k];
-          last_g[k] = c.x;
-          dL_dopa += (c.x - acc_g[k]) * dLg[k];
-          g_g += dch * dLg[k];
-          acc_b[k] = last_alpha[k] * last_b[k] + (1.f - last_alpha[k]) * acc_b[k];
-          last_b[k] = c.y;
-          dL_dopa += (c.y - acc_b[k]) * dLb[k];
-          g_b += dch * dLb[k];
+          const v2f dch2 = {dch, dch}, al2 = {alpha, alpha}, om2 = {om, om};
+          // dL/dalpha through the colours behind this splat (acc = what lies behind, blended)
+          const v2f d1 = (col_rg - acc_rg[k]) * dL_rg[k];
+          const v2f d2 = (col_bd - acc_bd[k]) * dL_bd[k];
+          const v2f ds = d1 + d2;
+          float dL_dopa = ds.x + ds.y;
+          g_rg = __builtin_elementwise_fma(dch2, dL_rg[k], g_rg);
+          g_bd = __builtin_elementwise_fma(dch2, dL_bd[k], g_bd);
+          acc_rg[k] = __builtin_elementwise_fma(al2, col_rg, om2 * acc_rg[k]);
+          acc_bd[k] = __builtin_elementwise_fma(al2, col_bd, om2 * acc_bd[k]);
           if (SMAX > 0) {
 #pragma unroll
             for (int cc = 0; cc < SM; cc++) {
               if (cc < S) {
                 const float sv = semantics[(size_t)gid * S + cc];
-                acc_s[k][cc] = last_alpha[k] * last_s[k][cc] + (1.f - last_alpha[k]) * acc_s[k][cc];
-                last_s[k][cc] = sv;
                 dL_dopa += (sv - acc_s[k][cc]) * dLs[k][cc];
                 g_s[cc] += dch * dLs[k][cc];
+                acc_s[k][cc] = alpha * sv + om * acc_s[k][cc];
               }
             }
           }
-          acc_d[k] = last_alpha[k] * last_d[k] + (1.f - last_alpha[k]) * acc_d[k];
-          last_d[k] = a.z;
-          dL_dopa += (a.z - acc_d[k]) * dLd[k];
-          g_d += dch * dLd[k];
-          acc_a[k] = last_alpha[k] + (1.f - last_alpha[k]) * acc_a[k];
           dL_dopa += (1.f - acc_a[k]) * dLa[k];
+          acc_a[k] = alpha + om * acc_a[k];
           dL_dopa *= T[k];
-          last_alpha[k] = alpha;
           dL_dopa += (-T_final[k] * inv_1ma) * bgdot[k];
           const float dL_dG = a.w * dL_dopa;
-          const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddelx = -gdx * b.x - gdy * b.y;
-          const float dG_ddely = -gdy * b.z - gdx * b.y;
-          const float mx_ = dL_dG * dG_ddelx * ddelx_dx;
-          const float my_ = dL_dG * dG_ddely * ddely_dy;
-          g_mx += mx_;
-          g_my += my_;
-          g_mabs += fabsf(mx_) + fabsf(my_);
-          g_cx += -0.5f * gdx * dx * dL_dG;
-          g_cy += -0.5f * gdx * dy * dL_dG;
-          g_cw += -0.5f * gdy * dy * dL_dG;
-          g_op += G * dL_dopa;
+          const v2f d2v = {dx, dy};
+          const v2f gd = (v2f){G, G} * d2v;                                   // (G dx, G dy)
+          // dG/ddelx = -gdx cx - gdy cy ;  dG/ddely = -gdy cz - gdx cy
+          const v2f dG = __builtin_elementwise_fma((v2f){gd.y, gd.x}, ncy2, -(gd * con_xz));
+          const v2f mxy = ((v2f){dL_dG, dL_dG} * dG) * ddel;
+          g_mxy += mxy;
+          g_mabs += fabsf(mxy.x) + fabsf(mxy.y);
+          const float h = -0.5f * dL_dG;
+          g_cxw = __builtin_elementwise_fma((v2f){h, h}, gd * d2v, g_cxw);    // (gdx dx, gdy dy)
+          g_cy = fmaf(h * gd.x, dy, g_cy);
+          g_op = fmaf(G, dL_dopa, g_op);
         }
       }
       if (__ballot(any) == 0ull) continue;   // wave-uniform: nobody in the tile used this splat
       if (ablate & 2) continue;   // experiment switch (GRPG_BWD_ABLATE): no reduction, no atomics
       {
-        const float q[12] = {g_mx, g_my, g_mabs, g_cx, g_cy, g_cw, g_r, g_g, g_b, g_op, g_d, 0.f};
+        const float q[12] = {g_mxy.x, g_mxy.y, g_mabs, g_cxw.x, g_cy, g_cxw.y, g_rg.x, g_rg.y, g_bd.x, g_op,
+                             g_bd.y, 0.f};
         float tot[3];
         wave_sum_12(q, tot);
         if (sc_ptr && !(ablate & 1))
@@ -378,8 +381,10 @@ __device__ __forceinline__ void backward_rect(
 // counts[4] (three heavy classes, light), then four lists of T tile ids.
 constexpr int NUM_CLASSES_B = 4;
 
-template <int SMAX>
-__global__ void __launch_bounds__(256)
+// MINW: waves per SIMD the register allocator must fit (4 -> 128 VGPRs, 24 B of scratch per lane in
+// the S = 0 / two-pixel-light variant; 1 -> whatever it takes: 138 VGPRs, 3 waves per SIMD)
+template <int SMAX, int LIGHT_SPLIT, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
 render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                        const RecView rec, const float* __restrict__ semantics,
                        const int S, const int W, const int H, const int gx, const uint32_t T,
@@ -400,12 +405,15 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   const uint32_t b = blockIdx.x;
   const uint32_t* lists = work + NUM_CLASSES_B;
   uint32_t tile;
+  uint32_t half = 0;   // light tiles: which 16x8 half of the tile this wave owns
   if (b < nheavy) {
     tile = b < n0 ? lists[b] : (b < n0 + n1 ? lists[T + (b - n0)] : lists[2 * T + (b - n0 - n1)]);
   } else {
+    // LIGHT tiles: LIGHT_SPLIT waves per tile, 4 / LIGHT_SPLIT pixels per lane.
     const uint32_t li = (b - nheavy) * RB_WAVES + (uint32_t)wave;
-    if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
-    tile = lists[3 * (size_t)T + li];
+    if (li >= LIGHT_SPLIT * nlight) return;   // whole wave exits together; no workgroup barriers are used
+    tile = lists[3 * (size_t)T + li / LIGHT_SPLIT];
+    half = li % LIGHT_SPLIT;
   }
   const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
   const uint2 range = ranges[tile];
@@ -418,6 +426,8 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                            dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, ablate)
   if (b < nheavy)
     RB_CALL(1, wave * 4, 1u << (SUBTILE_SHIFT + wave));
+  else if (LIGHT_SPLIT == 2)
+    RB_CALL(2, (int)half * 8, (half ? 0xCu : 0x3u) << SUBTILE_SHIFT);
   else
     RB_CALL(4, 0, 0xFu << SUBTILE_SHIFT);
 #undef RB_CALL
@@ -439,13 +449,25 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
       dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity,  \
       dL_dcolor, dL_ddepth, dL_dsemantic, ablate
-  // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
-  if (S <= 0)
-    render_backward_kernel<0><<<ntiles, 256, 0, s>>>(RB_ARGS);
-  else if (S <= 4)
-    render_backward_kernel<4><<<ntiles, 256, 0, s>>>(RB_ARGS);
-  else
-    render_backward_kernel<32><<<ntiles, 256, 0, s>>>(RB_ARGS);   // S <= 32 (reference: 20)
+  // nheavy + ceil(LIGHT_SPLIT nlight / 4) <= ntiles for LIGHT_SPLIT <= 2 ... not for nheavy ~ ntiles/2:
+  // launch nheavy_max + light workgroups = ntiles + ntiles/2 + 1, surplus workgroups exit at once.
+  // Light tiles: one wave per tile, 4 pixels per lane (default).  GRPG_BWD_LIGHT=2 selects two
+  // waves per light tile at 2 pixels per lane (138 VGPRs / 3 waves per SIMD instead of 178 / 2, or
+  // 128 / 4 with GRPG_BWD_WAVES=4): measured SLOWER (1.25 / 1.36 vs 1.14 ms at config 5) -- the
+  // second wave repeats the tile's list traversal, which outweighs the occupancy.
+  static const int light4 = [] { const char* e = getenv("GRPG_BWD_LIGHT"); return !(e && atoi(e) == 2); }();
+  const int grid = light4 ? ntiles : ntiles + ntiles / 2 + 1;
+  if (S <= 0) {
+    static const int minw = [] { const char* e = getenv("GRPG_BWD_WAVES"); return e ? atoi(e) : 1; }();
+    if (light4) render_backward_kernel<0, 1><<<grid, 256, 0, s>>>(RB_ARGS);
+    else if (minw >= 4) render_backward_kernel<0, 2, 4><<<grid, 256, 0, s>>>(RB_ARGS);
+    else render_backward_kernel<0, 2><<<grid, 256, 0, s>>>(RB_ARGS);
+  } else if (S <= 4) {
+    if (light4) render_backward_kernel<4, 1><<<grid, 256, 0, s>>>(RB_ARGS);
+    else render_backward_kernel<4, 2><<<grid, 256, 0, s>>>(RB_ARGS);
+  } else {
+    render_backward_kernel<32, 1><<<ntiles, 256, 0, s>>>(RB_ARGS);   // S <= 32 (reference: 20)
+  }
 #undef RB_ARGS
 }
 

@@ -179,17 +179,28 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   if (sh.size(0) != 0) M = sh.size(1);
 
   auto o = means3D.options();
-  torch::Tensor dL_dmeans3D = torch::zeros({P, 3}, o);
-  torch::Tensor dL_dmeans2D = torch::zeros({P, 3}, o);
-  torch::Tensor dL_dcolors = torch::zeros({P, GRPG_NUM_CHANNELS}, o);
-  torch::Tensor dL_ddepths = torch::zeros({P, 1}, o);
-  torch::Tensor dL_dconic = torch::zeros({P, 2, 2}, o);
-  torch::Tensor dL_dopacity = torch::zeros({P, 1}, o);
-  torch::Tensor dL_dcov3D = torch::zeros({P, 6}, o);
-  torch::Tensor dL_dsh = torch::zeros({P, M, 3}, o);
-  torch::Tensor dL_dscales = torch::zeros({P, 3}, o);
-  torch::Tensor dL_drotations = torch::zeros({P, 4}, o);
-  torch::Tensor dL_dsemantic = torch::zeros({P, S}, o);
+  // The eleven gradient arrays of rasterize_points.cu:166-176 must arrive zero-filled (atomics and
+  // "+=" accumulate into them).  One allocation and ONE zero-fill launch instead of eleven; the
+  // returned tensors are disjoint views (each starts on a 256-byte boundary).
+  const int64_t widths[11] = {3, 3, GRPG_NUM_CHANNELS, 1, 4, 1, 6, (int64_t)M * 3, 3, 4, S};
+  int64_t offs[12];
+  offs[0] = 0;
+  for (int i = 0; i < 11; i++) offs[i + 1] = offs[i] + (((int64_t)P * widths[i] + 63) / 64) * 64;
+  torch::Tensor pool = torch::zeros({offs[11]}, o);
+  auto view = [&](int i, std::vector<int64_t> shape) {
+    return pool.narrow(0, offs[i], (int64_t)P * widths[i]).view(shape);
+  };
+  torch::Tensor dL_dmeans3D = view(0, {P, 3});
+  torch::Tensor dL_dmeans2D = view(1, {P, 3});
+  torch::Tensor dL_dcolors = view(2, {P, GRPG_NUM_CHANNELS});
+  torch::Tensor dL_ddepths = view(3, {P, 1});
+  torch::Tensor dL_dconic = view(4, {P, 2, 2});
+  torch::Tensor dL_dopacity = view(5, {P, 1});
+  torch::Tensor dL_dcov3D = view(6, {P, 6});
+  torch::Tensor dL_dsh = view(7, {P, M, 3});
+  torch::Tensor dL_dscales = view(8, {P, 3});
+  torch::Tensor dL_drotations = view(9, {P, 4});
+  torch::Tensor dL_dsemantic = view(10, {P, S});
 
   if (P != 0) {
     torch::Tensor k[16];
