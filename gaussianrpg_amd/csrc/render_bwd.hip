@@ -395,12 +395,18 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                        const float* __restrict__ dL_dpix_semantic, float* __restrict__ dL_dmean2D,
                        float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                        float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
-                       float* __restrict__ dL_dsemantic, const int ablate) {
+                       float* __restrict__ dL_dsemantic, const int ablate, const int wide_classes) {
   __shared__ float4 s_rec[RB_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RB_WAVES][BQCAP];
   __shared__ uint32_t s_qpos[RB_WAVES][BQCAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
+  // wide_classes = k: the k shortest heavy classes of the forward's classification are walked like
+  // light tiles here (one wave per tile, 4 pixels per lane) -- one reduction + atomic per
+  // (tile, splat) instead of four
+  const uint32_t n0 = work[0], n1 = work[1];
+  const uint32_t n2 = wide_classes >= 1 ? 0u : work[2];
+  const uint32_t nmid = wide_classes >= 1 ? work[2] : 0u;
+  const uint32_t nlight = work[3] + nmid;
   const uint32_t nheavy = n0 + n1 + n2;
   const uint32_t b = blockIdx.x;
   const uint32_t* lists = work + NUM_CLASSES_B;
@@ -412,7 +418,8 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     // LIGHT tiles: LIGHT_SPLIT waves per tile, 4 / LIGHT_SPLIT pixels per lane.
     const uint32_t li = (b - nheavy) * RB_WAVES + (uint32_t)wave;
     if (li >= LIGHT_SPLIT * nlight) return;   // whole wave exits together; no workgroup barriers are used
-    tile = lists[3 * (size_t)T + li / LIGHT_SPLIT];
+    const uint32_t lt_ = li / LIGHT_SPLIT;   // mid tiles first (longer lists start earlier)
+    tile = lt_ < nmid ? lists[2 * (size_t)T + lt_] : lists[3 * (size_t)T + (lt_ - nmid)];
     half = li % LIGHT_SPLIT;
   }
   const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
@@ -445,10 +452,11 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   if (ntiles <= 0) return;
   // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
   static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
+  static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 0; }();
 #define RB_ARGS                                                                                  \
   ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
       dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity,  \
-      dL_dcolor, dL_ddepth, dL_dsemantic, ablate
+      dL_dcolor, dL_ddepth, dL_dsemantic, ablate, wide
   // nheavy + ceil(LIGHT_SPLIT nlight / 4) <= ntiles for LIGHT_SPLIT <= 2 ... not for nheavy ~ ntiles/2:
   // launch nheavy_max + light workgroups = ntiles + ntiles/2 + 1, surplus workgroups exit at once.
   // Light tiles: one wave per tile, 4 pixels per lane (default).  GRPG_BWD_LIGHT=2 selects two
