@@ -53,7 +53,10 @@ def _rasterize(dev, sc, cam, bg=None, semantics=None, colors_precomp=None, cov3D
         scales=None if use_cov else d.scales, rotations=None if use_cov else d.rotations,
         cov3D_precomp=cov3D_precomp.to(dev) if use_cov else None,
         semantics=None if semantics is None else semantics.to(dev))
+    # (no input requires grad, so the Module takes the eval entry point, which skips what only a
+    # backward needs: every output must still be bit-identical)
     assert torch.equal(out2[0], color) and torch.equal(out2[1], radii)
+    assert torch.equal(out2[2], depth) and torch.equal(out2[3], alpha) and torch.equal(out2[4], semantic)
     return dict(R=R, color=color.cpu().numpy(), depth=depth.cpu().numpy(), alpha=alpha.cpu().numpy(),
                 semantic=semantic.cpu().numpy(), radii=radii.cpu().numpy(),
                 **{k: v.cpu().numpy() for k, v in dbg.items()})
