@@ -728,6 +728,17 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
   }
 }
 
+// XCD-aware work assignment (experiment, off by default: see launch_render_forward).  The
+// hardware places workgroup b on XCD b mod 8 and every XCD has its own L2.  Consecutive entries of a work list are neighbouring tiles (classify appends runs of up
+// to 64 consecutive tile ids), and neighbouring tiles gather the same Gaussians' records -- so
+// workgroup i of the n that walk a list takes item  j * n/8 + i/8  (j = i mod 8): each XCD works on
+// one contiguous eighth of the list and re-finds its neighbours' records in its own L2.
+__device__ __forceinline__ uint32_t xcd_contiguous(const uint32_t i, const uint32_t n, const int on) {
+  if (!on) return i;
+  const uint32_t per = n >> 3, rem = n & 7u, j = i & 7u, k = i >> 3;
+  return j * per + min(j, rem) + k;   // bijection on [0, n): k < per + (j < rem) whenever i < n
+}
+
 #ifndef GRPG_RENDER_MIN_WAVES
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
 // 112 KB of LDS per CU so that the other stream's sort workgroups can co-reside) measured slightly
@@ -742,8 +753,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                      const uint32_t pc_slots, uint32_t* __restrict__ trace = nullptr,
-                      const int ablate = 0) {
+                      const uint32_t pc_slots, const int xcd_on,
+                      uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
@@ -793,8 +804,9 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   if (is_heavy) {
     if (b >= nlong + n2) return;
     // heavy tile: four independent 16x4 sub-tiles, 1 pixel per lane, 4 splats per iteration
-    const uint32_t tile = b < nh0 ? lists[b]
-                                  : (b < nh0 + n1 ? lists[T + (b - nh0)] : lists[2 * T + (b - nh0 - n1)]);
+    const uint32_t tile = b < nh0 ? lists[xcd_contiguous(b, nh0, xcd_on)]
+                                  : (b < nh0 + n1 ? lists[T + xcd_contiguous(b - nh0, n1, xcd_on)]
+                                                  : lists[2 * T + xcd_contiguous(b - nh0 - n1, n2, xcd_on)]);
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
@@ -804,7 +816,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                        ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
                        out_alpha, n_contrib, &tr);
   } else {
-    const uint32_t li = b * RW_WAVES + (uint32_t)wave;
+    if (b >= nlwg) return;
+    const uint32_t li = xcd_contiguous(b, nlwg, xcd_on) * RW_WAVES + (uint32_t)wave;
     if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
     const uint32_t tile = lists[3 * (size_t)T + li];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
@@ -944,6 +957,9 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   const uint32_t pc_slots = render_pc_slots(R, heavy_min);
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
                                                             pc ? pc_mul : 8u, pc ? 8u : 2u, work);
+  // measured: OFF is faster (render 0.232 vs 0.248 ms) -- neighbouring tiles are also similarly
+  // LONG, so a contiguous eighth of a list per XCD unbalances the XCDs by more than the L2 hits save
+  static const int xcd = [] { const char* e = getenv("GRPG_XCD_SWIZZLE"); return e ? atoi(e) : 0; }();
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
   // aux == false (no backward will follow): n_contrib is neither tracked nor written
 #define RF_LAUNCH(GL)                                                                          \
@@ -951,11 +967,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
     if (aux)                                                                                   \
       render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, 0, s>>>(                        \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots);                                                      \
+          out_alpha, n_contrib, pc_slots, xcd);                                                 \
     else                                                                                       \
       render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, 0, s>>>(                       \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots);                                                      \
+          out_alpha, n_contrib, pc_slots, xcd);                                                 \
   } while (0)
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
   if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
@@ -965,7 +981,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
       render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, 0, s>>>(
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
-          out_alpha, n_contrib, pc_slots, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
+          out_alpha, n_contrib, pc_slots, xcd, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
       (void)hipMemcpyAsync(h.data(), d_trace, words * 4, hipMemcpyDeviceToHost, s);
       (void)hipStreamSynchronize(s);
