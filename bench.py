@@ -53,8 +53,12 @@ NUM_FRAMES = 200               # poses of the synthetic drive (BASELINE config 4
 P_GAUSS = 2_000_000            # "Waymo scene 002 full Street-Gaussians (~2M)" stand-in
 SCENE_SEED = 2
 W, H = hz.WAYMO_W, hz.WAYMO_H
-STAGES = ["preprocess", "depth_sort", "offsets_scan", "emit", "tile_sort", "tile_ranges", "render",
-          "semantic_render"]
+STAGES_SORT = ["preprocess", "depth_sort", "offsets_scan", "emit", "tile_sort", "tile_ranges", "render",
+               "semantic_render"]
+# the hierarchical binning (default) fills the same eight timer slots with its own stages
+STAGES_HIER = ["preprocess", "depth_sort", "coarse_scan", "coarse_emit", "coarse_partition",
+               "tile_count_fill", "render", "semantic_render"]
+STAGES = STAGES_HIER
 
 
 def parse():
@@ -283,6 +287,8 @@ def main():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from gaussianrpg_amd.rasterizer import _C
     _C.set_binning_mode(args.binning_mode)
+    global STAGES
+    STAGES = STAGES_HIER if _C.get_binning_algorithm() == 1 else STAGES_SORT
 
     scene_cpu = hz.street_scene(args.gaussians, seed=SCENE_SEED, sh_degree=1)
     sc = scene_cpu.to(dev)
@@ -539,6 +545,7 @@ def main():
                        "P": P, "V_avg": V_avg, "R_avg": R_avg, "T": T_tiles, "width": W,
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
                        "streams_per_gpu": ns, "binning_mode": "exact" if args.binning_mode else "speculative",
+                       "binning_algorithm": "hierarchical" if STAGES is STAGES_HIER else "sort",
                        "gather_batch_frames": args.gather_batch if world > 1 else None,
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
             "roofline": roof,

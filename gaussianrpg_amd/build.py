@@ -30,6 +30,7 @@ HIP_UNITS = {
     "preprocess_bwd.hip": ["-ffp-contract=off"],
     "sort.hip": [],
     "binning.hip": [],
+    "hier_binning.hip": [],
     "render_fwd.hip": [],
     # hardware global_atomic_add_f32 instead of a CAS loop
     "render_bwd.hip": ["-munsafe-fp-atomics"],

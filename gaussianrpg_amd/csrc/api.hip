@@ -62,6 +62,7 @@ struct CapKey { int dev, P, W, H; };
 struct CapHint {
   CapKey key{-1, 0, 0, 0};
   uint32_t high = 0;      // decaying high-water mark of num_rendered
+  uint32_t high_c = 0;    // same for the coarse (Gaussian, super-tile) count of the hierarchical binning
   uint64_t stamp = 0;     // last use (LRU replacement)
   bool valid = false;
 };
@@ -82,15 +83,26 @@ uint32_t padded_capacity(uint32_t r) {
   const uint64_t c = ((uint64_t)r + r / 4 + 65536 + 65535) / 65536 * 65536;
   return (uint32_t)(c > 0x7FFF0000ull ? 0x7FFF0000ull : c);
 }
-uint32_t capacity_from_hint(const CapKey& k) {
-  static const long forced = [] { const char* e = getenv("GRPG_RCAP_TEST"); return e ? atol(e) : -1L; }();
-  if (forced >= 0) return (uint32_t)forced;   // test hook: exercises the overflow / redo path
+uint32_t capacity_from_hint(const CapKey& k, uint32_t* coarse_cap) {
+  // test hook "R" or "R:Rc": forced capacities, to exercise the overflow / redo paths
+  static const char* forced_env = getenv("GRPG_RCAP_TEST");
+  if (forced_env) {
+    const long r = atol(forced_env);
+    const char* c = strchr(forced_env, ':');
+    *coarse_cap = (uint32_t)(c ? atol(c + 1) : r);
+    return (uint32_t)r;
+  }
   std::lock_guard<std::mutex> lk(g_hint_mu);
   for (auto& h : g_hints)
-    if (h.valid && same_key(h.key, k)) { h.stamp = ++g_hint_clock; return padded_capacity(h.high); }
+    if (h.valid && same_key(h.key, k)) {
+      h.stamp = ++g_hint_clock;
+      *coarse_cap = h.high_c ? padded_capacity(h.high_c) : padded_capacity(h.high);
+      return padded_capacity(h.high);
+    }
+  *coarse_cap = 0u;
   return 0u;
 }
-void update_hint(const CapKey& k, uint32_t R) {
+void update_hint(const CapKey& k, uint32_t R, uint32_t Rc) {
   std::lock_guard<std::mutex> lk(g_hint_mu);
   CapHint* slot = nullptr;
   for (auto& h : g_hints)
@@ -107,6 +119,10 @@ void update_hint(const CapKey& k, uint32_t R) {
   }
   const uint32_t decayed = slot->high - slot->high / 64;   // lets the mark follow a shrinking scene
   slot->high = R > decayed ? R : decayed;
+  if (Rc) {
+    const uint32_t dc = slot->high_c - slot->high_c / 64;
+    slot->high_c = Rc > dc ? Rc : dc;
+  }
   slot->stamp = ++g_hint_clock;
 }
 
@@ -157,6 +173,15 @@ uint32_t heavy_tile_min() {
   return v;
 }
 
+// Tile binning algorithm: "hier" (hier_binning.hip, default) or "sort" (emit + stable partition).
+bool binning_is_hier() {
+  static const bool v = [] {
+    const char* e = getenv("GRPG_BINNING");
+    return !(e && strcmp(e, "sort") == 0);
+  }();
+  return v;
+}
+
 int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit in b bits
   int b = 0;
   while ((1ull << b) < (unsigned long long)T) b++;
@@ -184,11 +209,11 @@ struct StageTimer {
     else { r = new TimingRecord(); for (auto& e : r->ev) (void)hipEventCreate(&e); }
     r->n = 0;
   }
-  int tail_n = -1;   // record count when the tail of the frame (emit onwards) began
+  int tail_n = -1;   // record count when the tail of the frame (everything redone on overflow) began
+  void begin_tail() { if (r && tail_n < 0) tail_n = r->n; }
   void restart_tail() { if (r && tail_n >= 0) r->n = tail_n; }
   void mark(int next_stage) {
     if (!r || r->n > GRPG_NUM_STAGES) return;
-    if (next_stage == 3) tail_n = r->n;
     if (mode == 2 && next_stage != 6 && next_stage != 7) return;   // render start / render end only
     (void)hipEventRecord(r->ev[r->n], s);
     r->stage_of[r->n] = next_stage;
@@ -253,6 +278,9 @@ int grpg_set_binning_mode(int mode) {
     return fail(GRPG_ERR_INVALID_ARGUMENT, "unknown binning mode");
   g_binning_mode.store(mode);
   return GRPG_OK;
+}
+int grpg_get_binning_algorithm(void) {
+  return binning_is_hier() ? GRPG_BINNING_ALG_HIER : GRPG_BINNING_ALG_SORT;
 }
 int grpg_reset_capacity_hints(void) {
   std::lock_guard<std::mutex> lk(g_hint_mu);
@@ -343,13 +371,22 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // memory.  Exact mode, or no history yet: wait for the count first, like the reference
     // (rasterizer_impl.cu:284).
     const bool fat_sort = depth_sort_is_fat(GL.nchunks_ds);
+    // hierarchical binning needs the compacted depth order of the fat sort (its coarse scan gathers
+    // the super-tile counts by sorted id); otherwise emit + partition
+    const uint32_t NS = super_tiles(cam.gx, cam.gy);
+    const bool hier = fat_sort && binning_is_hier() && NS <= 65536u;   // 16 id bits in a coarse key
+    // cap: instances (point list); ccap: coarse (Gaussian, super-tile) pairs, <= cap
+    auto layout_for = [&](uint32_t cap, uint32_t ccap) {
+      return hier ? bin_layout((size_t)cap, T, NS, ccap) : bin_layout((size_t)cap);
+    };
     const CapKey ck = {dev, P, width, height};
-    uint32_t Rcap = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? capacity_from_hint(ck) : 0u;
+    uint32_t Ccap = 0u;
+    uint32_t Rcap = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? capacity_from_hint(ck, &Ccap) : 0u;
     const bool speculative = Rcap != 0u;
     char* bin = nullptr;
     BinLayout BL{};
     if (speculative) {
-      BL = bin_layout((size_t)Rcap);
+      BL = layout_for(Rcap, Ccap);
       bin = binning_alloc(BL.total, binning_user);
       if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
     }
@@ -357,9 +394,10 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
                       (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
                       geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
+    uint32_t* ctiles = hier ? (uint32_t*)(geom + GL.ctiles) : nullptr;
     if (segs == nullptr) {
       launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                        cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles,
+                        cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles, ctiles,
                         fat_sort ? ds_table : nullptr);
     } else {
       // segment table: host structs -> pinned staging -> the geometry blob (asynchronous copy)
@@ -383,7 +421,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)nseg,
                              hipMemcpyHostToDevice, stream));
       launch_preprocess_composed(stream, P, D, M, seg_dev, nseg, scale_modifier, cam, radii_int, rec_w,
-                                 key_a, tiles, fat_sort ? ds_table : nullptr);
+                                 key_a, tiles, ctiles, fat_sort ? ds_table : nullptr);
     }
     STAGE_CHECK("preprocess");
     tm.mark(1);
@@ -400,19 +438,40 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       sorted_gid = in_b ? val_b : val_a;  // 4 passes -> back in "a"
     }
     STAGE_CHECK("depth sort");
-    tm.mark(2);
+    tm.begin_tail();
     uint32_t* emit_win = (uint32_t*)(geom + GL.emit_win);
-    launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, fat_sort ? sorted_gid : nullptr, tiles,
-                        offsets, block_sums, GL.nblocks_scan, &gh->R, hw->dev_ptr, emit_win,
-                        GL.emit_win_cap);
-    STAGE_CHECK("offsets scan");
-    HIP_TRY(hipEventRecord(hw->ev, stream));   // fires when num_rendered sits in the pinned word
+    // num_rendered from the tile counts (the only way the sort path learns it; the hierarchical path
+    // uses it when it has no capacity to speculate with): scan, count to the pinned word, event
+    auto scan_tiles = [&]() -> int {
+      tm.mark(2);
+      launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, fat_sort ? sorted_gid : nullptr, tiles,
+                          offsets, block_sums, GL.nblocks_scan, &gh->R, hw->dev_ptr, emit_win,
+                          GL.emit_win_cap);
+      STAGE_CHECK("offsets scan");
+      HIP_TRY(hipEventRecord(hw->ev, stream));   // fires when num_rendered sits in the pinned word
+      return GRPG_OK;
+    };
+    auto render_tail = [&](const uint32_t* point_list, uint32_t cap) -> int {
+      tm.mark(6);
+      launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
+                            out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
+                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
+      STAGE_CHECK("render");
+      tm.mark(7);
+      if (S > 0) {
+        launch_render_semantic(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
+                               cam.gy, out_semantic);
+        STAGE_CHECK("semantic render");
+      }
+      tm.mark(-1);
+      return GRPG_OK;
+    };
 
     const int tbits = bits_for(T);
     const int passes = radix_sort_num_passes(0, tbits);
     const int bits0 = radix_sort_first_pass_bits(0, tbits);
-    // everything behind the offsets scan, for a binning blob of capacity `cap`
-    auto enqueue_tail = [&](char* binp, const BinLayout& L, uint32_t cap) -> int {
+    // sort path: everything behind the offsets scan, for a binning blob of capacity `cap`
+    auto tail_sort = [&](char* binp, const BinLayout& L, uint32_t cap) -> int {
       uint32_t* bkey_a = (uint32_t*)(binp + L.key_a);
       uint32_t* bkey_b = (uint32_t*)(binp + L.key_b);
       uint32_t* bval_a = (uint32_t*)(binp + L.val_a);
@@ -441,43 +500,110 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       tm.mark(5);
       launch_tile_ranges(stream, &gh->R, cap, bkey_a, ranges, T);
       STAGE_CHECK("tile ranges");
-      tm.mark(6);
-      launch_render_forward(stream, ranges, bval_a, rec, width, height, cam.gx, cam.gy, background,
-                            out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
-                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
-      STAGE_CHECK("render");
-      tm.mark(7);
-      if (S > 0) {
-        launch_render_semantic(stream, ranges, bval_a, rec, semantics, S, width, height, cam.gx,
-                               cam.gy, out_semantic);
-        STAGE_CHECK("semantic render");
-      }
-      tm.mark(-1);
-      return GRPG_OK;
+      return render_tail(bval_a, cap);
     };
-
-    if (speculative) {
-      if (int rc = enqueue_tail(bin, BL, Rcap)) return rc;
-    }
-    // The one host wait of the frame.  In speculative mode the device is already busy with the
-    // rest of the frame (and the caller can enqueue the next one as soon as we return).
-    HIP_TRY(hipEventSynchronize(hw->ev));
-    R = hw->host_ptr[0];
-    if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
-    if (!speculative || R > Rcap) {
-      // exact mode / first frame / capacity overflow (the speculative tail clamped its work to the
-      // old capacity and its results are discarded): carve the blob for the true count, redo the tail
-      const bool redo = speculative;
-      Rcap = speculative || g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? padded_capacity(R) : R;
-      BL = bin_layout((size_t)Rcap);
+    // hierarchical path (hier_binning.hip): everything behind the depth sort.  Stage slots: 2 = scan
+    // over the super-tile counts, 3 = coarse emit, 4 = coarse partition + super-tile runs,
+    // 5 = segment counts, tile ranges and the point-list fill.  `publish`: the tile scan stores
+    // num_rendered (and the coarse count) to the pinned word and the event is recorded behind it.
+    const int sgx = (cam.gx + STILE - 1) / STILE, sgy = (cam.gy + STILE - 1) / STILE;
+    const int cbits = bits_for(NS);
+    const int cpasses = radix_sort_num_passes(0, cbits);
+    const int cbits0 = radix_sort_first_pass_bits(0, cbits);
+    auto tail_hier = [&](char* binp, const BinLayout& L, uint32_t cap, uint32_t ccap, bool publish) -> int {
+      uint32_t* ckey_a = (uint32_t*)(binp + L.key_a);
+      uint32_t* ckey_b = (uint32_t*)(binp + L.key_b);
+      uint32_t* cval_a = (uint32_t*)(binp + L.val_b);
+      uint32_t* cval_b = (uint32_t*)(binp + L.val_c);
+      uint32_t* plist = (uint32_t*)(binp + L.val_a);
+      uint32_t* btable = (uint32_t*)(binp + L.table);
+      uint32_t* btotals = (uint32_t*)(binp + L.totals);
+      uint2* cranges = (uint2*)(binp + L.cranges);
+      tm.mark(2);
+      launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, sorted_gid, ctiles, offsets,
+                          block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap);
+      STAGE_CHECK("coarse offsets scan");
+      tm.mark(3);
+      launch_emit_coarse(stream, &gh->V, &gh->Rc, ccap, sorted_gid, offsets, emit_win, GL.emit_win_cap,
+                         rec, sgx, sgy, ckey_a, cval_a, cpasses > 0 ? btable : nullptr,
+                         (1u << cbits0) - 1u, L.nchunks_coarse, cranges, NS);
+      STAGE_CHECK("coarse emit");
+      tm.mark(4);
+      bool in_b = false;
+      if (cpasses > 0 && ccap > 0)
+        in_b = radix_sort_pairs(stream, ccap, &gh->Rc, ckey_a, cval_a, ckey_b, cval_b, false, 0, cbits,
+                                btable, btotals, L.nchunks_coarse, true);
+      STAGE_CHECK("coarse partition");
+      const uint32_t* ckey = in_b ? ckey_b : ckey_a;
+      launch_tile_ranges(stream, &gh->Rc, ccap, ckey, cranges, NS, 0xFFFFu);
+      STAGE_CHECK("super-tile runs");
+      tm.mark(5);
+      const uint32_t* cval = in_b ? cval_b : cval_a;
+      launch_hier_count(stream, cranges, NS, binp + L.seg_desc, (uint2*)(binp + L.st_seg),
+                        (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
+                        (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
+                        (uint32_t*)(binp + L.tile_start), ranges, &gh->R, publish ? hw->dev_ptr : nullptr,
+                        &gh->Rc, (BlobHeader*)binp, cap, ccap);
+      STAGE_CHECK("tile counts");
+      if (publish) HIP_TRY(hipEventRecord(hw->ev, stream));
+      launch_hier_fill(stream, binp + L.seg_desc, (const uint32_t*)(binp + L.nseg), L.max_seg, ckey, cval, rec,
+                       cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),
+                       (const uint32_t*)(binp + L.tile_start), cap, plist);
+      STAGE_CHECK("point list fill");
+      return render_tail(plist, cap);
+    };
+    auto carve = [&](uint32_t cap, uint32_t ccap, bool rezero) -> int {
+      Rcap = cap;
+      Ccap = ccap;
+      BL = layout_for(Rcap, Ccap);
       bin = binning_alloc(BL.total, binning_user);
       if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
       launch_bin_header(stream, bin, (uint32_t)P, Rcap, (uint32_t)width, (uint32_t)height, (uint32_t)S,
-                        redo ? ranges : nullptr, T, redo ? work : nullptr);
-      if (redo) tm.restart_tail();
-      if (int rc = enqueue_tail(bin, BL, Rcap)) return rc;
+                        rezero ? ranges : nullptr, T, rezero ? work : nullptr);
+      return GRPG_OK;
+    };
+    const bool spec_mode = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE;
+
+    // Speculative: the whole frame is enqueued, then the one host wait (the device is already busy
+    // with the rest of the frame and the caller can enqueue the next one as soon as we return).
+    // Exact mode / no history: wait for the count first, like the reference (rasterizer_impl.cu:284).
+    bool need_exact = !speculative;
+    uint32_t Rc_seen = 0u;   // coarse count of this frame, once the host has seen it
+    if (speculative) {
+      if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, true)) return rc; }
+      else { if (int rc = scan_tiles()) return rc; if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+      HIP_TRY(hipEventSynchronize(hw->ev));
+      R = hw->host_ptr[0];
+      if (hier) Rc_seen = hw->host_ptr[1];
+      if (hier && Rc_seen > Ccap) {
+        need_exact = true;          // the coarse list itself was clamped: the count is not usable
+      } else if (R > Rcap) {
+        // capacity overflow (the speculative tail clamped its work to the old capacity and its
+        // results are discarded): R is exact; carve the blob for it and redo the tail
+        if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+        if (int rc = carve(padded_capacity(R), Ccap, true)) return rc;
+        tm.restart_tail();
+        if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, false)) return rc; }
+        else { if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+      }
     }
-    update_hint(ck, R);
+    if (need_exact) {
+      const bool redo = speculative;
+      if (redo) tm.restart_tail();
+      if (int rc = scan_tiles()) return rc;
+      HIP_TRY(hipEventSynchronize(hw->ev));
+      R = hw->host_ptr[0];
+      if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+      // the coarse count is unknown here, but never above num_rendered
+      const uint32_t cap = spec_mode ? padded_capacity(R) : R;
+      uint32_t ccap = cap;
+      if (Rc_seen && padded_capacity(Rc_seen) < cap) ccap = padded_capacity(Rc_seen);   // exact, from the scan
+      if (int rc = carve(cap, ccap, redo)) return rc;
+      if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, false)) return rc; }
+      else { if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+    }
+    if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+    update_hint(ck, R, Rc_seen);
     tm.finish();
   } else {
     // P == 0: the reference launches nothing and its pre-zeroed planes stay zero
@@ -800,12 +926,15 @@ int grpg_debug_export(int P, int R, int width, int height, const char* geom_buff
   HIP_TRY(hipStreamSynchronize(stream));
   if (bh.magic != BIN_MAGIC || bh.Rcap < (uint32_t)R)
     return fail(GRPG_ERR_BAD_BUFFER, "binning buffer does not match this call");
-  const BinLayout BL = bin_layout((size_t)bh.Rcap);
+  // hierarchical blob: the header's Rc is the coarse capacity it was carved for
+  const BinLayout BL = bh.hier ? bin_layout((size_t)bh.Rcap, (size_t)gx * gy, super_tiles(gx, gy), (size_t)bh.Rc)
+                               : bin_layout((size_t)bh.Rcap);
   const ImgLayout IL = img_layout((size_t)gx * gy, (size_t)width * height);
   launch_debug_export(stream, P, (uint32_t)R, width, height, gx, gy,
                       RecView{(const float4*)(geom_buffer + GL.rec)},
                       (const uint32_t*)(geom_buffer + GL.tiles),
                       (const uint32_t*)(binning_buffer + BL.key_a),
+                      bh.hier ? (const uint32_t*)(binning_buffer + BL.tile_start) : nullptr,
                       (const uint32_t*)(binning_buffer + BL.val_a),
                       (const uint2*)(image_buffer + IL.ranges),
                       (const uint32_t*)(image_buffer + IL.n_contrib), keys_sorted, point_list,

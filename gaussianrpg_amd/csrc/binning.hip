@@ -65,6 +65,34 @@ __device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k
   val = g | (bits << SUBTILE_SHIFT);
 }
 
+// Coarse instance (hierarchical binning, hier_binning.hip): slot k of Gaussian g's SUPER-TILE
+// rectangle (row-major) -> key = super-tile id | local column mask << 16 | local row mask << 24
+// (the tiles of that super-tile the rectangle covers; the coarse partition sorts on the id bits
+// only), value = g.  r3 = the packed tile rectangle of the record.
+__device__ __forceinline__ void emit_coarse_instance(const uint32_t g, const uint32_t k, const float4 r3,
+                                                     const int sgx, uint32_t& key, uint32_t& val) {
+  const uint32_t rx = __float_as_uint(r3.x), ry = __float_as_uint(r3.y);
+  const int minx = (int)(rx & 0xFFFFu), maxx = (int)(rx >> 16);
+  const int miny = (int)(ry & 0xFFFFu), maxy = (int)(ry >> 16);
+  const uint32_t sx0 = (uint32_t)minx / STILE, sx1 = ((uint32_t)maxx + STILE - 1) / STILE;
+  const uint32_t sy0 = (uint32_t)miny / STILE;
+  const uint32_t w = sx1 - sx0;
+  uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
+  row -= (row * w > k) ? 1u : 0u;
+  row += ((row + 1u) * w <= k) ? 1u : 0u;
+  const uint32_t col = k - row * w;
+  const int sx = (int)(sx0 + col), sy = (int)(sy0 + row);
+  const int lx0 = max(minx - sx * STILE, 0), lx1 = min(maxx - sx * STILE, STILE);   // half-open
+  const int ly0 = max(miny - sy * STILE, 0), ly1 = min(maxy - sy * STILE, STILE);
+  const uint32_t cm = ((1u << lx1) - 1u) & ~((1u << lx0) - 1u);
+  const uint32_t rm = ((1u << ly1) - 1u) & ~((1u << ly0) - 1u);
+  key = ((uint32_t)sy * (uint32_t)sgx + (uint32_t)sx) | (cm << 16) | (rm << 24);
+  val = g;
+}
+
+// COARSE: the slots are (Gaussian, super-tile) pairs -- `offsets` is the scan over the super-tile
+// counts, gx = super-tiles per row -- and only the packed rectangle of the record is read.
+template <bool COARSE>
 __global__ void __launch_bounds__(EMIT_THREADS)
 emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_dev,
             const uint32_t R_cap, const uint32_t* __restrict__ sorted_gid,
@@ -72,7 +100,9 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
             const uint32_t emit_win_cap, const RecView rec, const int gx, const int gy,
             uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
             uint32_t* __restrict__ hist_table /* [digit][nchunks], may be NULL */,
-            const uint32_t hist_mask, const uint32_t nchunks) {
+            const uint32_t hist_mask, const uint32_t nchunks,
+            uint2* __restrict__ zero_ranges /* COARSE: super-tile runs cleared by workgroup 0 */,
+            const uint32_t nzero) {
   __shared__ uint32_t s_win[2];
   __shared__ uint32_t s_off[EMIT_WIN];
   __shared__ uint32_t s_own[EMIT_PER_BLOCK];
@@ -81,6 +111,8 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t R = min(*R_dev, R_cap);
   const uint32_t o0 = blockIdx.x * EMIT_PER_BLOCK;
+  if (COARSE && blockIdx.x == 0)
+    for (uint32_t i = tid; i < nzero; i += EMIT_THREADS) zero_ranges[i] = make_uint2(0u, 0u);
   if (o0 >= R) return;   // whole workgroup
   const uint32_t o1 = min(R, o0 + EMIT_PER_BLOCK);
   const uint32_t nG = *V_dev;   // Gaussians in the depth-sorted arrays
@@ -140,12 +172,16 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
     }
     float4 q0[4], q1[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) { q0[r] = rec.geo0(gid4[r]); q1[r] = rec.geo1(gid4[r]); }
+    for (int r = 0; r < 4; r++) {
+      if (COARSE) { q0[r] = rec.rect(gid4[r]); q1[r] = q0[r]; }
+      else { q0[r] = rec.geo0(gid4[r]); q1[r] = rec.geo1(gid4[r]); }
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       key[r] = 0u; val[r] = 0u;
       if (s0 + r < o1) {
-        emit_instance(gid4[r], k4[r], q0[r], q1[r], gx, gy, key[r], val[r]);
+        if (COARSE) emit_coarse_instance(gid4[r], k4[r], q0[r], gx, key[r], val[r]);
+        else emit_instance(gid4[r], k4[r], q0[r], q1[r], gx, gy, key[r], val[r]);
         if (hist_table) atomicAdd(&s_hist[key[r] & hist_mask], 1u);
       }
     }
@@ -162,7 +198,8 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
       const uint32_t i = last_leq(offsets, lo, hi, s);
       const uint32_t g = sorted_gid[i];
       uint32_t key, val;
-      emit_instance(g, s - offsets[i], rec.geo0(g), rec.geo1(g), gx, gy, key, val);
+      if (COARSE) emit_coarse_instance(g, s - offsets[i], rec.rect(g), gx, key, val);
+      else emit_instance(g, s - offsets[i], rec.geo0(g), rec.geo1(g), gx, gy, key, val);
       tile_keys[s] = key;
       vals[s] = val;
       if (hist_table) atomicAdd(&s_hist[key & hist_mask], 1u);
@@ -178,20 +215,21 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
 // Four consecutive keys per thread (one 16-byte load + the two neighbours).
 __global__ void __launch_bounds__(256)
 tile_ranges_kernel(const uint32_t* __restrict__ R_dev, const uint32_t R_cap,
-                   const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
+                   const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges,
+                   const uint32_t key_mask /* coarse keys carry payload above the id bits */) {
   const uint32_t R = min(*R_dev, R_cap);
   const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= R) return;
   uint32_t k[6];   // k[0] = predecessor, k[1..4] = own keys, k[5] = successor
   if (i0 + 4 <= R) {
     const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);
-    k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+    k[1] = v.x & key_mask; k[2] = v.y & key_mask; k[3] = v.z & key_mask; k[4] = v.w & key_mask;
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < R ? tile_keys[i0 + j] : 0xFFFFFFFFu;
+    for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < R ? tile_keys[i0 + j] & key_mask : 0xFFFFFFFFu;
   }
-  k[0] = i0 > 0 ? tile_keys[i0 - 1] : 0xFFFFFFFFu;
-  k[5] = i0 + 4 < R ? tile_keys[i0 + 4] : 0xFFFFFFFFu;
+  k[0] = i0 > 0 ? tile_keys[i0 - 1] & key_mask : 0xFFFFFFFFu;
+  k[5] = i0 + 4 < R ? tile_keys[i0 + 4] & key_mask : 0xFFFFFFFFu;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const uint32_t i = i0 + j;
@@ -207,16 +245,27 @@ void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, ui
                  uint32_t emit_win_cap, const RecView rec, int gx, int gy, uint32_t* tile_keys,
                  uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks) {
   if (R_cap == 0) return;
-  emit_kernel<<<(R_cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK, EMIT_THREADS, 0, s>>>(
+  emit_kernel<false><<<(R_cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK, EMIT_THREADS, 0, s>>>(
       V_dev, R_dev, R_cap, sorted_gid, offsets, emit_win, emit_win_cap, rec, gx, gy, tile_keys, vals,
-      hist_table, hist_mask, nchunks);
+      hist_table, hist_mask, nchunks, nullptr, 0u);
+}
+
+void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc_dev, uint32_t cap,
+                        const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
+                        uint32_t emit_win_cap, const RecView rec, int sgx, int sgy, uint32_t* st_keys,
+                        uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks,
+                        uint2* cranges, uint32_t NS) {
+  const uint32_t grid = cap ? (cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK : 1u;   // block 0 clears the runs
+  emit_kernel<true><<<grid, EMIT_THREADS, 0, s>>>(
+      V_dev, Rc_dev, cap, sorted_gid, offsets, emit_win, emit_win_cap, rec, sgx, sgy, st_keys, vals,
+      hist_table, hist_mask, nchunks, cranges, NS);
 }
 
 void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
-                        const uint32_t* tile_keys, uint2* ranges, uint32_t T) {
+                        const uint32_t* tile_keys, uint2* ranges, uint32_t T, uint32_t key_mask) {
   // ranges were zeroed by frame_init_kernel (same stream, earlier in the frame)
   if (R_cap == 0) return;
-  tile_ranges_kernel<<<(R_cap + 1023) / 1024, 256, 0, s>>>(R_dev, R_cap, tile_keys, ranges);
+  tile_ranges_kernel<<<(R_cap + 1023) / 1024, 256, 0, s>>>(R_dev, R_cap, tile_keys, ranges, key_mask);
 }
 
 // ---------------------------------- debug / parity decoder --------------------------------
@@ -241,19 +290,23 @@ debug_geom_kernel(const int P, const RecView rec, const uint32_t* __restrict__ t
 
 __global__ void __launch_bounds__(256)
 debug_keys_kernel(const uint32_t R, const uint32_t* __restrict__ tile_keys,
+                  const uint32_t* __restrict__ tile_start, const uint32_t T,
                   const uint32_t* __restrict__ point_list, const RecView rec,
                   uint64_t* keys_sorted, uint32_t* point_list_out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
   const uint32_t g = point_list[i] & ID_MASK;
+  // hierarchical blob: the tile of instance i is the LAST tile whose start is <= i (empty tiles
+  // share their start with their successor)
+  const uint32_t tile = tile_start ? last_leq(tile_start, 0u, T - 1u, i) : tile_keys[i];
   if (keys_sorted)
-    keys_sorted[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec.geo1(g).w);
+    keys_sorted[i] = ((uint64_t)tile << 32) | (uint64_t)__float_as_uint(rec.geo1(g).w);
   if (point_list_out) point_list_out[i] = g;
 }
 
 void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
                          const RecView rec, const uint32_t* tiles, const uint32_t* tile_keys,
-                         const uint32_t* point_list, const uint2* ranges,
+                         const uint32_t* tile_start, const uint32_t* point_list, const uint2* ranges,
                          const uint32_t* n_contrib_in, uint64_t* keys_sorted,
                          uint32_t* point_list_out, uint32_t* ranges_out, uint32_t* n_contrib_out,
                          float* means2D, float* depths, float* conic_opacity, float* rgb,
@@ -262,8 +315,8 @@ void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx,
     debug_geom_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, rec, tiles, means2D, depths,
                                                       conic_opacity, rgb, tiles_out);
   if (R > 0 && (keys_sorted || point_list_out))
-    debug_keys_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, tile_keys, point_list, rec, keys_sorted,
-                                                      point_list_out);
+    debug_keys_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, tile_keys, tile_start, (uint32_t)(gx * gy),
+                                                      point_list, rec, keys_sorted, point_list_out);
   if (ranges_out)
     (void)hipMemcpyAsync(ranges_out, ranges, (size_t)gx * gy * sizeof(uint2), hipMemcpyDeviceToDevice, s);
   if (n_contrib_out)
@@ -293,6 +346,7 @@ frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint
     if (h) {
       h->magic = t == 0 ? GEOM_MAGIC : (t == 1 ? BIN_MAGIC : IMG_MAGIC);
       h->P = P; h->R = 0u; h->W = W; h->H = H; h->S = S; h->V = V_init; h->Rcap = Rcap;
+      h->Rc = 0u; h->hier = 0u;
     }
   }
 }
@@ -322,7 +376,7 @@ bin_header_kernel(BlobHeader* bin, const uint32_t P, const uint32_t Rcap, const 
   if (work && t < 4) work[t] = 0u;
   if (t == 0 && bin) {
     bin->magic = BIN_MAGIC; bin->P = P; bin->R = 0u; bin->W = W; bin->H = H; bin->S = S;
-    bin->V = 0u; bin->Rcap = Rcap;
+    bin->V = 0u; bin->Rcap = Rcap; bin->Rc = 0u; bin->hier = 0u;
   }
 }
 

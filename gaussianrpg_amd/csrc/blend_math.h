@@ -130,30 +130,46 @@ __device__ __forceinline__ bool splat_misses_rect(const float gx, const float gy
 // minimisations).  t is inflated by 1e-4 relative + 2e-3 and the extent by 1e-3 + 1e-5 |y|, far
 // above the fp32 error of these expressions; det uses Kahan's fma form, because a c and b^2
 // nearly cancel for elongated splats.
-__device__ __forceinline__ uint32_t quarter_reach_mask(const float gx, const float gy,
-                                                       const float a, const float b, const float c,
-                                                       const float opacity, const float x0,
-                                                       const float y0) {
+// The evaluation comes in three pieces, so that a caller looping over the tiles of one splat
+// (hier_binning.hip) pays for each piece once: quarter_pre depends on the splat alone, strip_extent
+// on the splat and the tile COLUMN, quarter_bits on the tile row.
+struct QuarterPre {
+  float b, ic, det, ct, xtop;   // conic b, 1/c, determinant, c t, abscissa of the upper extreme
+  bool sane, transparent;
+};
+__device__ __forceinline__ QuarterPre quarter_pre(const float a, const float b, const float c,
+                                                  const float opacity) {
+  QuarterPre q;
   float t = 2.0f * __logf(255.0f * opacity);
   t = t + 1e-4f * fabsf(t) + 2e-3f;
   const float p = b * b;
   const float det = fmaf(a, c, -p) - fmaf(b, b, -p);
-  const bool sane = (a > 0.0f) && (c > 0.0f) && (det > 0.0f) && (fabsf(t) < 3e38f) &&
-                    (fabsf(det) < 3e38f);
-  const float xl = x0 - gx, xh = xl + 15.0f;
+  q.sane = (a > 0.0f) && (c > 0.0f) && (det > 0.0f) && (fabsf(t) < 3e38f) && (fabsf(det) < 3e38f);
   const float ytop = __builtin_amdgcn_sqrtf(fmaxf(t * a * __builtin_amdgcn_rcpf(det), 0.0f));
-  const float xtop = -(b * __builtin_amdgcn_rcpf(a)) * ytop;
-  const float xet = fminf(fmaxf(xtop, xl), xh), xeb = fminf(fmaxf(-xtop, xl), xh);
-  const float ct = c * t;
-  const float dt = fmaf(-det * xet, xet, ct), db = fmaf(-det * xeb, xeb, ct);
-  const float ic = __builtin_amdgcn_rcpf(c);
-  float yup = (__builtin_amdgcn_sqrtf(fmaxf(dt, 0.0f)) - b * xet) * ic;
-  float ylo = (-__builtin_amdgcn_sqrtf(fmaxf(db, 0.0f)) - b * xeb) * ic;
+  q.xtop = -(b * __builtin_amdgcn_rcpf(a)) * ytop;
+  q.ct = c * t;
+  q.ic = __builtin_amdgcn_rcpf(c);
+  q.b = b;
+  q.det = det;
+  // alpha <= opacity, so a splat below 1/255 never passes anywhere
+  q.transparent = opacity < (1.0f / 255.0f) * 0.999f;
+  return q;
+}
+// y-extent [ylo, yup] (relative to the centre) of the ellipse over the column strip starting at x0
+__device__ __forceinline__ void strip_extent(const QuarterPre& q, const float gx, const float x0,
+                                             float& ylo, float& yup, bool& empty) {
+  const float xl = x0 - gx, xh = xl + 15.0f;
+  const float xet = fminf(fmaxf(q.xtop, xl), xh), xeb = fminf(fmaxf(-q.xtop, xl), xh);
+  const float dt = fmaf(-q.det * xet, xet, q.ct), db = fmaf(-q.det * xeb, xeb, q.ct);
+  yup = (__builtin_amdgcn_sqrtf(fmaxf(dt, 0.0f)) - q.b * xet) * q.ic;
+  ylo = (-__builtin_amdgcn_sqrtf(fmaxf(db, 0.0f)) - q.b * xeb) * q.ic;
   yup += 1e-3f + 1e-5f * fabsf(yup);
   ylo -= 1e-3f + 1e-5f * fabsf(ylo);
-  const bool empty = (dt < 0.0f) && (db < 0.0f);
-  // alpha <= opacity, so a splat below 1/255 never passes anywhere
-  const bool transparent = opacity < (1.0f / 255.0f) * 0.999f;
+  empty = (dt < 0.0f) && (db < 0.0f);
+}
+__device__ __forceinline__ uint32_t quarter_bits(const bool sane, const bool transparent,
+                                                 const float ylo, const float yup, const bool empty,
+                                                 const float gy, const float y0) {
   uint32_t m = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -162,6 +178,31 @@ __device__ __forceinline__ uint32_t quarter_reach_mask(const float gx, const flo
     m |= (hit && !transparent) ? (1u << q) : 0u;
   }
   return m;
+}
+// All 32 quarter rows of a COLUMN of 8 tiles at once (hier_binning.hip): bit k = the splat may
+// reach pixel rows Y0 + 4k .. Y0 + 4k + 3 of the strip, i.e. quarter k & 3 of tile k >> 2.  The same
+// test as quarter_bits -- band k is reached iff ylo + gy <= Y0 + 4k + 3 and yup + gy >= Y0 + 4k --
+// solved for k; the float rounding of the division is far inside the 1e-3 inflation of the extent.
+__device__ __forceinline__ uint32_t quarter_column_mask(const bool sane, const bool transparent,
+                                                        const float ylo, const float yup,
+                                                        const bool empty, const float gy,
+                                                        const float Y0) {
+  const float ya = ylo + (gy - Y0), yb = yup + (gy - Y0);
+  const int klo = max(0, (int)ceilf((ya - 3.0f) * 0.25f));
+  const int khi = min(31, (int)floorf(yb * 0.25f));
+  uint32_t m = (klo <= khi && !empty) ? (0xFFFFFFFFu >> (31 - (khi - klo))) << klo : 0u;
+  if (!sane || ya != ya || yb != yb) m = 0xFFFFFFFFu;   // never reject on doubt
+  return transparent ? 0u : m;
+}
+__device__ __forceinline__ uint32_t quarter_reach_mask(const float gx, const float gy,
+                                                       const float a, const float b, const float c,
+                                                       const float opacity, const float x0,
+                                                       const float y0) {
+  const QuarterPre q = quarter_pre(a, b, c, opacity);
+  float ylo, yup;
+  bool empty;
+  strip_extent(q, gx, x0, ylo, yup, empty);
+  return quarter_bits(q.sane, q.transparent, ylo, yup, empty, gy, y0);
 }
 
 }  // namespace grpg

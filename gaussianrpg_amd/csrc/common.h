@@ -8,6 +8,8 @@
 namespace grpg {
 
 constexpr int TILE = 16;            // cuda_rasterizer/config.h:17-18
+constexpr int STILE = 8;            // a super-tile of the hierarchical binning: STILE x STILE tiles
+constexpr int STILE_TILES = STILE * STILE;
 constexpr int WAVE = 64;            // gfx950 wavefront
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;  // depth key of a culled Gaussian (sorts last)
 
@@ -22,7 +24,8 @@ constexpr int SUBTILE_SHIFT = 28;
 //   r[0] = { px, py, opacity, bits(radius as int32) }      first 32 bytes: all that binning needs
 //   r[1] = { conic.x, conic.y, conic.z, depth(view z) }
 //   r[2] = { R, G, B, bits(clamped mask: bit0 R, bit1 G, bit2 B) }
-//   r[3] = padding (written as zeros so that preprocess stores whole sectors)
+//   r[3] = { bits(minx | maxx << 16), bits(miny | maxy << 16), 0, 0 }   the tile rectangle
+//          (half-open, as getRect computes it); zeros for a culled Gaussian
 // so that the random per-instance gathers of emit (32 B) and of render / backward (48 B) each
 // touch exactly ONE 64-byte memory sector.  A packed 48-byte record straddles two sectors in
 // half of the cases, separate arrays always cost two (measured: +68 % FETCH_SIZE in render).
@@ -38,6 +41,7 @@ struct RecView {
   __device__ __forceinline__ float4 geo0(const size_t id) const { return rec[REC_STRIDE * id]; }
   __device__ __forceinline__ float4 geo1(const size_t id) const { return rec[REC_STRIDE * id + 1]; }
   __device__ __forceinline__ float4 colour(const size_t id) const { return rec[REC_STRIDE * id + 2]; }
+  __device__ __forceinline__ float4 rect(const size_t id) const { return rec[REC_STRIDE * id + 3]; }
   __device__ __forceinline__ void load(const size_t id, float4& a, float4& b, float4& c) const {
     const float4 g0 = geo0(id), g1 = geo1(id), cc = colour(id);
     a = make_float4(g0.x, g0.y, g1.w, g0.z);
@@ -60,7 +64,10 @@ struct BlobHeader {      // first 256 bytes of every blob
   uint32_t S;
   uint32_t V;            // visible Gaussians (device-written in the geometry blob by the depth sort)
   uint32_t Rcap;         // instance capacity the binning blob was carved for (binning blob)
-  uint32_t reserved[56];
+  uint32_t Rc;           // coarse (Gaussian, super-tile) pairs (geometry blob, hierarchical binning)
+  uint32_t hier;         // binning blob: 1 = the point list came from the hierarchical path (no
+                         // sorted tile keys; tile_start[] instead)
+  uint32_t reserved[54];
 };
 static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 
@@ -113,7 +120,7 @@ static_assert(sizeof(SegmentDev) % 16 == 0, "segment table entries are read as 1
 
 struct GeomLayout {
   size_t total;
-  size_t rec, key_a, key_b, val_a, val_b, tiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
+  size_t rec, key_a, key_b, val_a, val_b, tiles, ctiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
   size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
   size_t zero_begin, zero_end;   // region frame_init clears: ds_table
@@ -122,7 +129,11 @@ struct GeomLayout {
 struct BinLayout {
   size_t total;
   size_t key_a, key_b, val_a, val_b, table, totals;
-  uint32_t nchunks_sort;
+  // hierarchical binning only (T > 0): second coarse value array, segment descriptors
+  // [max_seg] x 16 B, (first, count) of segments per super-tile, segment count, per-segment tile
+  // counts [max_seg][64], per-tile totals / starts [T], super-tile runs [NS]
+  size_t val_c, seg_desc, st_seg, nseg, seg_table, tile_tot, tile_start, cranges;
+  uint32_t nchunks_sort, nchunks_coarse, max_seg;
 };
 struct ImgLayout {
   size_t total;
@@ -141,6 +152,7 @@ inline GeomLayout geom_layout(size_t P) {
   L.val_a = take(P * 4);
   L.val_b = take(P * 4);
   L.tiles = take(P * 4);
+  L.ctiles = take(P * 4);   // super-tile counts (hierarchical binning)
   L.tiles_sorted = take(P * 4);
   L.offsets = take(P * 4);
   L.radii = take(P * 4);
@@ -159,17 +171,36 @@ inline GeomLayout geom_layout(size_t P) {
   L.total = o;
   return L;
 }
-inline BinLayout bin_layout(size_t R) {
+uint32_t hier_max_segments(uint32_t Rcap, uint32_t NS);   // hier_binning.hip
+inline uint32_t super_tiles(int gx, int gy) {
+  return (uint32_t)((gx + STILE - 1) / STILE) * (uint32_t)((gy + STILE - 1) / STILE);
+}
+// T = NS = 0: classic layout only (the offsets of the classic arrays do not depend on T / NS)
+// hierarchical: val_a holds R instances; the four coarse arrays hold Rc <= R pairs
+inline BinLayout bin_layout(size_t R, size_t T = 0, size_t NS = 0, size_t Rc = 0) {
   BinLayout L{};
   size_t o = sizeof(BlobHeader);
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  const size_t Rk = T > 0 ? Rc : R;   // entries of the key / second value arrays
   L.nchunks_sort = (uint32_t)((R + RS_CHUNK - 1) / RS_CHUNK);
+  L.nchunks_coarse = (uint32_t)((Rc + RS_CHUNK - 1) / RS_CHUNK);
   L.val_a = take(R * 4);   // == point_list after the tile sort
-  L.key_a = take(R * 4);   // == sorted tile ids
-  L.key_b = take(R * 4);
-  L.val_b = take(R * 4);
+  L.key_a = take(Rk * 4);  // == sorted tile ids
+  L.key_b = take(Rk * 4);
+  L.val_b = take(Rk * 4);
   L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);
   L.totals = take(4 * RS_MAX_RADIX * 4);
+  if (T > 0) {
+    L.max_seg = hier_max_segments((uint32_t)Rc, (uint32_t)NS);
+    L.val_c = take(Rc * 4);
+    L.seg_desc = take((size_t)L.max_seg * 16);
+    L.st_seg = take(NS * 8);
+    L.nseg = take(4);
+    L.seg_table = take((size_t)L.max_seg * STILE_TILES * 4);
+    L.tile_tot = take(T * 4);
+    L.tile_start = take(T * 4);
+    L.cranges = take(NS * 8);
+  }
   L.total = o;
   return L;
 }
@@ -198,11 +229,13 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles,
+                       uint32_t* ctiles /* super-tile counts (hierarchical binning), or NULL */,
                        uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */);
 // Composed variants (preprocess.hip): raw per-model parameters + actor poses instead of flat tensors.
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
-                                uint32_t* depth_key, uint32_t* tiles, uint32_t* ds_table0);
+                                uint32_t* depth_key, uint32_t* tiles, uint32_t* ctiles,
+                                uint32_t* ds_table0);
 void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
                     float* scales, float* rotations, float* opacities, float* shs);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
@@ -243,7 +276,28 @@ void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, ui
                  uint32_t emit_win_cap, const RecView rec, int gx, int gy, uint32_t* tile_keys,
                  uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks);
 void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
-                        const uint32_t* tile_keys, uint2* ranges, uint32_t T);
+                        const uint32_t* tile_keys, uint2* ranges, uint32_t T,
+                        uint32_t key_mask = 0xFFFFFFFFu);
+
+// Hierarchical binning (hier_binning.hip; coarse emit in binning.hip).
+void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc_dev, uint32_t cap,
+                        const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
+                        uint32_t emit_win_cap, const RecView rec, int sgx, int sgy, uint32_t* st_keys,
+                        uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks,
+                        uint2* cranges /* [NS] super-tile runs, cleared here */, uint32_t NS);
+// counts: segments, per-segment tile counts, tile ranges, num_rendered (-> *R_out, host_word[0];
+// host_word[1] = *Rc_dev); marks the binning blob's header as hierarchical
+void launch_hier_count(hipStream_t s, uint2* cranges, uint32_t NS, char* seg_desc, uint2* st_seg,
+                       uint32_t* nseg_total, uint32_t max_seg, const uint32_t* ckey_sorted,
+                       int gx, int gy, uint32_t* seg_table, uint32_t* tile_tot,
+                       uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,
+                       const uint32_t* Rc_dev, BlobHeader* bin_header, uint32_t R_cap,
+                       uint32_t coarse_cap);
+void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_total, uint32_t max_seg,
+                      const uint32_t* ckey_sorted, const uint32_t* cval_sorted, const RecView rec,
+                      int gx, int gy,
+                      const uint32_t* seg_table, const uint32_t* tile_start, uint32_t R_cap,
+                      uint32_t* point_list);
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
@@ -285,6 +339,7 @@ void launch_pack_hwc(hipStream_t s, const float* src, unsigned char* dst, size_t
 
 void launch_debug_export(hipStream_t s, int P, uint32_t R, int W, int H, int gx, int gy,
                          const RecView rec, const uint32_t* tiles, const uint32_t* tile_keys,
+                         const uint32_t* tile_start /* hierarchical blob: replaces tile_keys */,
                          const uint32_t* point_list, const uint2* ranges,
                          const uint32_t* n_contrib_in, uint64_t* keys_sorted,
                          uint32_t* point_list_out, uint32_t* ranges_out, uint32_t* n_contrib_out,

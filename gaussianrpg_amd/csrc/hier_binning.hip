@@ -1,0 +1,385 @@
+// Hierarchical tile binning for gfx950: an alternative to "emit R (tile, value) pairs + stable
+// two-pass partition" (binning.hip / sort.hip) that never materialises 8-byte pairs for the R
+// instances.  Same result, bit for bit: per tile the (depth_bits, id)-ordered list of the reference's
+// duplicateWithKeys + SortPairs + identifyTileRanges (cuda_rasterizer/rasterizer_impl.cu:70-138,
+// 306-321), `num_rendered` = sum of the tile rectangles.
+//
+//   coarse emit   one entry per (Gaussian, SUPER-TILE) -- a super-tile is 8x8 tiles -- in depth
+//                 order: Rc ~ 0.2 R entries (emit_kernel<true> in binning.hip, slot-parallel)
+//   coarse sort   stable partition of the Rc entries by super-tile id (<= 8 bits at 1920x1280:
+//                 ONE radix pass whose histogram the coarse emit leaves behind)
+//   segments      every super-tile's run is cut into segments of 1024 entries (seg_setup)
+//   count         per segment: how many of its Gaussians touch each of the super-tile's 64 tiles
+//   prefix, scan  per tile the exclusive prefix over its super-tile's segments; exclusive scan
+//                 over all tiles = the tile ranges; total = num_rendered
+//   fill          per segment and tile: the touching Gaussians, in order, go to
+//                 point_list[tile_start + segment prefix ...] with their quarter-reach mask
+//
+// Order argument: the coarse sort is stable from depth order, segments are consecutive pieces of a
+// super-tile's run, and inside a segment the entries of a tile are written in segment order: the
+// list of a tile is in (depth_bits, id) order like the sorted 64-bit keys of the reference.
+// A coarse key carries, above the super-tile id, the 8-bit column and row masks of the tiles of that
+// super-tile the Gaussian's rectangle covers: count and fill never look at the rectangle again.
+// HBM traffic: 8 B x Rc x 4 (coarse emit / partition / count, fill) + one record line per coarse
+// entry in the fill (quarter masks) + 4 B x R (the point list).
+#include "blend_math.h"
+#include "common.h"
+
+namespace grpg {
+
+constexpr int HB_SEG = 1024;        // coarse entries per segment
+constexpr int HB_CNT_THREADS = 256;
+constexpr int HB_FILL_THREADS = 512;   // 8 waves: one per tile row of the super-tile
+
+struct SegDesc { uint32_t st, begin, end, pad; };
+
+// ---- segments: cranges[st] (run of super-tile st in the sorted coarse list) -> descriptors ----
+__global__ void __launch_bounds__(1024)
+hb_seg_setup_kernel(const uint2* __restrict__ cranges, const uint32_t NS, SegDesc* __restrict__ seg,
+                    uint2* __restrict__ st_seg /* [NS] (first segment, count) */,
+                    uint32_t* __restrict__ nseg_total, const uint32_t max_seg) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < NS; base += 1024) {
+    const uint32_t st = base + tid;
+    uint2 r = make_uint2(0u, 0u);
+    if (st < NS) r = cranges[st];
+    const uint32_t ns = (r.y - r.x + HB_SEG - 1) / HB_SEG;
+    uint32_t inc = ns;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= (uint32_t)d) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t before = s_carry;
+    for (uint32_t w = 0; w < wave; w++) before += s_w[w];
+    if (st < NS) st_seg[st] = make_uint2(before + inc - ns, ns);
+    __syncthreads();
+    if (tid == 1023) s_carry = before + inc;
+    __syncthreads();
+  }
+  const uint32_t total = min(s_carry, max_seg);
+  if (tid == 0) *nseg_total = total;
+  __threadfence_block();
+  __syncthreads();
+  // descriptors, one thread per segment: the super-tile is the LAST one whose first segment is
+  // <= the segment's index (super-tiles without segments share their first index with a successor)
+  for (uint32_t q = tid; q < total; q += 1024) {
+    uint32_t lo = 0, hi = NS - 1;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo + 1) / 2;
+      if (st_seg[mid].x <= q) lo = mid; else hi = mid - 1;
+    }
+    const uint2 r = cranges[lo];
+    const uint32_t k = q - st_seg[lo].x;
+    SegDesc d;
+    d.st = lo; d.begin = r.x + k * HB_SEG; d.end = min(r.y, r.x + (k + 1) * HB_SEG); d.pad = 0u;
+    seg[q] = d;
+  }
+}
+
+// ---- count: table[seg][64] = Gaussians of the segment touching each tile of its super-tile ----
+__global__ void __launch_bounds__(HB_CNT_THREADS)
+hb_count_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nseg_total,
+                const uint32_t* __restrict__ ckey, uint32_t* __restrict__ table) {
+  __shared__ uint16_t s_m[HB_SEG];
+  const uint32_t sid = blockIdx.x;
+  if (sid >= *nseg_total) return;
+  const SegDesc d = seg[sid];
+  const uint32_t n = d.end - d.begin;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < HB_SEG / HB_CNT_THREADS; i++) {
+    const uint32_t e = i * HB_CNT_THREADS + tid;
+    s_m[e] = e < n ? (uint16_t)(ckey[d.begin + e] >> 16) : (uint16_t)0;
+  }
+  __syncthreads();
+  // wave w counts tile rows 2w and 2w+1: every lane walks 16 entries and keeps the 8 column
+  // counters of a row as bytes of two words (a lane adds at most 16: no overflow)
+#pragma unroll
+  for (int rr = 0; rr < 2; rr++) {
+    const int row = (int)wave * 2 + rr;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 0; r < HB_SEG / WAVE; r++) {
+      const uint32_t m = s_m[r * WAVE + lane];
+      const uint32_t cm = ((m >> (8 + row)) & 1u) ? (m & 0xFFu) : 0u;
+      lo += ((cm & 0xFu) * 0x00204081u) & 0x01010101u;          // bits 0-3 -> bytes 0-3
+      hi += (((cm >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;   // bits 4-7 -> bytes 0-3
+    }
+#pragma unroll
+    for (int tx = 0; tx < STILE; tx++) {
+      uint32_t c = ((tx < 4 ? lo : hi) >> (8 * (tx & 3))) & 0xFFu;
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) c += (uint32_t)__shfl_xor((int)c, s, 64);
+      if ((int)lane == tx) table[(size_t)sid * STILE_TILES + row * STILE + tx] = c;
+    }
+  }
+}
+
+// ---- per tile: exclusive prefix over the segments of its super-tile (in place) + tile total ----
+// One workgroup per super-tile, lane = tile; the 16 waves each take a contiguous share of the
+// segments (sum it, exchange, then write the prefixes): a super-tile with hundreds of segments
+// costs a few dependent batches, not hundreds of dependent loads.
+__global__ void __launch_bounds__(1024)
+hb_tile_prefix_kernel(const uint2* __restrict__ st_seg, uint32_t* __restrict__ table, const int sgx,
+                      const int gx, const int gy, uint32_t* __restrict__ tile_tot) {
+  __shared__ uint32_t s_part[16][STILE_TILES];
+  const uint32_t st = blockIdx.x, l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2 sg = st_seg[st];
+  const uint32_t per = (sg.y + 15u) / 16u;
+  const uint32_t q0 = min(sg.y, wave * per), q1 = min(sg.y, q0 + per);
+  uint32_t sum = 0;
+  for (uint32_t q = q0; q < q1; q++) sum += table[(size_t)(sg.x + q) * STILE_TILES + l];
+  s_part[wave][l] = sum;
+  __syncthreads();
+  uint32_t run = 0, tot = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; w++) {
+    const uint32_t v = s_part[w][l];
+    if (w < wave) run += v;
+    tot += v;
+  }
+  for (uint32_t qb = q0; qb < q1; qb += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++)
+      v[j] = qb + j < q1 ? table[(size_t)(sg.x + qb + j) * STILE_TILES + l] : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      if (qb + j < q1) table[(size_t)(sg.x + qb + j) * STILE_TILES + l] = run;
+      run += v[j];
+    }
+  }
+  if (wave == 0) {
+    const int sy = (int)(st / (uint32_t)sgx), sx = (int)(st - (uint32_t)sy * (uint32_t)sgx);
+    const int tx = sx * STILE + (int)(l & 7u), ty = sy * STILE + (int)(l >> 3);
+    if (tx < gx && ty < gy) tile_tot[(size_t)ty * gx + tx] = tot;
+  }
+}
+
+// ---- exclusive scan over all tiles -> ranges (untouched tiles stay (0,0) like the reference's
+// memset + identifyTileRanges), monotone tile_start[] for the fill, num_rendered ----
+__global__ void __launch_bounds__(1024)
+hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
+                    uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
+                    uint32_t* __restrict__ R_out, uint32_t* __restrict__ host_word,
+                    const uint32_t* __restrict__ Rc_dev, BlobHeader* __restrict__ bin_header,
+                    const uint32_t R_cap, const uint32_t coarse_cap) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  constexpr int PER = 10;   // 10240 tiles per sweep: one sweep at 1920x1280
+  for (uint32_t base = 0; base < T; base += 1024 * PER) {
+    uint32_t v[PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const uint32_t t = base + tid * PER + k;
+      v[k] = t < T ? tile_tot[t] : 0u;
+      s += v[k];
+    }
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(inc, d, 64);
+      if (lane >= (uint32_t)d) inc += u;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t ex = s_carry + inc - s;
+    for (uint32_t w = 0; w < wave; w++) ex += s_w[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const uint32_t t = base + tid * PER + k;
+      if (t < T) {
+        tile_start[t] = ex;
+        // clamped to the point list's capacity: on an overflow the frame's tail is redone, but
+        // the render enqueued behind this launch must stay inside the list
+        ranges[t] = v[k] ? make_uint2(min(ex, R_cap), min(ex + v[k], R_cap)) : make_uint2(0u, 0u);
+      }
+      ex += v[k];
+    }
+    __syncthreads();
+    if (tid == 1023) s_carry = ex;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *R_out = s_carry;
+    if (bin_header) { bin_header->hier = 1u; bin_header->Rc = coarse_cap; }
+    if (host_word) { host_word[0] = s_carry; host_word[1] = Rc_dev ? *Rc_dev : 0u; }
+  }
+}
+
+// ---- fill ----
+// Ids, masks and the splat-only part of the quarter-reach test of a segment go to LDS (one record
+// line per entry).  Wave w owns tile COLUMN w of the super-tile: it compacts the entries whose
+// rectangle reaches the column (in order), then walks that list 64 entries at a time: the y-extent
+// of the splat over the column strip is evaluated once, and for each of the column's 8 tiles the
+// lanes whose entry covers the tile derive the quarter mask from it and store to consecutive
+// positions of the tile's list (ballot prefix).
+// Workgroups are persistent and walk the segments with a stride: the descriptor and the (key, id)
+// pairs of the NEXT segment are fetched while the current one is processed, so a segment exposes
+// one memory round trip (the record gather) instead of three.
+__global__ void __launch_bounds__(HB_FILL_THREADS)
+hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nseg_total,
+               const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cval, const RecView rec,
+               const int sgx, const int gx, const int gy, const uint32_t* __restrict__ table,
+               const uint32_t* __restrict__ tile_start, const uint32_t R_cap,
+               uint32_t* __restrict__ point_list) {
+  __shared__ uint32_t s_gid[HB_SEG];
+  __shared__ uint16_t s_m[HB_SEG];
+  __shared__ uint8_t s_fl[HB_SEG];       // bit 0: sane, bit 1: transparent
+  __shared__ float2 s_xy[HB_SEG];        // px, py
+  __shared__ float2 s_bi[HB_SEG];        // conic b, 1 / conic c
+  __shared__ float2 s_dc[HB_SEG];        // det, c t
+  __shared__ float s_xt[HB_SEG];         // xtop
+  __shared__ uint16_t s_col[STILE][HB_SEG];   // per wave: entries reaching its column
+  constexpr int ITEMS = HB_SEG / HB_FILL_THREADS;   // 2
+  const uint32_t nseg = *nseg_total;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const int col = (int)wave;
+  uint16_t* coll = s_col[wave];
+  uint32_t sid = blockIdx.x;
+  if (sid >= nseg) return;
+  SegDesc d = seg[sid];
+  uint32_t gid[ITEMS], key[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t e = i * HB_FILL_THREADS + tid;
+    const bool on = e < d.end - d.begin;
+    gid[i] = on ? cval[d.begin + e] : 0u;
+    key[i] = on ? ckey[d.begin + e] : 0u;
+  }
+  while (true) {
+    const uint32_t n = d.end - d.begin;
+    const int sy = (int)(d.st / (uint32_t)sgx), sx = (int)(d.st - (uint32_t)sy * (uint32_t)sgx);
+    const int tx = sx * STILE + col;
+    float4 g0[ITEMS], g1[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) { g0[i] = rec.geo0(gid[i]); g1[i] = rec.geo1(gid[i]); }
+    // running output position of each of the column's tiles (independent of the gather)
+    uint32_t out[STILE];
+    {
+      const int txc = min(tx, gx - 1);
+#pragma unroll
+      for (int r = 0; r < STILE; r++) {
+        const int ty = min(sy * STILE + r, gy - 1);
+        out[r] = tile_start[(uint32_t)ty * (uint32_t)gx + (uint32_t)txc] +
+                 table[(size_t)sid * STILE_TILES + r * STILE + col];
+      }
+    }
+    const uint32_t sid_next = sid + gridDim.x;
+    const bool more = sid_next < nseg;
+    SegDesc dn = d;
+    if (more) dn = seg[sid_next];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const uint32_t e = i * HB_FILL_THREADS + tid;
+      const QuarterPre q = quarter_pre(g1[i].x, g1[i].y, g1[i].z, g0[i].z);
+      s_gid[e] = gid[i];
+      s_m[e] = (uint16_t)(key[i] >> 16);      // entries beyond n carry mask 0
+      s_fl[e] = (uint8_t)((q.sane ? 1u : 0u) | (q.transparent ? 2u : 0u));
+      s_xy[e] = make_float2(g0[i].x, g0[i].y);
+      s_bi[e] = make_float2(q.b, q.ic);
+      s_dc[e] = make_float2(q.det, q.ct);
+      s_xt[e] = q.xtop;
+    }
+    __syncthreads();
+    // the next segment's pairs travel while this one is processed
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < ITEMS; i++) {
+        const uint32_t e = i * HB_FILL_THREADS + tid;
+        const bool on = e < dn.end - dn.begin;
+        gid[i] = on ? cval[dn.begin + e] : 0u;
+        key[i] = on ? ckey[dn.begin + e] : 0u;
+      }
+    }
+    if (tx < gx) {
+      const uint32_t nround = (n + WAVE - 1) / WAVE;
+      uint32_t ncol = 0;
+      for (uint32_t r = 0; r < nround; r++) {
+        const uint32_t e = r * WAVE + lane;
+        const bool hit = (s_m[e] >> col) & 1u;
+        const uint64_t m = __ballot(hit);
+        if (hit) coll[ncol + (uint32_t)__popcll(m & lt)] = (uint16_t)e;
+        ncol += (uint32_t)__popcll(m);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float tile_x = (float)(tx * TILE), super_y = (float)(sy * STILE * TILE);
+      for (uint32_t i0 = 0; i0 < ncol; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < ncol;
+        const uint32_t e = valid ? coll[i] : 0u;
+        const uint32_t rm = valid ? (uint32_t)s_m[e] >> 8 : 0u;
+        const uint32_t g = s_gid[e];
+        const uint32_t fl = s_fl[e];
+        const float2 xy = s_xy[e], bi = s_bi[e], dc = s_dc[e];
+        QuarterPre q;
+        q.b = bi.x; q.ic = bi.y; q.det = dc.x; q.ct = dc.y; q.xtop = s_xt[e];
+        q.sane = fl & 1u; q.transparent = fl & 2u;
+        float ylo, yup;
+        bool empty;
+        strip_extent(q, xy.x, tile_x, ylo, yup, empty);
+        // quarter masks of the column's 8 tiles, 4 bits each
+        const uint32_t qm = quarter_column_mask(q.sane, q.transparent, ylo, yup, empty, xy.y, super_y);
+#pragma unroll
+        for (int r = 0; r < STILE; r++) {
+          const bool hit = (rm >> r) & 1u;
+          const uint64_t m = __ballot(hit);
+          if (m == 0ull) continue;       // wave-uniform (also skips rows beyond the grid: mask 0)
+          if (hit) {
+            const uint32_t bits = (qm >> (4 * r)) & 15u;
+            const uint32_t pos = out[r] + (uint32_t)__popcll(m & lt);
+            if (pos < R_cap) point_list[pos] = g | (bits << SUBTILE_SHIFT);
+          }
+          out[r] += (uint32_t)__popcll(m);
+        }
+      }
+    }
+    if (!more) break;
+    sid = sid_next;
+    d = dn;
+    __syncthreads();   // LDS is refilled
+  }
+}
+
+void launch_hier_count(hipStream_t s, uint2* cranges, uint32_t NS, char* seg_desc, uint2* st_seg,
+                       uint32_t* nseg_total, uint32_t max_seg, const uint32_t* ckey_sorted,
+                       int gx, int gy, uint32_t* seg_table, uint32_t* tile_tot,
+                       uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,
+                       const uint32_t* Rc_dev, BlobHeader* bin_header, uint32_t R_cap,
+                       uint32_t coarse_cap) {
+  const int sgx = (gx + STILE - 1) / STILE;
+  const uint32_t T = (uint32_t)gx * (uint32_t)gy;
+  SegDesc* seg = (SegDesc*)seg_desc;
+  hb_seg_setup_kernel<<<1, 1024, 0, s>>>(cranges, NS, seg, st_seg, nseg_total, max_seg);
+  hb_count_kernel<<<max_seg, HB_CNT_THREADS, 0, s>>>(seg, nseg_total, ckey_sorted, seg_table);
+  hb_tile_prefix_kernel<<<NS, 1024, 0, s>>>(st_seg, seg_table, sgx, gx, gy, tile_tot);
+  hb_tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_tot, tile_start, ranges, R_out, host_word, Rc_dev,
+                                         bin_header, R_cap, coarse_cap);
+}
+
+void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_total, uint32_t max_seg,
+                      const uint32_t* ckey_sorted, const uint32_t* cval_sorted, const RecView rec,
+                      int gx, int gy, const uint32_t* seg_table, const uint32_t* tile_start,
+                      uint32_t R_cap, uint32_t* point_list) {
+  const int sgx = (gx + STILE - 1) / STILE;
+  // persistent workgroups: 3 fit a CU (LDS), 256 CUs
+  const uint32_t grid = max_seg < 768u ? max_seg : 768u;
+  hb_fill_kernel<<<grid, HB_FILL_THREADS, 0, s>>>((const SegDesc*)seg_desc, nseg_total, ckey_sorted,
+                                                     cval_sorted, rec, sgx, gx, gy, seg_table, tile_start,
+                                                     R_cap, point_list);
+}
+
+uint32_t hier_max_segments(uint32_t Rcap, uint32_t NS) { return Rcap / HB_SEG + NS + 1; }
+
+}  // namespace grpg

@@ -621,4 +621,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     if (grpg_set_binning_mode(mode) != GRPG_OK) raise_abi_error("grpg_set_binning_mode", -1);
   });
   m.def("reset_capacity_hints", []() { grpg_reset_capacity_hints(); });
+  m.def("get_binning_algorithm", []() { return grpg_get_binning_algorithm(); });
 }

@@ -214,6 +214,14 @@ GRPG_API int grpg_set_binning_mode(int mode);
 /* Forget the remembered num_rendered high-water marks (the next grpg_forward of every shape waits
  * for the count before it sizes the binning blob). */
 GRPG_API int grpg_reset_capacity_hints(void);
+/* Tile binning algorithm of grpg_forward, fixed at load time: GRPG_BINNING_ALG_HIER (default;
+ * csrc/hier_binning.hip: coarse (Gaussian, 8x8-tile super-tile) pairs partitioned by super-tile,
+ * then per-tile counts and a direct fill of the point list) or GRPG_BINNING_ALG_SORT (environment
+ * GRPG_BINNING=sort; csrc/binning.hip + sort.hip: one (tile, value) pair per instance, stably
+ * partitioned by tile).  Both produce the same point list and tile ranges, bit for bit. */
+#define GRPG_BINNING_ALG_SORT 0
+#define GRPG_BINNING_ALG_HIER 1
+GRPG_API int grpg_get_binning_algorithm(void);
 
 /*
  * Rasterizer::backward  (rasterizer.h:60-96, rasterizer_impl.cu:396-505).
@@ -304,7 +312,9 @@ GRPG_API int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, 
  * over those calls into stage_ms_sum[GRPG_NUM_STAGES] and their count into *num_calls, then
  * forgets them.  Stages: 0 frame init + preprocess, 1 depth sort, 2 offsets scan (+ in exact mode
  * the wait for num_rendered and the binning-blob allocation), 3 instance emit, 4 tile sort, 5 tile ranges, 6 render,
- * 7 semantic render.  enabled == 2 records only the two events around the render stage (the
+ * 7 semantic render.  With the hierarchical binning slots 2-5 hold: 2 scan over the super-tile
+ * counts, 3 coarse emit, 4 coarse partition + super-tile runs, 5 segment counts, tile ranges and
+ * the point-list fill.  enabled == 2 records only the two events around the render stage (the
  * cheap mode for a timed region: 2 event records per call instead of 9).
  */
 #define GRPG_NUM_STAGES 8

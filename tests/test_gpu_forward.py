@@ -370,13 +370,17 @@ def test_streams_and_threads_give_identical_frames(dev):
 @pytest.mark.parametrize("env", [{"GRPG_RENDER_PC": "0"}, {"GRPG_PC_MUL": "1"},
                                  {"GRPG_RENDER_VARIANT": "1", "GRPG_HEAVY_MIN": "64"},
                                  {"GRPG_DEPTH_SORT": "classic"}, {"GRPG_SYNC_R": "1"},
-                                 {"GRPG_RCAP_TEST": "3000"}])
+                                 {"GRPG_RCAP_TEST": "3000"}, {"GRPG_RCAP_TEST": "3000:3000000"},
+                                 {"GRPG_BINNING": "sort"},
+                                 {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"}])
 def test_alternative_code_paths(env):
     """The experiment switches are read once per process, so the parity cases are re-run in a
     subprocess: no producer/consumer pairs; pairs for EVERY heavy tile; light path with one splat
     per iteration and a low heavy threshold; the classic three-kernel depth-sort passes; the
     reference-like mid-frame wait for num_rendered (exact binning-blob size); a binning capacity
-    guess of 3000 instances, so that every frame overflows it and re-runs its tail."""
+    guess of 3000 instances, so that every frame overflows it and re-runs its tail (hierarchical
+    binning: first with the coarse list overflowing too, then with only the point list); the sort-based
+    binning (emit + stable partition) instead of the hierarchical one, also with overflows."""
     import os
     import subprocess
     import sys

@@ -1,7 +1,7 @@
 # quick A/B of the frame loop: bash tools/gpu_ab.sh tag [ENV=val ...]   (one bench line per call)
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
-env "$@" timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err
+env "$@" timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery ${AB_ARGS:-} > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err
 python - gpurun_out/ab_$tag.json <<'PY'
 import json,sys
 try:

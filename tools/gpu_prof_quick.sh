@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -o stats -- \
-    python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery \
+    python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery ${PROF_ARGS:-} \
     > $OUT/prof_${tag}_bench.json 2> $OUT/prof_$tag.err
 echo "prof $tag rc=$?"
 f=$(find $OUT/prof_$tag -name "*kernel_stats.csv" | head -1)
