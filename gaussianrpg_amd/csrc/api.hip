@@ -394,10 +394,11 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
                       (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
                       geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
-    uint32_t* ctiles = hier ? (uint32_t*)(geom + GL.ctiles) : nullptr;
+    uint2* rects = hier ? (uint2*)(geom + GL.rects) : nullptr;
+    uint2* rect_sorted = (uint2*)(geom + GL.rect_sorted);
     if (segs == nullptr) {
       launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                        cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles, ctiles,
+                        cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles, rects,
                         fat_sort ? ds_table : nullptr);
     } else {
       // segment table: host structs -> pinned staging -> the geometry blob (asynchronous copy)
@@ -421,7 +422,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)nseg,
                              hipMemcpyHostToDevice, stream));
       launch_preprocess_composed(stream, P, D, M, seg_dev, nseg, scale_modifier, cam, radii_int, rec_w,
-                                 key_a, tiles, ctiles, fat_sort ? ds_table : nullptr);
+                                 key_a, tiles, rects, fat_sort ? ds_table : nullptr);
     }
     STAGE_CHECK("preprocess");
     tm.mark(1);
@@ -520,12 +521,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       uint32_t* btotals = (uint32_t*)(binp + L.totals);
       uint2* cranges = (uint2*)(binp + L.cranges);
       tm.mark(2);
-      launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, sorted_gid, ctiles, offsets,
-                          block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap);
+      launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, sorted_gid, nullptr, offsets,
+                          block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap, rects,
+                          rect_sorted);
       STAGE_CHECK("coarse offsets scan");
       tm.mark(3);
-      launch_emit_coarse(stream, &gh->V, &gh->Rc, ccap, sorted_gid, offsets, emit_win, GL.emit_win_cap,
-                         rec, sgx, sgy, ckey_a, cval_a, cpasses > 0 ? btable : nullptr,
+      launch_emit_coarse(stream, &gh->V, &gh->Rc, ccap, sorted_gid, rect_sorted, offsets, emit_win,
+                         GL.emit_win_cap, sgx, sgy, ckey_a, cval_a, cpasses > 0 ? btable : nullptr,
                          (1u << cbits0) - 1u, L.nchunks_coarse, cranges, NS);
       STAGE_CHECK("coarse emit");
       tm.mark(4);
@@ -535,11 +537,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                                 btable, btotals, L.nchunks_coarse, true);
       STAGE_CHECK("coarse partition");
       const uint32_t* ckey = in_b ? ckey_b : ckey_a;
-      launch_tile_ranges(stream, &gh->Rc, ccap, ckey, cranges, NS, 0xFFFFu);
+      // one pass (<= 256 super-tiles): its digit totals ARE the run lengths; otherwise find the runs
+      const bool runs_from_totals = cpasses == 1 && ccap > 0;
+      if (!runs_from_totals) launch_tile_ranges(stream, &gh->Rc, ccap, ckey, cranges, NS, 0xFFFFu);
       STAGE_CHECK("super-tile runs");
       tm.mark(5);
       const uint32_t* cval = in_b ? cval_b : cval_a;
-      launch_hier_count(stream, cranges, NS, binp + L.seg_desc, (uint2*)(binp + L.st_seg),
+      launch_hier_count(stream, cranges, runs_from_totals ? btotals : nullptr, NS, binp + L.seg_desc, (uint2*)(binp + L.st_seg),
                         (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
                         (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
                         (uint32_t*)(binp + L.tile_start), ranges, &gh->R, publish ? hw->dev_ptr : nullptr,

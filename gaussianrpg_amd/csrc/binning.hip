@@ -68,10 +68,10 @@ __device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k
 // Coarse instance (hierarchical binning, hier_binning.hip): slot k of Gaussian g's SUPER-TILE
 // rectangle (row-major) -> key = super-tile id | local column mask << 16 | local row mask << 24
 // (the tiles of that super-tile the rectangle covers; the coarse partition sorts on the id bits
-// only), value = g.  r3 = the packed tile rectangle of the record.
-__device__ __forceinline__ void emit_coarse_instance(const uint32_t g, const uint32_t k, const float4 r3,
+// only), value = g.  rc = the packed tile rectangle.
+__device__ __forceinline__ void emit_coarse_instance(const uint32_t g, const uint32_t k, const uint2 rc,
                                                      const int sgx, uint32_t& key, uint32_t& val) {
-  const uint32_t rx = __float_as_uint(r3.x), ry = __float_as_uint(r3.y);
+  const uint32_t rx = rc.x, ry = rc.y;
   const int minx = (int)(rx & 0xFFFFu), maxx = (int)(rx >> 16);
   const int miny = (int)(ry & 0xFFFFu), maxy = (int)(ry >> 16);
   const uint32_t sx0 = (uint32_t)minx / STILE, sx1 = ((uint32_t)maxx + STILE - 1) / STILE;
@@ -91,13 +91,15 @@ __device__ __forceinline__ void emit_coarse_instance(const uint32_t g, const uin
 }
 
 // COARSE: the slots are (Gaussian, super-tile) pairs -- `offsets` is the scan over the super-tile
-// counts, gx = super-tiles per row -- and only the packed rectangle of the record is read.
+// counts, gx = super-tiles per row -- and instead of the records the packed tile rectangles are
+// read, which the scan left behind in depth order (no dependent gather).
 template <bool COARSE>
 __global__ void __launch_bounds__(EMIT_THREADS)
 emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_dev,
             const uint32_t R_cap, const uint32_t* __restrict__ sorted_gid,
             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ emit_win,
-            const uint32_t emit_win_cap, const RecView rec, const int gx, const int gy,
+            const uint32_t emit_win_cap, const RecView rec,
+            const uint2* __restrict__ rect_sorted /* COARSE only */, const int gx, const int gy,
             uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals,
             uint32_t* __restrict__ hist_table /* [digit][nchunks], may be NULL */,
             const uint32_t hist_mask, const uint32_t nchunks,
@@ -162,25 +164,27 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
     const uint32_t s0 = o0 + 4 * tid;
     // the dependent loads (owner id -> its record) of the thread's 4 slots are issued together:
     // two memory round trips per thread instead of eight
-    uint32_t gid4[4], k4[4];
+    uint32_t gid4[4], k4[4], j4[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const uint32_t j = max(own[r], before);
       const bool on = s0 + r < o1;
+      j4[r] = j;
       gid4[r] = on ? sorted_gid[lo + j] : 0u;
       k4[r] = s0 + r - s_off[j];
     }
     float4 q0[4], q1[4];
+    uint2 rc4[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      if (COARSE) { q0[r] = rec.rect(gid4[r]); q1[r] = q0[r]; }
+      if (COARSE) { rc4[r] = (s0 + r < o1) ? rect_sorted[lo + j4[r]] : make_uint2(0u, 0u); }
       else { q0[r] = rec.geo0(gid4[r]); q1[r] = rec.geo1(gid4[r]); }
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       key[r] = 0u; val[r] = 0u;
       if (s0 + r < o1) {
-        if (COARSE) emit_coarse_instance(gid4[r], k4[r], q0[r], gx, key[r], val[r]);
+        if (COARSE) emit_coarse_instance(gid4[r], k4[r], rc4[r], gx, key[r], val[r]);
         else emit_instance(gid4[r], k4[r], q0[r], q1[r], gx, gy, key[r], val[r]);
         if (hist_table) atomicAdd(&s_hist[key[r] & hist_mask], 1u);
       }
@@ -198,7 +202,7 @@ emit_kernel(const uint32_t* __restrict__ V_dev, const uint32_t* __restrict__ R_d
       const uint32_t i = last_leq(offsets, lo, hi, s);
       const uint32_t g = sorted_gid[i];
       uint32_t key, val;
-      if (COARSE) emit_coarse_instance(g, s - offsets[i], rec.rect(g), gx, key, val);
+      if (COARSE) emit_coarse_instance(g, s - offsets[i], rect_sorted[i], gx, key, val);
       else emit_instance(g, s - offsets[i], rec.geo0(g), rec.geo1(g), gx, gy, key, val);
       tile_keys[s] = key;
       vals[s] = val;
@@ -246,19 +250,19 @@ void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, ui
                  uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks) {
   if (R_cap == 0) return;
   emit_kernel<false><<<(R_cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK, EMIT_THREADS, 0, s>>>(
-      V_dev, R_dev, R_cap, sorted_gid, offsets, emit_win, emit_win_cap, rec, gx, gy, tile_keys, vals,
-      hist_table, hist_mask, nchunks, nullptr, 0u);
+      V_dev, R_dev, R_cap, sorted_gid, offsets, emit_win, emit_win_cap, rec, nullptr, gx, gy, tile_keys,
+      vals, hist_table, hist_mask, nchunks, nullptr, 0u);
 }
 
 void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc_dev, uint32_t cap,
-                        const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
-                        uint32_t emit_win_cap, const RecView rec, int sgx, int sgy, uint32_t* st_keys,
+                        const uint32_t* sorted_gid, const uint2* rect_sorted, const uint32_t* offsets,
+                        const uint32_t* emit_win, uint32_t emit_win_cap, int sgx, int sgy, uint32_t* st_keys,
                         uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks,
                         uint2* cranges, uint32_t NS) {
   const uint32_t grid = cap ? (cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK : 1u;   // block 0 clears the runs
   emit_kernel<true><<<grid, EMIT_THREADS, 0, s>>>(
-      V_dev, Rc_dev, cap, sorted_gid, offsets, emit_win, emit_win_cap, rec, sgx, sgy, st_keys, vals,
-      hist_table, hist_mask, nchunks, cranges, NS);
+      V_dev, Rc_dev, cap, sorted_gid, offsets, emit_win, emit_win_cap, RecView{nullptr}, rect_sorted, sgx,
+      sgy, st_keys, vals, hist_table, hist_mask, nchunks, cranges, NS);
 }
 
 void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,

@@ -24,8 +24,7 @@ constexpr int SUBTILE_SHIFT = 28;
 //   r[0] = { px, py, opacity, bits(radius as int32) }      first 32 bytes: all that binning needs
 //   r[1] = { conic.x, conic.y, conic.z, depth(view z) }
 //   r[2] = { R, G, B, bits(clamped mask: bit0 R, bit1 G, bit2 B) }
-//   r[3] = { bits(minx | maxx << 16), bits(miny | maxy << 16), 0, 0 }   the tile rectangle
-//          (half-open, as getRect computes it); zeros for a culled Gaussian
+//   r[3] = padding (written as zeros so that preprocess stores whole sectors)
 // so that the random per-instance gathers of emit (32 B) and of render / backward (48 B) each
 // touch exactly ONE 64-byte memory sector.  A packed 48-byte record straddles two sectors in
 // half of the cases, separate arrays always cost two (measured: +68 % FETCH_SIZE in render).
@@ -41,7 +40,6 @@ struct RecView {
   __device__ __forceinline__ float4 geo0(const size_t id) const { return rec[REC_STRIDE * id]; }
   __device__ __forceinline__ float4 geo1(const size_t id) const { return rec[REC_STRIDE * id + 1]; }
   __device__ __forceinline__ float4 colour(const size_t id) const { return rec[REC_STRIDE * id + 2]; }
-  __device__ __forceinline__ float4 rect(const size_t id) const { return rec[REC_STRIDE * id + 3]; }
   __device__ __forceinline__ void load(const size_t id, float4& a, float4& b, float4& c) const {
     const float4 g0 = geo0(id), g1 = geo1(id), cc = colour(id);
     a = make_float4(g0.x, g0.y, g1.w, g0.z);
@@ -120,7 +118,7 @@ static_assert(sizeof(SegmentDev) % 16 == 0, "segment table entries are read as 1
 
 struct GeomLayout {
   size_t total;
-  size_t rec, key_a, key_b, val_a, val_b, tiles, ctiles, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
+  size_t rec, key_a, key_b, val_a, val_b, tiles, rects, rect_sorted, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
   size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
   size_t zero_begin, zero_end;   // region frame_init clears: ds_table
@@ -152,7 +150,8 @@ inline GeomLayout geom_layout(size_t P) {
   L.val_a = take(P * 4);
   L.val_b = take(P * 4);
   L.tiles = take(P * 4);
-  L.ctiles = take(P * 4);   // super-tile counts (hierarchical binning)
+  L.rects = take(P * 8);        // packed tile rectangles by id (hierarchical binning)
+  L.rect_sorted = take(P * 8);  // ... of the visible Gaussians in depth order
   L.tiles_sorted = take(P * 4);
   L.offsets = take(P * 4);
   L.radii = take(P * 4);
@@ -172,6 +171,11 @@ inline GeomLayout geom_layout(size_t P) {
   return L;
 }
 uint32_t hier_max_segments(uint32_t Rcap, uint32_t NS);   // hier_binning.hip
+// super-tiles a packed tile rectangle (x = minx | maxx << 16, y likewise, half-open) reaches
+__host__ __device__ inline uint32_t rect_super_tiles(const uint32_t rx, const uint32_t ry) {
+  const uint32_t minx = rx & 0xFFFFu, maxx = rx >> 16, miny = ry & 0xFFFFu, maxy = ry >> 16;
+  return ((maxx + STILE - 1) / STILE - minx / STILE) * ((maxy + STILE - 1) / STILE - miny / STILE);
+}
 inline uint32_t super_tiles(int gx, int gy) {
   return (uint32_t)((gx + STILE - 1) / STILE) * (uint32_t)((gy + STILE - 1) / STILE);
 }
@@ -229,12 +233,12 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles,
-                       uint32_t* ctiles /* super-tile counts (hierarchical binning), or NULL */,
+                       uint2* rects /* packed tile rectangles (hierarchical binning), or NULL */,
                        uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */);
 // Composed variants (preprocess.hip): raw per-model parameters + actor poses instead of flat tensors.
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
-                                uint32_t* depth_key, uint32_t* tiles, uint32_t* ctiles,
+                                uint32_t* depth_key, uint32_t* tiles, uint2* rects,
                                 uint32_t* ds_table0);
 void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
                     float* scales, float* rotations, float* opacities, float* shs);
@@ -264,12 +268,15 @@ void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a,
 
 // offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total_out (device) = sum, also stored
 // to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.  gather_gid != NULL:
-// tiles_sorted is first filled with tiles_by_id[gather_gid[i]].
+// tiles_sorted is first filled with tiles_by_id[gather_gid[i]].  rects_by_id != NULL (hierarchical
+// binning): the counts are the SUPER-TILE counts of the gathered rectangles instead, and the
+// rectangles are left behind in sorted order in rect_sorted.
 void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
                          uint32_t* tiles_sorted, const uint32_t* gather_gid,
                          const uint32_t* tiles_by_id, uint32_t* offsets, uint32_t* block_sums,
                          uint32_t nblocks, uint32_t* total_out, uint32_t* total_host,
-                         uint32_t* emit_win, uint32_t emit_win_cap);
+                         uint32_t* emit_win, uint32_t emit_win_cap,
+                         const uint2* rects_by_id = nullptr, uint2* rect_sorted = nullptr);
 
 void launch_emit(hipStream_t s, const uint32_t* V_dev, const uint32_t* R_dev, uint32_t R_cap,
                  const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
@@ -281,13 +288,16 @@ void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
 
 // Hierarchical binning (hier_binning.hip; coarse emit in binning.hip).
 void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc_dev, uint32_t cap,
-                        const uint32_t* sorted_gid, const uint32_t* offsets, const uint32_t* emit_win,
-                        uint32_t emit_win_cap, const RecView rec, int sgx, int sgy, uint32_t* st_keys,
+                        const uint32_t* sorted_gid, const uint2* rect_sorted, const uint32_t* offsets,
+                        const uint32_t* emit_win, uint32_t emit_win_cap, int sgx, int sgy, uint32_t* st_keys,
                         uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask, uint32_t nchunks,
                         uint2* cranges /* [NS] super-tile runs, cleared here */, uint32_t NS);
 // counts: segments, per-segment tile counts, tile ranges, num_rendered (-> *R_out, host_word[0];
 // host_word[1] = *Rc_dev); marks the binning blob's header as hierarchical
-void launch_hier_count(hipStream_t s, uint2* cranges, uint32_t NS, char* seg_desc, uint2* st_seg,
+// run_totals != NULL: entries per super-tile (the digit totals of a one-pass coarse partition); the
+// runs in cranges are derived from them here.  NULL: cranges already holds the runs.
+void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals, uint32_t NS,
+                       char* seg_desc, uint2* st_seg,
                        uint32_t* nseg_total, uint32_t max_seg, const uint32_t* ckey_sorted,
                        int gx, int gy, uint32_t* seg_table, uint32_t* tile_tot,
                        uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,

@@ -121,7 +121,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   const float tan_fovy, const float focal_x, const float focal_y,
                   int* __restrict__ radii, float4* __restrict__ rec,
                   uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
-                  uint32_t* __restrict__ ctiles /* super-tiles touched (hierarchical binning), or NULL */,
+                  uint2* __restrict__ rects /* packed tile rectangles (hierarchical binning), or NULL */,
                   uint32_t* __restrict__ ds_table0 /* [chunk][256] pass-0 counts of the fat depth sort, or NULL */,
                   const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
   // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
@@ -158,7 +158,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   __shared__ uint32_t s_dh[DS_RADIX];
   s_dh[threadIdx.x] = 0u;
   const int idx = base + threadIdx.x;
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;   // r3: packed tile rectangle
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   uint32_t my_key = CULLED_KEY;
   if (idx < P) {
     const float mx = s_mean[3 * threadIdx.x], my = s_mean[3 * threadIdx.x + 1],
@@ -174,7 +174,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
     if (!vis) {
       radii[idx] = 0;
       tiles[idx] = 0;
-      if (ctiles) ctiles[idx] = 0;
+      if (rects) rects[idx] = make_uint2(0u, 0u);
       depth_key[idx] = CULLED_KEY;
     } else {
       float rgb[3];
@@ -198,11 +198,9 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
       }
       radii[idx] = o.radius;
       tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
-      if (ctiles)   // 8x8-tile super-tiles the rectangle reaches (hier_binning.hip)
-        ctiles[idx] = (uint32_t)(((o.maxx + STILE - 1) / STILE) - o.minx / STILE) *
-                      (uint32_t)(((o.maxy + STILE - 1) / STILE) - o.miny / STILE);
-      r3 = make_float4(__uint_as_float((uint32_t)o.minx | ((uint32_t)o.maxx << 16)),
-                       __uint_as_float((uint32_t)o.miny | ((uint32_t)o.maxy << 16)), 0.f, 0.f);
+      if (rects)   // x and y tile ranges, half-open, 16 bits each (hier_binning.hip)
+        rects[idx] = make_uint2((uint32_t)o.minx | ((uint32_t)o.maxx << 16),
+                                (uint32_t)o.miny | ((uint32_t)o.maxy << 16));
       depth_key[idx] = __float_as_uint(o.depth);
       my_key = __float_as_uint(o.depth);
       r0 = make_float4(o.px, o.py, opacities[idx], __int_as_float(o.radius));
@@ -213,7 +211,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   s_out[REC_STRIDE * threadIdx.x + 0] = r0;
   s_out[REC_STRIDE * threadIdx.x + 1] = r1;
   s_out[REC_STRIDE * threadIdx.x + 2] = r2;
-  s_out[REC_STRIDE * threadIdx.x + 3] = r3;
+  s_out[REC_STRIDE * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();   // also orders the zeroing of s_dh before the atomics below
   if (ds_table0 != nullptr && my_key != CULLED_KEY) atomicAdd(&s_dh[my_key & (DS_RADIX - 1)], 1u);
   const int nrec4 = min(256, P - base) * REC_STRIDE;
@@ -389,13 +387,13 @@ preprocess_composed_kernel(const int P, const int D, const int M,
                            const float tan_fovx, const float tan_fovy, const float focal_x,
                            const float focal_y, int* __restrict__ radii, float4* __restrict__ rec,
                            uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
-                           uint32_t* __restrict__ ctiles, uint32_t* __restrict__ ds_table0) {
+                           uint2* __restrict__ rects, uint32_t* __restrict__ ds_table0) {
   __shared__ float4 s_out[256 * REC_STRIDE];
   __shared__ uint32_t s_dh[DS_RADIX];
   s_dh[threadIdx.x] = 0u;
   const int base = blockIdx.x * 256;
   const int idx = base + threadIdx.x;
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;   // r3: packed tile rectangle
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   uint32_t my_key = CULLED_KEY;
   if (idx < P) {
     const SegmentDev& sg = *find_segment(segs, nseg, (uint32_t)idx);
@@ -408,7 +406,7 @@ preprocess_composed_kernel(const int P, const int D, const int M,
     if (!vis) {
       radii[idx] = 0;
       tiles[idx] = 0;
-      if (ctiles) ctiles[idx] = 0;
+      if (rects) rects[idx] = make_uint2(0u, 0u);
       depth_key[idx] = CULLED_KEY;
     } else {
       float rgb[3];
@@ -428,11 +426,9 @@ preprocess_composed_kernel(const int P, const int D, const int M,
       }
       radii[idx] = o.radius;
       tiles[idx] = (uint32_t)(o.maxy - o.miny) * (uint32_t)(o.maxx - o.minx);
-      if (ctiles)   // 8x8-tile super-tiles the rectangle reaches (hier_binning.hip)
-        ctiles[idx] = (uint32_t)(((o.maxx + STILE - 1) / STILE) - o.minx / STILE) *
-                      (uint32_t)(((o.maxy + STILE - 1) / STILE) - o.miny / STILE);
-      r3 = make_float4(__uint_as_float((uint32_t)o.minx | ((uint32_t)o.maxx << 16)),
-                       __uint_as_float((uint32_t)o.miny | ((uint32_t)o.maxy << 16)), 0.f, 0.f);
+      if (rects)   // x and y tile ranges, half-open, 16 bits each (hier_binning.hip)
+        rects[idx] = make_uint2((uint32_t)o.minx | ((uint32_t)o.maxx << 16),
+                                (uint32_t)o.miny | ((uint32_t)o.maxy << 16));
       depth_key[idx] = __float_as_uint(o.depth);
       my_key = __float_as_uint(o.depth);
       r0 = make_float4(o.px, o.py, a.opacity, __int_as_float(o.radius));
@@ -443,7 +439,7 @@ preprocess_composed_kernel(const int P, const int D, const int M,
   s_out[REC_STRIDE * threadIdx.x + 0] = r0;
   s_out[REC_STRIDE * threadIdx.x + 1] = r1;
   s_out[REC_STRIDE * threadIdx.x + 2] = r2;
-  s_out[REC_STRIDE * threadIdx.x + 3] = r3;
+  s_out[REC_STRIDE * threadIdx.x + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   if (ds_table0 != nullptr && my_key != CULLED_KEY) atomicAdd(&s_dh[my_key & (DS_RADIX - 1)], 1u);
   const int nrec4 = min(256, P - base) * REC_STRIDE;
@@ -463,14 +459,14 @@ preprocess_composed_kernel(const int P, const int D, const int M,
 
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
-                                uint32_t* depth_key, uint32_t* tiles, uint32_t* ctiles,
+                                uint32_t* depth_key, uint32_t* tiles, uint2* rects,
                                 uint32_t* ds_table0) {
   if (P <= 0) return;
 #define PC_LAUNCH(M4)                                                                           \
   preprocess_composed_kernel<M4><<<(P + 255) / 256, 256, 0, s>>>(                                \
       P, D, M, segs, nseg, scale_modifier, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx,  \
       cam.gy, cam.tan_fovx, cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, \
-      ctiles, ds_table0)
+      rects, ds_table0)
   if (M == 4) PC_LAUNCH(true); else PC_LAUNCH(false);
 #undef PC_LAUNCH
 }
@@ -486,13 +482,13 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* scales, float scale_modifier, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
-                       float4* rec, uint32_t* depth_key, uint32_t* tiles, uint32_t* ctiles,
+                       float4* rec, uint32_t* depth_key, uint32_t* tiles, uint2* rects,
                        uint32_t* ds_table0) {
   if (P <= 0) return;
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
       colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
-      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, ctiles, ds_table0,
+      cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, rects, ds_table0,
       ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
 }
 

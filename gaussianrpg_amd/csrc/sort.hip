@@ -533,7 +533,8 @@ __global__ void __launch_bounds__(SC_THREADS)
 scan_reduce_kernel(const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
                    const uint32_t* __restrict__ tiles, uint32_t* __restrict__ block_sums,
                    const uint32_t* __restrict__ gid, const uint32_t* __restrict__ tiles_by_id,
-                   uint32_t* __restrict__ tiles_out) {
+                   uint32_t* __restrict__ tiles_out, const uint2* __restrict__ rects_by_id,
+                   uint2* __restrict__ rect_out) {
   __shared__ uint32_t s_wave[4];
   const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
   const uint32_t base = blockIdx.x * SC_CHUNK;
@@ -552,15 +553,32 @@ scan_reduce_kernel(const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
       const uint32_t i = base + k * SC_THREADS + threadIdx.x;
       g[k] = i < n ? gid[i] : 0u;
     }
+    if (rects_by_id != nullptr) {
+      // hierarchical binning: the counts are super-tile counts, derived from the gathered tile
+      // rectangles, which stay behind in sorted order for the coarse emit
+      uint2 rc[SC_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-      const uint32_t i = base + k * SC_THREADS + threadIdx.x;
-      v[k] = i < n ? tiles_by_id[g[k]] : 0u;
-    }
+      for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+        rc[k] = i < n ? rects_by_id[g[k]] : make_uint2(0u, 0u);
+      }
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) {
-      const uint32_t i = base + k * SC_THREADS + threadIdx.x;
-      if (i < n) tiles_out[i] = v[k];
+      for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+        v[k] = rect_super_tiles(rc[k].x, rc[k].y);
+        if (i < n) { tiles_out[i] = v[k]; rect_out[i] = rc[k]; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+        v[k] = i < n ? tiles_by_id[g[k]] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < SC_ITEMS; k++) {
+        const uint32_t i = base + k * SC_THREADS + threadIdx.x;
+        if (i < n) tiles_out[i] = v[k];
+      }
     }
   } else {
 #pragma unroll
@@ -647,10 +665,11 @@ void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
                          uint32_t* tiles_sorted, const uint32_t* gather_gid,
                          const uint32_t* tiles_by_id, uint32_t* offsets, uint32_t* block_sums,
                          uint32_t nblocks, uint32_t* total_out, uint32_t* total_host,
-                         uint32_t* emit_win, uint32_t emit_win_cap) {
+                         uint32_t* emit_win, uint32_t emit_win_cap, const uint2* rects_by_id,
+                         uint2* rect_sorted) {
   if (n == 0) return;
   scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, n_dev, tiles_sorted, block_sums, gather_gid,
-                                                     tiles_by_id, tiles_sorted);
+                                                     tiles_by_id, tiles_sorted, rects_by_id, rect_sorted);
   scan_down_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, n_dev, tiles_sorted, block_sums, nblocks, offsets,
                                                    total_out, total_host, emit_win, emit_win_cap);
 }

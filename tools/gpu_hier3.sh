@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
 bash tools/gpu_ab.sh hier
+AB_ARGS='--steps 200' bash tools/gpu_ab.sh h_200
