@@ -174,13 +174,11 @@ uint32_t heavy_tile_min() {
 }
 
 // Tile binning algorithm: "hier" (hier_binning.hip, default) or "sort" (emit + stable partition).
-bool binning_is_hier() {
-  static const bool v = [] {
-    const char* e = getenv("GRPG_BINNING");
-    return !(e && strcmp(e, "sort") == 0);
-  }();
-  return v;
-}
+std::atomic<int> g_binning_alg{[] {
+  const char* e = getenv("GRPG_BINNING");
+  return (e && strcmp(e, "sort") == 0) ? GRPG_BINNING_ALG_SORT : GRPG_BINNING_ALG_HIER;
+}()};
+bool binning_is_hier() { return g_binning_alg.load() == GRPG_BINNING_ALG_HIER; }
 
 int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit in b bits
   int b = 0;
@@ -279,8 +277,12 @@ int grpg_set_binning_mode(int mode) {
   g_binning_mode.store(mode);
   return GRPG_OK;
 }
-int grpg_get_binning_algorithm(void) {
-  return binning_is_hier() ? GRPG_BINNING_ALG_HIER : GRPG_BINNING_ALG_SORT;
+int grpg_get_binning_algorithm(void) { return g_binning_alg.load(); }
+int grpg_set_binning_algorithm(int alg) {
+  if (alg != GRPG_BINNING_ALG_SORT && alg != GRPG_BINNING_ALG_HIER)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "unknown binning algorithm");
+  g_binning_alg.store(alg);
+  return GRPG_OK;
 }
 int grpg_reset_capacity_hints(void) {
   std::lock_guard<std::mutex> lk(g_hint_mu);

@@ -622,4 +622,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   });
   m.def("reset_capacity_hints", []() { grpg_reset_capacity_hints(); });
   m.def("get_binning_algorithm", []() { return grpg_get_binning_algorithm(); });
+  m.def("set_binning_algorithm", [](int alg) {
+    if (grpg_set_binning_algorithm(alg) != GRPG_OK) raise_abi_error("grpg_set_binning_algorithm", -1);
+  });
 }

@@ -214,7 +214,7 @@ GRPG_API int grpg_set_binning_mode(int mode);
 /* Forget the remembered num_rendered high-water marks (the next grpg_forward of every shape waits
  * for the count before it sizes the binning blob). */
 GRPG_API int grpg_reset_capacity_hints(void);
-/* Tile binning algorithm of grpg_forward, fixed at load time: GRPG_BINNING_ALG_HIER (default;
+/* Tile binning algorithm of grpg_forward (process-wide): GRPG_BINNING_ALG_HIER (default;
  * csrc/hier_binning.hip: coarse (Gaussian, 8x8-tile super-tile) pairs partitioned by super-tile,
  * then per-tile counts and a direct fill of the point list) or GRPG_BINNING_ALG_SORT (environment
  * GRPG_BINNING=sort; csrc/binning.hip + sort.hip: one (tile, value) pair per instance, stably
@@ -222,6 +222,7 @@ GRPG_API int grpg_reset_capacity_hints(void);
 #define GRPG_BINNING_ALG_SORT 0
 #define GRPG_BINNING_ALG_HIER 1
 GRPG_API int grpg_get_binning_algorithm(void);
+GRPG_API int grpg_set_binning_algorithm(int alg);
 
 /*
  * Rasterizer::backward  (rasterizer.h:60-96, rasterizer_impl.cu:396-505).
