@@ -2,8 +2,10 @@
 (gs_oracle.c: every per-(pixel,Gaussian) term in fp32 as the reference writes it, summed in fp64).
 
 The reference sums float atomics in an unspecified order, so gradients are compared with a
-tolerance: per array, relative L2 error <= 2e-3 and >= 99.5 % of the elements within
-2e-3 * max|ref| (a threshold-fragile pixel may legitimately flip one contribution).
+tolerance: per array, relative L2 error <= 1e-3 (measured: 1e-6 .. 6e-4), >= 99.5 % of the elements
+within 2e-3 * max|ref|, and >= 98.5 % of the elements within SURVEY §8(d)'s rtol 1e-3 / atol 1e-5
+(times max|ref|; measured: 98.9 % on the 18 k-entry tiles, >= 99.8 % elsewhere -- the rest are fed by
+threshold-fragile pixels, which may legitimately flip one contribution).
 """
 import numpy as np
 import pytest
@@ -23,7 +25,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _grad_close(name, got, ref, rel_l2=2e-3, elem_tol=2e-3, frac=0.995):
+def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995):
+    import os
+    from helpers import PARITY_STATS
     got = np.asarray(got, np.float64).reshape(ref.shape)
     ref = np.asarray(ref, np.float64)
     if ref.size == 0:
@@ -31,7 +35,16 @@ def _grad_close(name, got, ref, rel_l2=2e-3, elem_tol=2e-3, frac=0.995):
     scale = np.abs(ref).max() + 1e-30
     l2 = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
     ok = (np.abs(got - ref) <= elem_tol * scale).mean()
+    # SURVEY §8(d) config 5 states rtol 1e-3 / atol 1e-5 (atol relative to the array's largest
+    # element here: the test losses are random planes, not unit-scale): recorded for every array,
+    # dumped with the parity statistics at session end
+    strict = (np.abs(got - ref) <= 1e-5 * scale + 1e-3 * np.abs(ref)).mean()
+    PARITY_STATS.append(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0],
+                             plane="grad:" + name, pixels=int(ref.size), rel_l2=float(l2),
+                             frac_within_rtol1e3_atol1e5=float(strict)))
     assert l2 <= rel_l2 and ok >= frac, "%s: relL2 %.3e, within-tol fraction %.5f" % (name, l2, ok)
+    # the strict element-wise bar holds for all but the elements a threshold-fragile pixel feeds
+    assert strict >= 0.985, "%s: only %.4f of the elements within rtol 1e-3 / atol 1e-5 max|ref|" % (name, strict)
 
 
 def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0):
@@ -188,3 +201,77 @@ def test_toy_fit_psnr_parity(dev):
     cpu = fit(lambda m, o, s, sc_, r: ts.rasterize(m, o, shs=s, scales=sc_, rotations=r, **kw)["color"],
               torch.device("cpu"))
     assert abs(hip - cpu) <= 0.3, (hip, cpu)
+
+
+def test_fit_psnr_parity_10k(dev):
+    """SURVEY §8(d) config 5 at its stated size: a 200-step Adam fit of a 10 k-Gaussian scene to a
+    fixed target (rendered from a different, 30 k-Gaussian scene) through the HIP op follows the same
+    PSNR curve as the same fit through a CPU autograd function built on the oracle (gs_oracle.c
+    forward + backward, OpenMP build: identical results to the scalar one).  Both fits start from
+    the same parameters and see the same target; they differ only by the op's rounding and atomic
+    summation order, which Adam amplifies step by step: two runs of the HIP op ITSELF are identical
+    to 1e-4 dB at step 50, 0.01 dB apart at step 100 and 0.05 dB apart at step 200
+    (tools/experiments/psnr_noise.py; the reference's float atomics behave the same way).  Bars:
+    +-0.01 dB at step 50, +-0.05 dB at step 100, +-0.15 dB at step 200."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import torch_splat as ts
+    from helpers import PARITY_STATS
+    W, H, P, STEPS, MARKS = 160, 120, 10000, 200, (50, 100, 200)
+    cam = hz.trajectory_camera(0, W=W, H=H)
+    kw = oracle_kwargs(cam, 0)
+    target_sc = hz.toy_scene(30000, seed=60, sh_degree=0, scale=0.04, spread=2.0)
+    start = hz.toy_scene(P, seed=61, sh_degree=0, scale=0.06, spread=2.0)
+    oracle.use_openmp(True)
+    try:
+        target = torch.from_numpy(oracle.forward(
+            target_sc.means3D, target_sc.opacity, shs=target_sc.shs, scales=target_sc.scales,
+            rotations=target_sc.rotations, **kw)["color"].copy())
+
+        class OracleSplat(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, means3D, opacity, shs, scales, rotations):
+                o = oracle.forward(means3D.detach(), opacity.detach(), shs=shs.detach(),
+                                   scales=scales.detach(), rotations=rotations, **kw)
+                ctx.o = o
+                return torch.from_numpy(o["color"].copy())
+
+            @staticmethod
+            def backward(ctx, grad_color):
+                z = np.zeros((H, W), np.float32)
+                g = oracle.backward(ctx.o, grad_color.contiguous().numpy(), z, z)
+                t = lambda k: torch.from_numpy(g[k])      # noqa: E731
+                return t("dL_dmeans3D"), t("dL_dopacity"), t("dL_dsh"), t("dL_dscales"), None
+
+        def fit(render, dev_):
+            p = {k: getattr(start, k).to(dev_).clone().requires_grad_(True)
+                 for k in ("means3D", "opacity", "shs", "scales")}
+            rot = start.rotations.to(dev_)
+            opt = torch.optim.Adam(p.values(), lr=0.002)
+            tgt = target.to(dev_)
+            curve = {}
+            for i in range(STEPS + 1):
+                opt.zero_grad()
+                img = render(p["means3D"], p["opacity"].clamp(0.01, 0.99), p["shs"],
+                             p["scales"].clamp(0.01, 2.0), rot)
+                if i == 0 or i in MARKS:
+                    curve[i] = ts.psnr(img.detach().clamp(0, 1).cpu(), tgt.clamp(0, 1).cpu())
+                if i == STEPS:
+                    break
+                (img - tgt).abs().mean().backward()
+                opt.step()
+            return curve
+
+        camd = hz.trajectory_camera(0, W=W, H=H, device=dev)
+        rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 0)))
+        hip = fit(lambda m, o, s, sc_, r: rast(means3D=m, means2D=None, opacities=o, shs=s, scales=sc_,
+                                                rotations=r)[0], dev)
+        cpu = fit(lambda m, o, s, sc_, r: OracleSplat.apply(m, o, s, sc_, r), torch.device("cpu"))
+    finally:
+        oracle.use_openmp(False)
+    PARITY_STATS.append(dict(test="test_fit_psnr_parity_10k", plane="psnr", P=P, steps=STEPS,
+                             psnr_hip={str(k): v for k, v in hip.items()},
+                             psnr_oracle={str(k): v for k, v in cpu.items()}))
+    assert abs(hip[0] - cpu[0]) <= 1e-3, (hip, cpu)
+    assert hip[200] > hip[0] + 15.0 and cpu[200] > cpu[0] + 15.0, (hip, cpu)   # the fits actually fit
+    for mark, bar in ((50, 0.01), (100, 0.05), (200, 0.15)):
+        assert abs(hip[mark] - cpu[mark]) <= bar, (mark, hip, cpu)
