@@ -203,7 +203,7 @@ hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  constexpr int PER = 10;   // 10240 tiles per sweep: one sweep at 1920x1280
+  constexpr int PER = 4;
   for (uint32_t base = 0; base < T; base += 1024 * PER) {
     uint32_t v[PER], s = 0;
 #pragma unroll

@@ -174,7 +174,6 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
     if (!vis) {
       radii[idx] = 0;
       tiles[idx] = 0;
-      if (rects) rects[idx] = make_uint2(0u, 0u);
       depth_key[idx] = CULLED_KEY;
     } else {
       float rgb[3];
@@ -219,7 +218,8 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
 #pragma unroll
   for (int k = 0; k < REC_STRIDE; k++) {
     const int e = k * 256 + threadIdx.x;
-    if (e < nrec4) dst[e] = s_out[e];
+    // a culled Gaussian's record (radius bits 0) is never read: its sector is not written
+    if (e < nrec4 && __float_as_int(s_out[e & ~(REC_STRIDE - 1)].w) != 0) dst[e] = s_out[e];
   }
   if (ds_table0 != nullptr) {
     __syncthreads();
@@ -406,7 +406,6 @@ preprocess_composed_kernel(const int P, const int D, const int M,
     if (!vis) {
       radii[idx] = 0;
       tiles[idx] = 0;
-      if (rects) rects[idx] = make_uint2(0u, 0u);
       depth_key[idx] = CULLED_KEY;
     } else {
       float rgb[3];
@@ -447,7 +446,8 @@ preprocess_composed_kernel(const int P, const int D, const int M,
 #pragma unroll
   for (int k = 0; k < REC_STRIDE; k++) {
     const int e = k * 256 + threadIdx.x;
-    if (e < nrec4) dst[e] = s_out[e];
+    // a culled Gaussian's record (radius bits 0) is never read: its sector is not written
+    if (e < nrec4 && __float_as_int(s_out[e & ~(REC_STRIDE - 1)].w) != 0) dst[e] = s_out[e];
   }
   if (ds_table0 != nullptr) {
     __syncthreads();
