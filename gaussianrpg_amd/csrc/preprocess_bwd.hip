@@ -36,8 +36,8 @@ __device__ __forceinline__ float dot3(const Vec3 a, const Vec3 b) { return a.x *
 // Writes dL_dsh[0 .. (deg+1)^2) and returns dL/d(mean - campos).
 __device__ __forceinline__ Vec3 sh_backward(const int deg, const float* __restrict__ sh, const Vec3 v,
                                             const Vec3 g, float* __restrict__ dL_dsh) {
-  const float len = sqrtf(dot3(v, v));
-  const Vec3 d = {v.x / len, v.y / len, v.z / len};
+  const float rlen = 1.0f / sqrtf(dot3(v, v));
+  const Vec3 d = {v.x * rlen, v.y * rlen, v.z * rlen};
   Vec3 gd = {0.f, 0.f, 0.f};   // dL/dd, d treated as three free variables like the reference does
   // one basis function: value Yk, gradient (yx, yy, yz)
   auto term = [&](const int k, const float Yk, const float yx, const float yy, const float yz) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ Vec3 sh_backward(const int deg, const float* __restri
   }
   // through the normalisation d = v / |v|: the component of gd orthogonal to d, over |v|
   const float along = dot3(d, gd);
-  return Vec3{(gd.x - d.x * along) / len, (gd.y - d.y * along) / len, (gd.z - d.z * along) / len};
+  return Vec3{(gd.x - d.x * along) * rlen, (gd.y - d.y * along) * rlen, (gd.z - d.z * along) * rlen};
 }
 
 // World covariance V = R D R^T (R from the unnormalised quaternion q = (r, x, y, z), D = diag(s^2),
@@ -171,16 +171,10 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
     HA[0][j] = Haa * A[0][j] + Hab * A[1][j];
     HA[1][j] = Hab * A[0][j] + Hcc * A[1][j];
   }
-  float dcov[6];
-  {
-    constexpr int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
+  auto aha = [&](const int r, const int c) { return A[0][r] * HA[0][c] + A[1][r] * HA[1][c]; };
+  const float dcov[6] = {aha(0, 0), 2.f * aha(0, 1), 2.f * aha(0, 2), aha(1, 1), 2.f * aha(1, 2), aha(2, 2)};
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-      const float v = A[0][ri[e]] * HA[0][ci[e]] + A[1][ri[e]] * HA[1][ci[e]];
-      dcov[e] = ri[e] == ci[e] ? v : 2.f * v;
-      dL_dcov[6 * idx + e] = dcov[e];
-    }
-  }
+  for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = dcov[e];
   const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
   float dA[2][3];
 #pragma unroll
@@ -230,8 +224,8 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   }
   if (shs != nullptr) {
     const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
-    const Vec3 g = {(clamped & 1u) ? 0.f : dL_dcolor[3 * idx], (clamped & 2u) ? 0.f : dL_dcolor[3 * idx + 1],
-                    (clamped & 4u) ? 0.f : dL_dcolor[3 * idx + 2]};
+    const float gr = dL_dcolor[3 * idx], gg = dL_dcolor[3 * idx + 1], gb = dL_dcolor[3 * idx + 2];
+    const Vec3 g = {(clamped & 1u) ? 0.f : gr, (clamped & 2u) ? 0.f : gg, (clamped & 4u) ? 0.f : gb};
     const Vec3 gs = sh_backward(D, shs + (size_t)idx * M * 3,
                                 Vec3{m.x - campos[0], m.y - campos[1], m.z - campos[2]}, g,
                                 dL_dsh + (size_t)idx * M * 3);

@@ -45,7 +45,7 @@ lines += ["", "# PMC (separate rocprofv3 --pmc passes, mean per dispatch).",
 for k in sorted(agg):
     if not any(x in k for x in ("render_forward", "preprocess_kernel", "radix_scatter", "emit_kernel",
                                 "radix_hist", "scan_down", "scan_reduce", "tile_ranges", "depth_scatter",
-                                "depth_hist", "frame_init", "pack_u8")):
+                                "depth_hist", "frame_init", "pack_u8", "hb_", "radix_digit_scan")):
         continue
     lines.append("== %s" % k)
     for c, v in sorted(agg[k].items()):
