@@ -955,6 +955,8 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   const bool pc = render_pc_enabled();
   const uint32_t pc_mul = render_pc_mul();
   const uint32_t pc_slots = render_pc_slots(R, heavy_min);
+  // GRPG_RENDER_LDS_PAD (experiment): unused dynamic LDS per workgroup, to cap the kernel's occupancy
+  static const uint32_t lds_pad = [] { const char* e = getenv("GRPG_RENDER_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
   classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
                                                             pc ? pc_mul : 8u, pc ? 8u : 2u, work);
   // measured: OFF is faster (render 0.232 vs 0.248 ms) -- neighbouring tiles are also similarly
@@ -965,11 +967,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
 #define RF_LAUNCH(GL)                                                                          \
   do {                                                                                         \
     if (aux)                                                                                   \
-      render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, 0, s>>>(                        \
+      render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                        \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
           out_alpha, n_contrib, pc_slots, xcd);                                                 \
     else                                                                                       \
-      render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, 0, s>>>(                       \
+      render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                       \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
           out_alpha, n_contrib, pc_slots, xcd);                                                 \
   } while (0)
@@ -979,7 +981,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
     const size_t words = (size_t)(ntiles + pc_slots) * RW_WAVES * 17;
     if (hipMalloc((void**)&d_trace, words * 4) == hipSuccess) {
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
-      render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, 0, s>>>(
+      render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, lds_pad, s>>>(
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
           out_alpha, n_contrib, pc_slots, xcd, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
