@@ -454,11 +454,11 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       HIP_TRY(hipEventRecord(hw->ev, stream));   // fires when num_rendered sits in the pinned word
       return GRPG_OK;
     };
-    auto render_tail = [&](const uint32_t* point_list, uint32_t cap) -> int {
+    auto render_tail = [&](const uint32_t* point_list, uint32_t cap, bool classified) -> int {
       tm.mark(6);
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
-                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
+                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified);
       STAGE_CHECK("render");
       tm.mark(7);
       if (S > 0) {
@@ -503,7 +503,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       tm.mark(5);
       launch_tile_ranges(stream, &gh->R, cap, bkey_a, ranges, T);
       STAGE_CHECK("tile ranges");
-      return render_tail(bval_a, cap);
+      return render_tail(bval_a, cap, false);
     };
     // hierarchical path (hier_binning.hip): everything behind the depth sort.  Stage slots: 2 = scan
     // over the super-tile counts, 3 = coarse emit, 4 = coarse partition + super-tile runs,
@@ -549,14 +549,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                         (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
                         (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
                         (uint32_t*)(binp + L.tile_start), ranges, &gh->R, publish ? hw->dev_ptr : nullptr,
-                        &gh->Rc, (BlobHeader*)binp, cap, ccap);
+                        &gh->Rc, (BlobHeader*)binp, cap, ccap, work, heavy_tile_min());
       STAGE_CHECK("tile counts");
       if (publish) HIP_TRY(hipEventRecord(hw->ev, stream));
       launch_hier_fill(stream, binp + L.seg_desc, (const uint32_t*)(binp + L.nseg), L.max_seg, ckey, cval, rec,
                        cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),
                        (const uint32_t*)(binp + L.tile_start), cap, plist);
       STAGE_CHECK("point list fill");
-      return render_tail(plist, cap);
+      return render_tail(plist, cap, true);
     };
     auto carve = [&](uint32_t cap, uint32_t ccap, bool rezero) -> int {
       Rcap = cap;

@@ -302,7 +302,8 @@ void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals
                        int gx, int gy, uint32_t* seg_table, uint32_t* tile_tot,
                        uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,
                        const uint32_t* Rc_dev, BlobHeader* bin_header, uint32_t R_cap,
-                       uint32_t coarse_cap);
+                       uint32_t coarse_cap, uint32_t* work /* render work lists [4 + 4T] */,
+                       uint32_t heavy_min);
 void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_total, uint32_t max_seg,
                       const uint32_t* ckey_sorted, const uint32_t* cval_sorted, const RecView rec,
                       int gx, int gy,
@@ -314,7 +315,9 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
                            uint32_t heavy_min, uint32_t R /* num_rendered */,
-                           bool aux /* track + write n_contrib (needed by the backward only) */);
+                           bool aux /* track + write n_contrib (needed by the backward only) */,
+                           bool classified = false /* work lists already built (hier_binning.hip) */);
+void render_class_multipliers(uint32_t* c0_mul, uint32_t* c1_mul);   // render_fwd.hip
 uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min);   // render_fwd.hip
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const RecView rec, const float* semantics, int S, int W, int H, int gx,

@@ -111,15 +111,70 @@ hb_seg_setup_kernel(uint2* __restrict__ cranges, const uint32_t* __restrict__ ru
 }
 
 // ---- count: table[seg][64] = Gaussians of the segment touching each tile of its super-tile ----
+// SETUP (<= 256 super-tiles, one-pass coarse partition): there is no segment-setup launch; every
+// workgroup derives the super-tile runs and the segment numbering itself from the partition's digit
+// totals (1 KB, one scan in wave 0), finds its own segment and leaves the descriptor behind for the
+// fill; workgroup 0 also publishes the runs, the per-super-tile segment ranges and the count.
+template <bool SETUP>
 __global__ void __launch_bounds__(HB_CNT_THREADS)
-hb_count_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nseg_total,
-                const uint32_t* __restrict__ ckey, uint32_t* __restrict__ table) {
+hb_count_kernel(SegDesc* __restrict__ seg, uint32_t* __restrict__ nseg_total,
+                const uint32_t* __restrict__ ckey, uint32_t* __restrict__ table,
+                const uint32_t* __restrict__ run_totals, const uint32_t NS, uint2* __restrict__ cranges,
+                uint2* __restrict__ st_seg, const uint32_t max_seg) {
   __shared__ uint16_t s_m[HB_SEG];
+  __shared__ uint32_t s_run[256 + 1], s_first[256 + 1];
   const uint32_t sid = blockIdx.x;
-  if (sid >= *nseg_total) return;
-  const SegDesc d = seg[sid];
-  const uint32_t n = d.end - d.begin;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SegDesc d;
+  if (SETUP) {
+    if (wave == 0) {
+      uint32_t len[4], ns[4], slen = 0, sns = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t st = lane * 4 + k;
+        len[k] = st < NS ? run_totals[st] : 0u;
+        ns[k] = (len[k] + HB_SEG - 1) / HB_SEG;
+        slen += len[k]; sns += ns[k];
+      }
+      uint32_t ilen = slen, ins = sns;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t a = __shfl_up(ilen, dd, 64), b = __shfl_up(ins, dd, 64);
+        if (lane >= (uint32_t)dd) { ilen += a; ins += b; }
+      }
+      uint32_t rs = ilen - slen, fs = ins - sns;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s_run[lane * 4 + k] = rs; s_first[lane * 4 + k] = fs;
+        rs += len[k]; fs += ns[k];
+      }
+      if (lane == 63) { s_run[256] = rs; s_first[256] = fs; }
+    }
+    __syncthreads();
+    const uint32_t total = min(s_first[256], max_seg);
+    if (sid == 0) {
+      if (tid == 0) *nseg_total = total;
+      if (tid < NS) {
+        const uint32_t b = s_run[tid], e = s_run[tid + 1];
+        cranges[tid] = e > b ? make_uint2(b, e) : make_uint2(0u, 0u);
+        st_seg[tid] = make_uint2(s_first[tid], s_first[tid + 1] - s_first[tid]);
+      }
+    }
+    if (sid >= total) return;
+    // the LAST super-tile whose first segment is <= sid (empty ones share theirs with a successor)
+    uint32_t lo = 0, hi = NS - 1;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo + 1) / 2;
+      if (s_first[mid] <= sid) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t k = sid - s_first[lo];
+    d.st = lo; d.begin = s_run[lo] + k * HB_SEG; d.end = min(s_run[lo + 1], d.begin + HB_SEG); d.pad = 0u;
+    if (tid == 0) seg[sid] = d;
+  } else {
+    if (sid >= *nseg_total) return;
+    d = seg[sid];
+  }
+  const uint32_t n = d.end - d.begin;
 #pragma unroll
   for (int i = 0; i < HB_SEG / HB_CNT_THREADS; i++) {
     const uint32_t e = i * HB_CNT_THREADS + tid;
@@ -191,27 +246,37 @@ hb_tile_prefix_kernel(const uint2* __restrict__ st_seg, uint32_t* __restrict__ t
 }
 
 // ---- exclusive scan over all tiles -> ranges (untouched tiles stay (0,0) like the reference's
-// memset + identifyTileRanges), monotone tile_start[] for the fill, num_rendered ----
+// memset + identifyTileRanges), monotone tile_start[] for the fill, num_rendered; and, since every
+// tile's length passes through here, the render's work lists (render_fwd.hip: classify_tiles_kernel
+// does the same from the ranges; slots come from LDS counters here, no global atomics) ----
 __global__ void __launch_bounds__(1024)
 hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
                     uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
                     uint32_t* __restrict__ R_out, uint32_t* __restrict__ host_word,
                     const uint32_t* __restrict__ Rc_dev, BlobHeader* __restrict__ bin_header,
-                    const uint32_t R_cap, const uint32_t coarse_cap) {
+                    const uint32_t R_cap, const uint32_t coarse_cap, uint32_t* __restrict__ work,
+                    const uint32_t heavy_min, const uint32_t c0_mul, const uint32_t c1_mul) {
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_cls[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_carry = 0;
+  if (tid < 4) s_cls[tid] = 0;
   __syncthreads();
-  constexpr int PER = 4;
+  constexpr int PER = 4;   // one 16-byte load / store per lane: a single CU must not waste lines
   for (uint32_t base = 0; base < T; base += 1024 * PER) {
     uint32_t v[PER], s = 0;
+    const uint32_t t0 = base + tid * PER;
+    const bool full = t0 + PER <= T;
+    if (full) {
+      const uint4 q = *reinterpret_cast<const uint4*>(tile_tot + t0);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-      const uint32_t t = base + tid * PER + k;
-      v[k] = t < T ? tile_tot[t] : 0u;
-      s += v[k];
+      for (int k = 0; k < PER; k++) v[k] = t0 + k < T ? tile_tot[t0 + k] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < PER; k++) s += v[k];
     uint32_t inc = s;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -222,21 +287,70 @@ hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
     __syncthreads();
     uint32_t ex = s_carry + inc - s;
     for (uint32_t w = 0; w < wave; w++) ex += s_w[w];
+    if (full) {   // starts and ranges of the lane's four tiles: 16 + 32 bytes, stored whole
+      uint32_t st[PER + 1];
+      st[0] = ex;
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-      const uint32_t t = base + tid * PER + k;
-      if (t < T) {
-        tile_start[t] = ex;
+      for (int k = 0; k < PER; k++) st[k + 1] = st[k] + v[k];
+      *reinterpret_cast<uint4*>(tile_start + t0) = make_uint4(st[0], st[1], st[2], st[3]);
+      uint32_t r[2 * PER];
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
         // clamped to the point list's capacity: on an overflow the frame's tail is redone, but
         // the render enqueued behind this launch must stay inside the list
+        r[2 * k] = v[k] ? min(st[k], R_cap) : 0u;
+        r[2 * k + 1] = v[k] ? min(st[k + 1], R_cap) : 0u;
+      }
+      uint4* rp = reinterpret_cast<uint4*>(ranges + t0);
+      rp[0] = make_uint4(r[0], r[1], r[2], r[3]);
+      rp[1] = make_uint4(r[4], r[5], r[6], r[7]);
+    }
+    // work-list class of each tile from its (clamped) list length; slots: per class one LDS counter
+    // bump per wave (lane c for class c), positions inside the wave from a packed lane scan
+    int cls[PER];
+    uint32_t n01 = 0, n23 = 0;   // per-lane class counts, 16-bit fields: (class 0, 1), (class 2, 3)
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const uint32_t t = t0 + k;
+      if (!full && t < T) {
+        tile_start[t] = ex;
         ranges[t] = v[k] ? make_uint2(min(ex, R_cap), min(ex + v[k], R_cap)) : make_uint2(0u, 0u);
       }
+      const uint32_t len = min(ex + v[k], R_cap) - min(ex, R_cap);
+      const uint64_t hm = heavy_min;
+      cls[k] = t >= T ? -1 : (len >= c0_mul * hm ? 0 : (len >= c1_mul * hm ? 1 : (len >= hm ? 2 : 3)));
+      n01 += cls[k] == 0 ? 1u : (cls[k] == 1 ? 0x10000u : 0u);
+      n23 += cls[k] == 2 ? 1u : (cls[k] == 3 ? 0x10000u : 0u);
       ex += v[k];
+    }
+    uint32_t i01 = n01, i23 = n23;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a = __shfl_up(i01, d, 64), b = __shfl_up(i23, d, 64);
+      if (lane >= (uint32_t)d) { i01 += a; i23 += b; }
+    }
+    const uint32_t tot01 = __shfl(i01, 63, 64), tot23 = __shfl(i23, 63, 64);
+    uint32_t slot = 0;
+    if (lane < 4) {
+      const uint32_t mine = lane == 0 ? tot01 & 0xFFFFu : (lane == 1 ? tot01 >> 16 : (lane == 2 ? tot23 & 0xFFFFu : tot23 >> 16));
+      if (mine) slot = atomicAdd(&s_cls[lane], mine);
+    }
+    uint32_t pos[4];
+    pos[0] = __shfl(slot, 0, 64) + ((i01 - n01) & 0xFFFFu);
+    pos[1] = __shfl(slot, 1, 64) + ((i01 - n01) >> 16);
+    pos[2] = __shfl(slot, 2, 64) + ((i23 - n23) & 0xFFFFu);
+    pos[3] = __shfl(slot, 3, 64) + ((i23 - n23) >> 16);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (cls[k] == c) { work[4 + (size_t)c * T + pos[c]] = t0 + k; pos[c]++; }
     }
     __syncthreads();
     if (tid == 1023) s_carry = ex;
     __syncthreads();
   }
+  if (tid < 4) work[tid] = s_cls[tid];
   if (tid == 0) {
     *R_out = s_carry;
     if (bin_header) { bin_header->hier = 1u; bin_header->Rc = coarse_cap; }
@@ -385,15 +499,23 @@ void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals
                        int gx, int gy, uint32_t* seg_table, uint32_t* tile_tot,
                        uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,
                        const uint32_t* Rc_dev, BlobHeader* bin_header, uint32_t R_cap,
-                       uint32_t coarse_cap) {
+                       uint32_t coarse_cap, uint32_t* work, uint32_t heavy_min) {
   const int sgx = (gx + STILE - 1) / STILE;
   const uint32_t T = (uint32_t)gx * (uint32_t)gy;
   SegDesc* seg = (SegDesc*)seg_desc;
-  hb_seg_setup_kernel<<<1, 1024, 0, s>>>(cranges, run_totals, NS, seg, st_seg, nseg_total, max_seg);
-  hb_count_kernel<<<max_seg, HB_CNT_THREADS, 0, s>>>(seg, nseg_total, ckey_sorted, seg_table);
+  if (run_totals != nullptr && NS <= 256u) {
+    hb_count_kernel<true><<<max_seg, HB_CNT_THREADS, 0, s>>>(seg, nseg_total, ckey_sorted, seg_table,
+                                                             run_totals, NS, cranges, st_seg, max_seg);
+  } else {
+    hb_seg_setup_kernel<<<1, 1024, 0, s>>>(cranges, run_totals, NS, seg, st_seg, nseg_total, max_seg);
+    hb_count_kernel<false><<<max_seg, HB_CNT_THREADS, 0, s>>>(seg, nseg_total, ckey_sorted, seg_table,
+                                                              nullptr, NS, cranges, st_seg, max_seg);
+  }
   hb_tile_prefix_kernel<<<NS, 1024, 0, s>>>(st_seg, seg_table, sgx, gx, gy, tile_tot);
+  uint32_t c0_mul, c1_mul;
+  render_class_multipliers(&c0_mul, &c1_mul);
   hb_tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_tot, tile_start, ranges, R_out, host_word, Rc_dev,
-                                         bin_header, R_cap, coarse_cap);
+                                         bin_header, R_cap, coarse_cap, work, heavy_min, c0_mul, c1_mul);
 }
 
 void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_total, uint32_t max_seg,

@@ -944,11 +944,18 @@ uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min) {
   return 2u * (uint32_t)((size_t)R / ((size_t)render_pc_mul() * heavy_min) + 1);
 }
 
+// Class thresholds of the work lists, as multiples of heavy_min (see classify_tiles_kernel).
+void render_class_multipliers(uint32_t* c0_mul, uint32_t* c1_mul) {
+  const bool pc = render_pc_enabled();
+  *c0_mul = pc ? render_pc_mul() : 8u;
+  *c1_mul = pc ? 8u : 2u;
+}
+
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
-                           uint32_t heavy_min, uint32_t R, bool aux) {
+                           uint32_t heavy_min, uint32_t R, bool aux, bool classified) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   // work[0..3] were zeroed by write_headers_kernel (same stream, earlier in the frame)
@@ -957,8 +964,10 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   const uint32_t pc_slots = render_pc_slots(R, heavy_min);
   // GRPG_RENDER_LDS_PAD (experiment): unused dynamic LDS per workgroup, to cap the kernel's occupancy
   static const uint32_t lds_pad = [] { const char* e = getenv("GRPG_RENDER_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
-  classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
-                                                            pc ? pc_mul : 8u, pc ? 8u : 2u, work);
+  // classified: the hierarchical binning's tile scan has already built the work lists
+  if (!classified)
+    classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
+                                                              pc ? pc_mul : 8u, pc ? 8u : 2u, work);
   // measured: OFF is faster (render 0.232 vs 0.248 ms) -- neighbouring tiles are also similarly
   // LONG, so a contiguous eighth of a list per XCD unbalances the XCDs by more than the L2 hits save
   static const int xcd = [] { const char* e = getenv("GRPG_XCD_SWIZZLE"); return e ? atoi(e) : 0; }();
