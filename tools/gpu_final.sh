@@ -21,3 +21,5 @@ except Exception as e:
     print(sys.argv[1], "unparsable", e)
 PY
 done
+# the N > 1 flow of the driver's launch line, two ranks on this box's one GPU (gloo stands in for RCCL)
+GRPG_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_2rank_gloo.json 2> gpurun_out/final_2rank_gloo.err; echo "2-rank rc=$?"; tail -c 600 gpurun_out/final_2rank_gloo.json
