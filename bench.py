@@ -13,14 +13,22 @@ trajectory mode.  With N GPUs the frames of the synthetic 200-pose drive are sha
 scaling) and the ONLY collective is the RCCL gather of the uint8 frames to rank 0, inside the
 timed region.  Rank 0 prints one JSON line.
 
-The frame loop alternates over `--streams` HIP streams (default 2).  The streams, the output
-buffer and the allocator pools of BOTH streams exist before the warm-up: the W warm-up frames run
-through exactly the loop that is timed afterwards.
+The frame loop alternates over `--streams` HIP streams (default 3) and uses the deferred-count
+entry point (`--deferred 1`, default: GaussianRasterizer.forward_deferred / C ABI
+grpg_forward_deferred): a frame is enqueued without the reference's per-frame host wait for
+num_rendered; every frame's status is checked a few frames behind, inside the timed region, and a
+frame that outgrew the capacity it was enqueued with is rendered again (`frames_rendered_twice` in
+the line's config; normally 0).  The streams, the output buffer and the allocator pools of ALL
+streams exist before the warm-up: the W warm-up frames run through exactly the loop that is timed
+afterwards.
 
 Extra objects in the line:
   roofline        dominant kernel (render_forward_kernel): algorithmic bytes per launch
                   (44*R + 8*T + 20*N, SURVEY.md §8(d) / DESIGN.md §6) / its average duration measured
-                  with HIP events on the op's own stream during the timed region, vs 8 TB/s.
+                  with HIP events on the op's own stream during the timed region, vs 8 TB/s.  With
+                  several frames in flight the kernel SHARES the chip with the other frames' kernels,
+                  so its wall duration (and this fraction) is not its speed alone: roofline_serial is
+                  the same kernel timed with one frame in flight.
   frame_roofline  whole-frame B_alg / ms_per_step (the figure BASELINE.json asks for).
   stages_ms(_serial)  per-stage average device time from HIP events on the op's stream.
   frame_latency   the reference's own method (render.py:30-60): synchronize-bracketed wall time per
@@ -71,11 +79,15 @@ def parse():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the config-5 fwd+bwd side leg")
     ap.add_argument("--no-strong", action="store_true", help="skip the 200-frame strong-scaling leg")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the frame loop alternates over (independent frames; 1 = serial)")
     ap.add_argument("--gather-batch", type=int, default=-1,
                     help="N > 1: frames per asynchronous gather to rank 0 (0 = one gather at the end; "
                          "default: min(25, steps // 5), so that a short run still overlaps its transfers)")
+    ap.add_argument("--deferred", type=int, default=1,
+                    help="1 (default): the frame loop uses forward_deferred -- frames are enqueued without "
+                         "the per-frame wait for num_rendered, their status is checked a few frames "
+                         "behind and an overflowed frame is rendered again; 0: one wait per frame")
     ap.add_argument("--no-delivery", action="store_true",
                     help="skip the host-delivery (rgb8 over PCIe) side measurement")
     ap.add_argument("--binning-mode", type=int, default=0,
@@ -309,6 +321,9 @@ def main():
             rotations=sc.rotations, cov3D_precomp=None, semantics=None)
         return color
 
+    frame_inputs = dict(means3D=sc.means3D, opacities=sc.opacity, shs=sc.shs, scales=sc.scales,
+                        rotations=sc.rotations, cov3D_precomp=None, semantics=None)
+
     K, Wm = args.steps, args.warmup
     if args.gather_batch < 0:
         # only the LAST batch's transfer is exposed: keep it a small share of the run
@@ -329,22 +344,38 @@ def main():
         for st_ in streams:
             st_.wait_stream(torch.cuda.current_stream())
 
+        redone_frames = [0]
+
         def frame_loop(n, first_frame=0, do_gather=False):
             """n frames alternating over the streams; returns the pending gather handles."""
             works = []
+            # --deferred (default): the frames go through forward_deferred -- no host wait for
+            # num_rendered per frame; every frame's status is checked (4 frames behind, the rest
+            # before the loop returns) and a frame that outgrew its capacity is rendered again
+            deferred = tj.DeferredFrames(window=4) if args.deferred else None
             for s in range(n):
                 with torch.cuda.stream(streams[s % ns]):
-                    tj.pack_u8(render_frame(frames_of(first_frame + s)), out=local[s % local.shape[0]])
+                    slot = local[s % local.shape[0]]
+                    if deferred is not None:
+                        deferred.render(rasterizers[frames_of(first_frame + s) % NUM_FRAMES],
+                                        lambda color, slot=slot: tj.pack_u8(color, out=slot), **frame_inputs)
+                    else:
+                        tj.pack_u8(render_frame(frames_of(first_frame + s)), out=slot)
                 # RCCL only for the image gather, issued per batch of frames so that it travels over
                 # xGMI while the next batch renders; only the last batch's transfer is exposed
                 if do_gather and args.gather_batch > 0 and ((s + 1) % GB == 0 or s == n - 1):
                     b0 = (s // GB) * GB
+                    if deferred is not None:      # a batch leaves only with every frame verified
+                        redone_frames[0] += deferred.finish()
+                        deferred.redone = 0
                     for st_ in streams:
                         torch.cuda.current_stream().wait_stream(st_)
                     src = local[b0:s + 1] if backend == "nccl" else local[b0:s + 1].cpu()
                     works.append(dist.gather(
                         src, gather_list=[g[b0:s + 1] for g in gather_bufs] if rank == 0 else None,
                         dst=0, async_op=True))
+            if deferred is not None:
+                redone_frames[0] += deferred.finish()
             for st_ in streams:
                 torch.cuda.current_stream().wait_stream(st_)
             return works
@@ -455,9 +486,14 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             ts0 = time.perf_counter()
-            if backend == "nccl" or world == 1:
+            if (backend == "nccl" or world == 1) and args.deferred:
+                frames = tj.render_sharded(None, NUM_FRAMES, rank, world, gather=True, num_streams=ns,
+                                           gather_batch=args.gather_batch or None, streams=streams,
+                                           frame_source=lambda i: (rasterizers[i % NUM_FRAMES], frame_inputs))
+            elif backend == "nccl" or world == 1:
                 frames = tj.render_sharded(render_frame, NUM_FRAMES, rank, world, gather=True,
-                                           num_streams=ns, gather_batch=args.gather_batch or None)
+                                           num_streams=ns, gather_batch=args.gather_batch or None,
+                                           streams=streams)
             else:   # gloo debugging aid: host-staged frames
                 frames = tj.render_sharded(lambda i: render_frame(i).cpu(), NUM_FRAMES, rank, world,
                                            gather=True, num_streams=1, gather_batch=args.gather_batch or None)
@@ -532,6 +568,9 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": b_render,
                     "avg_launch_ms": render_ms,
+                    "frames_in_flight": ("several (deferred count, %d streams): the kernel's wall time is "
+                                         "shared with the other frames' kernels -- see roofline_serial" % ns)
+                    if args.deferred else "at most %d (one host wait per frame)" % ns,
                     "note": "render is VALU-bound (about 25 flop per pixel-splat pair), see DESIGN.md §6"}
         ach_f = b_frame / (ms_per_step * 1e-3) / 1e9
         line = {
@@ -546,6 +585,7 @@ def main():
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
                        "streams_per_gpu": ns, "binning_mode": "exact" if args.binning_mode else "speculative",
                        "binning_algorithm": "hierarchical" if STAGES is STAGES_HIER else "sort",
+                       "deferred_count": bool(args.deferred), "frames_rendered_twice": redone_frames[0],
                        "gather_batch_frames": args.gather_batch if world > 1 else None,
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
             "roofline": roof,

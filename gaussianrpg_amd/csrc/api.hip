@@ -59,6 +59,24 @@ HostWord* host_word() {
 
 // ---- capacity hints: high-water mark of num_rendered per (device, P, W, H), process-wide ----
 struct CapKey { int dev, P, W, H; };
+
+// ---- deferred frames (grpg_forward_deferred / grpg_frame_status): the count of a frame lands in
+// its own pinned words; nobody waits for it until its status is asked for.  A ring per thread;
+// a slot that comes round again while still pending is resolved first. ----
+struct DeferSlot {
+  int dev = -1;
+  uint32_t* host_ptr = nullptr;
+  uint32_t* dev_ptr = nullptr;
+  hipEvent_t ev = nullptr;
+  int state = 0;            // 0 free, 1 pending (count not looked at yet), 2 resolved
+  int result = 0;           // resolved: num_rendered or GRPG_ERR_CAPACITY
+  uint32_t Rcap = 0, Ccap = 0;
+  bool hier = false;
+  CapKey key{-1, 0, 0, 0};
+};
+constexpr int DEFER_SLOTS = 64;
+thread_local DeferSlot g_defer[DEFER_SLOTS];
+thread_local int g_defer_next = 0;
 struct CapHint {
   CapKey key{-1, 0, 0, 0};
   uint32_t high = 0;      // decaying high-water mark of num_rendered
@@ -309,7 +327,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                  float tan_fovx, float tan_fovy, float* out_color,
                  float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
-                 void* hip_stream, const grpg_model_segment* segs, int nseg, unsigned flags = 0u) {
+                 void* hip_stream, const grpg_model_segment* segs, int nseg, unsigned flags = 0u,
+                 DeferSlot* defer = nullptr) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
@@ -367,6 +386,9 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipGetDevice(&dev));
     HostWord* hw = host_word();
     if (!hw) return fail(GRPG_ERR_HIP, "pinned host word / event allocation failed");
+    // where the speculative frame publishes its count: the thread's word, or the deferred frame's own
+    uint32_t* const pub_ptr = defer ? defer->dev_ptr : hw->dev_ptr;
+    hipEvent_t const pub_ev = defer ? defer->ev : hw->ev;
     // Instance capacity of the binning blob.  Speculative mode (default): from the high-water mark
     // of earlier frames of this (device, P, W, H), so the blob is carved and every kernel of the
     // frame is enqueued BEFORE the host learns num_rendered; the kernels read the count from device
@@ -445,13 +467,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     uint32_t* emit_win = (uint32_t*)(geom + GL.emit_win);
     // num_rendered from the tile counts (the only way the sort path learns it; the hierarchical path
     // uses it when it has no capacity to speculate with): scan, count to the pinned word, event
-    auto scan_tiles = [&]() -> int {
+    auto scan_tiles = [&](uint32_t* word, hipEvent_t ev) -> int {
       tm.mark(2);
       launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, fat_sort ? sorted_gid : nullptr, tiles,
-                          offsets, block_sums, GL.nblocks_scan, &gh->R, hw->dev_ptr, emit_win,
+                          offsets, block_sums, GL.nblocks_scan, &gh->R, word, emit_win,
                           GL.emit_win_cap);
       STAGE_CHECK("offsets scan");
-      HIP_TRY(hipEventRecord(hw->ev, stream));   // fires when num_rendered sits in the pinned word
+      HIP_TRY(hipEventRecord(ev, stream));   // fires when num_rendered sits in the pinned word
       return GRPG_OK;
     };
     auto render_tail = [&](const uint32_t* point_list, uint32_t cap, bool classified) -> int {
@@ -548,10 +570,10 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       launch_hier_count(stream, cranges, runs_from_totals ? btotals : nullptr, NS, binp + L.seg_desc, (uint2*)(binp + L.st_seg),
                         (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
                         (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
-                        (uint32_t*)(binp + L.tile_start), ranges, &gh->R, publish ? hw->dev_ptr : nullptr,
+                        (uint32_t*)(binp + L.tile_start), ranges, &gh->R, publish ? pub_ptr : nullptr,
                         &gh->Rc, (BlobHeader*)binp, cap, ccap, work, heavy_tile_min());
       STAGE_CHECK("tile counts");
-      if (publish) HIP_TRY(hipEventRecord(hw->ev, stream));
+      if (publish) HIP_TRY(hipEventRecord(pub_ev, stream));
       launch_hier_fill(stream, binp + L.seg_desc, (const uint32_t*)(binp + L.nseg), L.max_seg, ckey, cval, rec,
                        cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),
                        (const uint32_t*)(binp + L.tile_start), cap, plist);
@@ -577,7 +599,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     uint32_t Rc_seen = 0u;   // coarse count of this frame, once the host has seen it
     if (speculative) {
       if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, true)) return rc; }
-      else { if (int rc = scan_tiles()) return rc; if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+      else { if (int rc = scan_tiles(pub_ptr, pub_ev)) return rc; if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+      if (defer) {
+        // deferred frame: the count is checked by grpg_frame_status, nothing to wait for here
+        defer->state = 1;
+        defer->Rcap = Rcap; defer->Ccap = Ccap; defer->hier = hier; defer->key = ck;
+        tm.finish();
+        return 0;
+      }
       HIP_TRY(hipEventSynchronize(hw->ev));
       R = hw->host_ptr[0];
       if (hier) Rc_seen = hw->host_ptr[1];
@@ -596,7 +625,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     if (need_exact) {
       const bool redo = speculative;
       if (redo) tm.restart_tail();
-      if (int rc = scan_tiles()) return rc;
+      if (int rc = scan_tiles(hw->dev_ptr, hw->ev)) return rc;
       HIP_TRY(hipEventSynchronize(hw->ev));
       R = hw->host_ptr[0];
       if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
@@ -611,6 +640,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
     update_hint(ck, R, Rc_seen);
     tm.finish();
+    if (defer) { defer->state = 2; defer->result = (int)R; }   // no capacity history: ran synchronously
   } else {
     // P == 0: the reference launches nothing and its pre-zeroed planes stay zero
     // (rasterize_points.cu:85-86,123); write the zeros explicitly.
@@ -624,7 +654,52 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     launch_frame_init(stream, geom, bin, img, 0u, 0u, 0u, (uint32_t)width, (uint32_t)height,
                       (uint32_t)S, ranges, T, work, geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
   }
+  if (defer && defer->state == 0) { defer->state = 2; defer->result = (int)R; }
   return (int)R;
+}
+
+// ---- deferred frames: slot management ----
+int defer_resolve(DeferSlot& d, bool wait) {
+  if (d.state == 2) return d.result;
+  if (d.state != 1) return fail(GRPG_ERR_INVALID_ARGUMENT, "ticket does not name a frame in flight");
+  if (wait) {
+    HIP_TRY(hipEventSynchronize(d.ev));
+  } else {
+    const hipError_t q = hipEventQuery(d.ev);
+    if (q == hipErrorNotReady) return GRPG_ERR_NOT_READY;
+    if (q != hipSuccess) return fail(GRPG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+  }
+  const uint32_t R = d.host_ptr[0], Rc = d.hier ? d.host_ptr[1] : 0u;
+  // a clamped coarse list undercounts R; either overflow invalidates the frame's outputs
+  const bool ok = R <= d.Rcap && (!d.hier || Rc <= d.Ccap) && R <= 0x7FFFFFFFu;
+  update_hint(d.key, R > Rc ? R : Rc, Rc);   // (an undercounted R is at least the coarse count)
+  d.state = 2;
+  d.result = ok ? (int)R : GRPG_ERR_CAPACITY;
+  return d.result;
+}
+
+DeferSlot* defer_acquire(int* ticket) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const int idx = g_defer_next;
+  g_defer_next = (g_defer_next + 1) % DEFER_SLOTS;
+  DeferSlot& d = g_defer[idx];
+  if (d.state == 1) (void)defer_resolve(d, true);   // comes round while pending: look at it now
+  if (d.host_ptr && d.dev != dev) {                  // pinned words map into one device's space
+    (void)hipHostFree(d.host_ptr);
+    (void)hipEventDestroy(d.ev);
+    d = DeferSlot{};
+  }
+  if (!d.host_ptr) {
+    if (hipHostMalloc((void**)&d.host_ptr, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+    if (hipHostGetDevicePointer((void**)&d.dev_ptr, d.host_ptr, 0) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    d.dev = dev;
+  }
+  d.host_ptr[0] = 0u; d.host_ptr[1] = 0u;
+  d.state = 0; d.result = 0;
+  *ticket = idx;
+  return &d;
 }
 
 int check_segments(const grpg_model_segment* segs, int nseg, int M, long long* P_out) {
@@ -683,6 +758,42 @@ int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_a
                       semantics, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                       viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth,
                       out_alpha, out_semantic, radii, debug, hip_stream, nullptr, 0, flags);
+}
+
+int grpg_forward_deferred(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                          void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D,
+                          int M, int S, const float* background, int width, int height,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* semantics, const float* opacities, const float* scales,
+                          float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                          float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                          float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
+                          void* hip_stream, unsigned flags, int* ticket) {
+  (void)prefiltered;
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (!ticket) return fail(GRPG_ERR_INVALID_ARGUMENT, "ticket must not be NULL");
+  DeferSlot* d = defer_acquire(ticket);
+  if (!d) return fail(GRPG_ERR_HIP, "pinned status words / event allocation failed");
+  const int rc = forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                              image_user, P, D, M, S, background, width, height, means3D, shs,
+                              colors_precomp, semantics, opacities, scales, scale_modifier, rotations,
+                              cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+                              out_color, out_depth, out_alpha, out_semantic, radii, debug, hip_stream,
+                              nullptr, 0, flags, d);
+  if (rc < 0) { d->state = 2; d->result = rc; return rc; }
+  return GRPG_OK;
+}
+
+int grpg_frame_status(int ticket, int wait, int* num_rendered) {
+  g_last_error.clear();
+  if (ticket < 0 || ticket >= DEFER_SLOTS) return fail(GRPG_ERR_INVALID_ARGUMENT, "no such ticket");
+  const int r = defer_resolve(g_defer[ticket], wait != 0);
+  if (r >= 0) { if (num_rendered) *num_rendered = r; return GRPG_OK; }
+  if (r == GRPG_ERR_CAPACITY)
+    g_last_error = "the frame overflowed the capacity it was enqueued with; render it again";
+  return r;
 }
 
 int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,

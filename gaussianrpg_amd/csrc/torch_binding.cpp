@@ -60,7 +60,8 @@ void require_device(const torch::Tensor& means3D) {
 
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor, torch::Tensor, torch::Tensor>
-RasterizeGaussiansImpl(const unsigned flags, const torch::Tensor& background, const torch::Tensor& means3D,
+RasterizeGaussiansImpl(const unsigned flags, int* ticket /* non-NULL: deferred frame */,
+                   const torch::Tensor& background, const torch::Tensor& means3D,
                    const torch::Tensor& colors, const torch::Tensor& semantics,
                    const torch::Tensor& opacity, const torch::Tensor& scales,
                    const torch::Tensor& rotations, const float scale_modifier,
@@ -121,11 +122,18 @@ RasterizeGaussiansImpl(const unsigned flags, const torch::Tensor& background, co
     // The call blocks once on the stream (num_rendered read-back): let other Python threads drive
     // their own streams meanwhile.  The blob callbacks only touch ATen, never Python objects.
     pybind11::gil_scoped_release nogil;
-    rendered = grpg_forward_flags(
-        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree,
-        M, S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov,
-        p_view, p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, p_out_color, p_out_depth,
-        p_out_alpha, p_out_sem, p_radii, debug ? 1 : 0, (void*)stream, flags);
+    if (ticket)
+      rendered = grpg_forward_deferred(
+          resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree,
+          M, S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov,
+          p_view, p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, p_out_color, p_out_depth,
+          p_out_alpha, p_out_sem, p_radii, debug ? 1 : 0, (void*)stream, flags, ticket);
+    else
+      rendered = grpg_forward_flags(
+          resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree,
+          M, S, p_bg, W, H, p_means, p_sh, p_col, p_sem, p_op, p_sc, scale_modifier, p_rot, p_cov,
+          p_view, p_proj, p_cam, tan_fovx, tan_fovy, prefiltered ? 1 : 0, p_out_color, p_out_depth,
+          p_out_alpha, p_out_sem, p_radii, debug ? 1 : 0, (void*)stream, flags);
   }
   if (rendered < 0) raise_abi_error("grpg_forward", rendered);
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, out_semantic, radii,
@@ -145,10 +153,32 @@ RasterizeGaussiansImpl(const unsigned flags, const torch::Tensor& background, co
       prefiltered, debug
 
 // the reference's entry point (rasterize_points.cu:35-124): blobs valid for the backward
-auto RasterizeGaussians(GRPG_RASTERIZE_ARGS) { return RasterizeGaussiansImpl(0u, GRPG_RASTERIZE_PASS); }
+auto RasterizeGaussians(GRPG_RASTERIZE_ARGS) { return RasterizeGaussiansImpl(0u, nullptr, GRPG_RASTERIZE_PASS); }
 // same call when no backward can follow (additive): n_contrib is not produced
 auto RasterizeGaussiansEval(GRPG_RASTERIZE_ARGS) {
-  return RasterizeGaussiansImpl(GRPG_FORWARD_NO_BACKWARD, GRPG_RASTERIZE_PASS);
+  return RasterizeGaussiansImpl(GRPG_FORWARD_NO_BACKWARD, nullptr, GRPG_RASTERIZE_PASS);
+}
+// ... and without the per-frame wait for num_rendered (additive; grpg_forward_deferred): returns
+// (ticket, color, depth, alpha, semantic, radii); the outputs may be consumed by further work on
+// the stream, but are only KNOWN good once frame_status(ticket) says so
+auto RasterizeGaussiansEvalDeferred(GRPG_RASTERIZE_ARGS) {
+  int ticket = -1;
+  auto r = RasterizeGaussiansImpl(GRPG_FORWARD_NO_BACKWARD, &ticket, GRPG_RASTERIZE_PASS);
+  return std::make_tuple(ticket, std::get<1>(r), std::get<2>(r), std::get<3>(r), std::get<4>(r),
+                         std::get<5>(r));
+}
+// (ok, num_rendered): ok = 1 valid, 0 the frame must be rendered again, -1 not ready (wait = false)
+std::tuple<int, int> FrameStatus(const int ticket, const bool wait) {
+  int R = 0, rc;
+  {
+    pybind11::gil_scoped_release nogil;
+    rc = grpg_frame_status(ticket, wait ? 1 : 0, &R);
+  }
+  if (rc == GRPG_OK) return std::make_tuple(1, R);
+  if (rc == GRPG_ERR_CAPACITY) return std::make_tuple(0, 0);
+  if (rc == GRPG_ERR_NOT_READY) return std::make_tuple(-1, 0);
+  raise_abi_error("grpg_frame_status", rc);
+  return std::make_tuple(0, 0);
 }
 
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -601,6 +631,8 @@ torch::Tensor distCUDA2(const torch::Tensor& points) {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians", &RasterizeGaussians);
   m.def("rasterize_gaussians_eval", &RasterizeGaussiansEval);
+  m.def("rasterize_gaussians_eval_deferred", &RasterizeGaussiansEvalDeferred);
+  m.def("frame_status", &FrameStatus, pybind11::arg("ticket"), pybind11::arg("wait") = true);
   m.def("distCUDA2", &distCUDA2);
   m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
   m.def("mark_visible", &markVisible);

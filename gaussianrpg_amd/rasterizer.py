@@ -165,6 +165,32 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, semantics, opacities,
                                    scales, rotations, cov3D_precomp, rs)
 
+    def forward_deferred(self, means3D, opacities, shs=None, colors_precomp=None, scales=None,
+                         rotations=None, cov3D_precomp=None, semantics=None):
+        """Evaluation-only forward WITHOUT the per-frame wait for num_rendered (additive; C ABI
+        grpg_forward_deferred).  Returns (ticket, color, radii, depth, alpha, semantic): the
+        outputs can feed further work on the stream at once, but they are only KNOWN valid when
+        frame_ok(ticket) returns True -- on False the frame outgrew the capacity it was enqueued
+        with and must be rendered again (forward() does).  gaussianrpg_amd.trajectory.DeferredFrames
+        wraps the bookkeeping."""
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        shs = _empty() if shs is None else shs
+        colors_precomp = _empty() if colors_precomp is None else colors_precomp
+        scales = _empty() if scales is None else scales
+        rotations = _empty() if rotations is None else rotations
+        cov3D_precomp = _empty() if cov3D_precomp is None else cov3D_precomp
+        if semantics is None:
+            semantics = torch.zeros(means3D.shape[0], 0, dtype=torch.float32, device=means3D.device)
+        with torch.no_grad():
+            ticket, color, depth, alpha, semantic, radii = _C.rasterize_gaussians_eval_deferred(
+                rs.bg, means3D, colors_precomp, semantics, opacities, scales, rotations,
+                rs.scale_modifier, cov3D_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                rs.tanfovy, rs.image_height, rs.image_width, shs, rs.sh_degree, rs.campos,
+                rs.prefiltered, rs.debug)
+        return ticket, color, radii, depth, alpha, semantic
+
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         """(radii int32[P], means2D [P,2]) without colour/conic (reference :235-259)."""
         rs = self.raster_settings
@@ -176,6 +202,13 @@ class GaussianRasterizer(nn.Module):
                 means3D, scales, rotations, rs.scale_modifier, cov3D_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
                 rs.prefiltered, rs.debug)
+
+
+def frame_ok(ticket, wait=True):
+    """Status of a forward_deferred frame: True = outputs valid, False = render it again, None =
+    not finished yet (wait=False only)."""
+    ok, _ = _C.frame_status(int(ticket), bool(wait))
+    return None if ok < 0 else bool(ok)
 
 
 def debug_export(geom, binning, img, P, R, image_height, image_width):

@@ -120,9 +120,10 @@ class FrameDelivery:
         return self.host[slot].numpy()
 
 
-def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int, rank: int,
+def render_sharded(render_frame: Optional[Callable[[int], torch.Tensor]], num_frames: int, rank: int,
                    world: int, *, gather: bool = True, group=None, num_streams: int = 2,
-                   gather_batch: Optional[int] = None) -> Optional[torch.Tensor]:
+                   gather_batch: Optional[int] = None, frame_source=None,
+                   streams=None) -> Optional[torch.Tensor]:
     """Render this rank's frames with ``render_frame(i) -> float [3,H,W]`` and gather all frames
     on rank 0 as uint8 [num_frames,3,H,W] (None on other ranks / when gather=False).
 
@@ -132,6 +133,14 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
     transfer is exposed).  On a GPU the frame loop alternates over ``num_streams`` HIP streams:
     frames are independent, so the VALU-bound render tail of frame k overlaps the HBM-bound
     preprocess / binning of frame k+1.
+
+    ``frame_source(i) -> (GaussianRasterizer, inputs)`` instead of ``render_frame`` (GPU only): the
+    frames go through ``forward_deferred`` (DeferredFrames below) -- the host does not wait for
+    num_rendered once per frame, every frame's status is checked a few frames behind (all of a
+    batch before its gather) and a frame that outgrew its capacity is rendered again.
+
+    ``streams``: side streams to use instead of fresh ones (a caller that renders tape after tape
+    keeps them, so their caching-allocator pools already hold the op's blobs).
     """
     # checked identically on EVERY rank before any collective, so a mis-sized job fails on all
     # ranks instead of leaving the others hanging in dist.gather
@@ -143,13 +152,28 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
     local = None
     bufs = None
     works = []
+    given_streams = list(streams) if streams else None
     streams = None
     on_gpu = False
+    deferred = DeferredFrames(window=4) if frame_source is not None else None
     for j in range(per_rank):
-        if j < len(mine):
+        if j < len(mine) and deferred is not None:
             i = mine[j]
-            if streams is None and torch.cuda.is_available() and num_streams > 1:
-                streams = [torch.cuda.Stream() for _ in range(num_streams)]
+            rasterizer, inputs = frame_source(i)
+            if streams is None:
+                streams = given_streams or [torch.cuda.Stream() for _ in range(max(1, num_streams))]
+                rs = rasterizer.raster_settings
+                on_gpu = True
+                local = torch.zeros((per_rank, 3, int(rs.image_height), int(rs.image_width)),
+                                    dtype=torch.uint8, device=inputs["means3D"].device)
+                for st in streams:
+                    st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[j % len(streams)]):
+                deferred.render(rasterizer, lambda color, slot=local[j]: pack_u8(color, out=slot), **inputs)
+        elif j < len(mine):
+            i = mine[j]
+            if streams is None and torch.cuda.is_available() and (num_streams > 1 or given_streams):
+                streams = given_streams or [torch.cuda.Stream() for _ in range(num_streams)]
             if streams:
                 st_j = streams[j % len(streams)]
                 with torch.cuda.stream(st_j):
@@ -173,6 +197,8 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
         if batched and ((j + 1) % gather_batch == 0 or j == per_rank - 1):
             import torch.distributed as dist
             b0 = (j // gather_batch) * gather_batch
+            if deferred is not None:
+                deferred.finish()    # a batch leaves only with every frame verified
             if streams and on_gpu:   # the collective must see the frames of this batch
                 for st in streams:
                     torch.cuda.current_stream().wait_stream(st)
@@ -181,6 +207,8 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
             works.append(dist.gather(local[b0:j + 1],
                                      gather_list=[b[b0:j + 1] for b in bufs] if rank == 0 else None,
                                      dst=0, group=group, async_op=True))
+    if deferred is not None:
+        deferred.finish()
     if streams:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
@@ -202,3 +230,43 @@ def render_sharded(render_frame: Callable[[int], torch.Tensor], num_frames: int,
         idx = shard_frames(num_frames, r, world)
         out[idx] = bufs[r][:len(idx)]
     return out
+
+
+class DeferredFrames:
+    """Frame loop without the per-frame host wait (GaussianRasterizer.forward_deferred).
+
+    render(key, rasterizer, consume, **inputs) enqueues one evaluation frame and hands its colour
+    plane to `consume` (e.g. a pack into the frame's slot of an output buffer) on the current
+    stream; the frame's ticket is kept.  Tickets older than `window` frames are checked as the loop
+    goes (they have long finished: no stall), the rest in finish().  A frame whose instance list
+    outgrew the capacity it was enqueued with is rendered again through the synchronous entry point
+    and consumed again -- `consume` must therefore be idempotent for a key (overwrite, not append).
+    """
+
+    def __init__(self, window=4):
+        self.window = int(window)
+        self.pending = []          # (ticket, rasterizer, consume, inputs, stream)
+        self.redone = 0
+
+    def render(self, rasterizer, consume, **inputs):
+        out = rasterizer.forward_deferred(**inputs)
+        consume(out[1])
+        self.pending.append((out[0], rasterizer, consume, inputs, torch.cuda.current_stream()))
+        while len(self.pending) > self.window:
+            self._check(self.pending.pop(0))
+
+    def _check(self, entry):
+        from .rasterizer import frame_ok
+        ticket, rasterizer, consume, inputs, stream = entry
+        if frame_ok(ticket, wait=True):
+            return
+        self.redone += 1
+        with torch.cuda.stream(stream), torch.no_grad():
+            consume(rasterizer(means2D=None, **inputs)[0])
+
+    def finish(self):
+        """Every frame rendered so far is valid (and consumed) once this returns and the streams
+        have been synchronised."""
+        while self.pending:
+            self._check(self.pending.pop(0))
+        return self.redone

@@ -54,7 +54,9 @@ enum {
   GRPG_ERR_NO_DEVICE = -2,
   GRPG_ERR_HIP = -3,        /* a HIP call or kernel failed; see grpg_last_error() */
   GRPG_ERR_ALLOC = -4,      /* a grpg_alloc_fn returned NULL */
-  GRPG_ERR_BAD_BUFFER = -5  /* a blob handed to grpg_backward was not produced by grpg_forward */
+  GRPG_ERR_BAD_BUFFER = -5, /* a blob handed to grpg_backward was not produced by grpg_forward */
+  GRPG_ERR_CAPACITY = -6,   /* grpg_frame_status: the deferred frame overflowed its capacity; redo it */
+  GRPG_ERR_NOT_READY = -7   /* grpg_frame_status(wait = 0): the frame's count has not arrived yet */
 };
 
 /* Replaces std::function<char*(size_t N)> (rasterizer.h:33-35, rasterize_points.cu:27-33):
@@ -123,6 +125,41 @@ GRPG_API int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_use
                  float tan_fovx, float tan_fovy, int prefiltered,
                  float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                  int* radii, int debug, void* hip_stream, unsigned flags);
+
+/*
+ * Deferred frames (additive; for frame loops that do not need num_rendered at once: trajectory /
+ * batch rendering).  grpg_forward_deferred enqueues the frame like grpg_forward_flags but does NOT
+ * wait for num_rendered: the host returns as soon as the launches are queued, so any number of
+ * frames can be in flight per thread (the reference, and grpg_forward, block once per frame,
+ * rasterizer_impl.cu:284).  The frame is enqueued for the capacities remembered from earlier frames
+ * of the same (device, P, W, H); *ticket names it.  grpg_frame_status(ticket, wait, &num_rendered)
+ * later tells whether the frame fitted:
+ *   GRPG_OK             outputs valid, *num_rendered set
+ *   GRPG_ERR_CAPACITY   the instance (or coarse) list outgrew the capacity: the outputs of that
+ *                       frame are invalid and it must be rendered again -- with grpg_forward /
+ *                       grpg_forward_flags, which always fits the frame and records its capacity
+ *                       for the frames that follow
+ *   GRPG_ERR_NOT_READY  wait == 0 and the count has not arrived yet
+ * A caller must not use a deferred frame's outputs before its status is GRPG_OK.  With no history
+ * for the shape (or in GRPG_BINNING_EXACT mode) the call runs synchronously and the ticket is
+ * resolved on return.  Tickets are per host thread, 64 in flight; an unresolved ticket that comes
+ * round again is resolved (waited for) first and then reused.  Pass GRPG_FORWARD_NO_BACKWARD: the
+ * blobs of a frame whose count is unknown cannot be handed to grpg_backward.
+ */
+GRPG_API int grpg_forward_deferred(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 int P, int D, int M, int S,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* semantics, const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, int prefiltered,
+                 float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
+                 int* radii, int debug, void* hip_stream, unsigned flags, int* ticket);
+GRPG_API int grpg_frame_status(int ticket, int wait, int* num_rendered);
 
 /*
  * Fused scene-graph composition (additive, no counterpart in the

@@ -213,6 +213,23 @@ def test_render_sharded_gpu_world1(dev):
     assert torch.equal(one, frames)
 
 
+def test_render_sharded_deferred_frames(dev):
+    """The same tape through render_sharded's deferred-count path (forward_deferred: no host wait
+    per frame, statuses checked behind the loop) is byte-identical."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.street_scene(50_000, seed=77).to(dev)
+    tape = tj.make_tape(8)
+    rasts = [GaussianRasterizer(GaussianRasterizationSettings(
+        **hz.settings_kwargs(tj.camera_from_tape(e, W=480, H=320, device=dev), 1))) for e in tape]
+    inputs = dict(means3D=sc.means3D, opacities=sc.opacity, shs=sc.shs, scales=sc.scales,
+                  rotations=sc.rotations)
+    want = tj.render_sharded(_hip_frame_renderer(dev, 8), 8, 0, 1, num_streams=2)
+    for ns in (1, 2, 3):
+        got = tj.render_sharded(None, 8, 0, 1, num_streams=ns, frame_source=lambda i: (rasts[i], inputs))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
