@@ -7,8 +7,9 @@ for i in 1 2 3; do
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/final_driver_$i.json 2> gpurun_out/final_driver_$i.err; echo "driver run $i rc=$?"
 done
 timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train > gpurun_out/final_200.json 2> gpurun_out/final_200.err; echo "200 rc=$?"
-timeout 300 python bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-train --no-strong --no-delivery > gpurun_out/final_streams1.json 2> gpurun_out/final_streams1.err
-timeout 300 python bench.py --steps 20 --warmup 5 --binning-mode 1 --no-cpu-baseline --no-train --no-strong --no-delivery > gpurun_out/final_exact.json 2> gpurun_out/final_exact.err
+timeout 300 python bench.py --steps 20 --warmup 5 --streams 1 --deferred 0 --no-cpu-baseline --no-train --no-strong --no-delivery > gpurun_out/final_streams1.json 2> gpurun_out/final_streams1.err
+timeout 300 python bench.py --steps 20 --warmup 5 --streams 2 --deferred 0 --no-cpu-baseline --no-train --no-delivery > gpurun_out/final_sync2.json 2> gpurun_out/final_sync2.err
+timeout 300 python bench.py --steps 20 --warmup 5 --binning-mode 1 --deferred 0 --streams 2 --no-cpu-baseline --no-train --no-strong --no-delivery > gpurun_out/final_exact.json 2> gpurun_out/final_exact.err
 bash tools/profile_gpu.sh > gpurun_out/profile_run.log 2>&1; grep "rc=" gpurun_out/profile_run.log
 for f in gpurun_out/final_*.json; do python - "$f" <<'PY'
 import json,sys
