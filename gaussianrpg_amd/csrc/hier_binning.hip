@@ -8,12 +8,17 @@
 //                 order: Rc ~ 0.2 R entries (emit_kernel<true> in binning.hip, slot-parallel)
 //   coarse sort   stable partition of the Rc entries by super-tile id (<= 8 bits at 1920x1280:
 //                 ONE radix pass whose histogram the coarse emit leaves behind)
-//   segments      every super-tile's run is cut into segments of 1024 entries (seg_setup)
+//   segments      every super-tile's run is cut into segments of 1024 entries (numbered by the
+//                 count kernel's workgroups themselves from the partition's digit totals; a
+//                 separate setup launch only beyond 256 super-tiles)
 //   count         per segment: how many of its Gaussians touch each of the super-tile's 64 tiles
 //   prefix, scan  per tile the exclusive prefix over its super-tile's segments; exclusive scan
-//                 over all tiles = the tile ranges; total = num_rendered
+//                 over all tiles = the tile ranges, total = num_rendered; the same launch sorts
+//                 the tiles into the render's work lists
 //   fill          per segment and tile: the touching Gaussians, in order, go to
-//                 point_list[tile_start + segment prefix ...] with their quarter-reach mask
+//                 point_list[tile_start + segment prefix ...] with their quarter-reach mask (a
+//                 wave per tile COLUMN: the splat's extent over the column strip gives the masks
+//                 of the column's 8 tiles at once)
 //
 // Order argument: the coarse sort is stable from depth order, segments are consecutive pieces of a
 // super-tile's run, and inside a segment the entries of a tile are written in segment order: the
@@ -29,11 +34,13 @@ namespace grpg {
 
 constexpr int HB_SEG = 1024;        // coarse entries per segment
 constexpr int HB_CNT_THREADS = 256;
-constexpr int HB_FILL_THREADS = 512;   // 8 waves: one per tile row of the super-tile
+constexpr int HB_FILL_THREADS = 512;   // 8 waves: one per tile column of the super-tile
 
 struct SegDesc { uint32_t st, begin, end, pad; };
 
-// ---- segments: cranges[st] (run of super-tile st in the sorted coarse list) -> descriptors ----
+// ---- segments: cranges[st] (run of super-tile st in the sorted coarse list) -> descriptors.
+// Stand-alone launch for grids of more than 256 super-tiles (hb_count_kernel<true> does this
+// itself otherwise). ----
 __global__ void __launch_bounds__(1024)
 hb_seg_setup_kernel(uint2* __restrict__ cranges, const uint32_t* __restrict__ run_totals,
                     const uint32_t NS, SegDesc* __restrict__ seg,

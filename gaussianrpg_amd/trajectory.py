@@ -235,7 +235,7 @@ def render_sharded(render_frame: Optional[Callable[[int], torch.Tensor]], num_fr
 class DeferredFrames:
     """Frame loop without the per-frame host wait (GaussianRasterizer.forward_deferred).
 
-    render(key, rasterizer, consume, **inputs) enqueues one evaluation frame and hands its colour
+    render(rasterizer, consume, **inputs) enqueues one evaluation frame and hands its colour
     plane to `consume` (e.g. a pack into the frame's slot of an output buffer) on the current
     stream; the frame's ticket is kept.  Tickets older than `window` frames are checked as the loop
     goes (they have long finished: no stall), the rest in finish().  A frame whose instance list
@@ -251,7 +251,8 @@ class DeferredFrames:
     def render(self, rasterizer, consume, **inputs):
         out = rasterizer.forward_deferred(**inputs)
         consume(out[1])
-        self.pending.append((out[0], rasterizer, consume, inputs, torch.cuda.current_stream()))
+        stream = torch.cuda.current_stream() if out[1].is_cuda else None
+        self.pending.append((out[0], rasterizer, consume, inputs, stream))
         while len(self.pending) > self.window:
             self._check(self.pending.pop(0))
 
@@ -261,8 +262,12 @@ class DeferredFrames:
         if frame_ok(ticket, wait=True):
             return
         self.redone += 1
-        with torch.cuda.stream(stream), torch.no_grad():
-            consume(rasterizer(means2D=None, **inputs)[0])
+        with torch.no_grad():
+            if stream is None:
+                consume(rasterizer(means2D=None, **inputs)[0])
+            else:
+                with torch.cuda.stream(stream):
+                    consume(rasterizer(means2D=None, **inputs)[0])
 
     def finish(self):
         """Every frame rendered so far is valid (and consumed) once this returns and the streams

@@ -1,10 +1,7 @@
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_ab.sh rs2 GRPG_RENDER_STREAM=2
-AB_ARGS='--steps 200' bash tools/gpu_ab.sh rs2_200 GRPG_RENDER_STREAM=2
-AB_ARGS='--streams 2' bash tools/gpu_ab.sh rs2_s2 GRPG_RENDER_STREAM=2
-AB_ARGS='--streams 2' bash tools/gpu_ab.sh base_s2
-python - <<'PY'
-import json
-for t in ("rs2","rs2_200","rs2_s2","base_s2"):
-    d=json.loads(open("gpurun_out/ab_%s.json"%t).read().strip().splitlines()[-1]); print(t, round(d["value"],1), "roof", round(d["roofline"]["frac"],3), round(d["roofline"]["avg_launch_ms"],3), "frame", round(d["frame_roofline"]["frac"],3), "lat", round(d["frame_latency"]["median_ms"],3), "sum", round(d["serial_stage_sum_ms"],3))
-PY
+AB_ARGS='--steps 100' bash tools/gpu_ab.sh hm256
+AB_ARGS='--steps 100' bash tools/gpu_ab.sh hm128 GRPG_HEAVY_MIN=128
+AB_ARGS='--steps 100' bash tools/gpu_ab.sh hm512 GRPG_HEAVY_MIN=512
+AB_ARGS='--steps 100' bash tools/gpu_ab.sh pc16 GRPG_PC_MUL=16
+AB_ARGS='--steps 100' bash tools/gpu_ab.sh pc64 GRPG_PC_MUL=64
+AB_ARGS='--steps 100' bash tools/gpu_ab.sh classic GRPG_DEPTH_SORT=classic
