@@ -73,6 +73,7 @@ struct DeferSlot {
   uint32_t Rcap = 0, Ccap = 0;
   bool hier = false;
   CapKey key{-1, 0, 0, 0};
+  int generation = 0;       // ticket = generation * DEFER_SLOTS + slot: a recycled slot's old tickets expire
 };
 constexpr int DEFER_SLOTS = 64;
 thread_local DeferSlot g_defer[DEFER_SLOTS];
@@ -688,7 +689,9 @@ DeferSlot* defer_acquire(int* ticket) {
   if (d.host_ptr && d.dev != dev) {                  // pinned words map into one device's space
     (void)hipHostFree(d.host_ptr);
     (void)hipEventDestroy(d.ev);
+    const int gen = d.generation;
     d = DeferSlot{};
+    d.generation = gen;
   }
   if (!d.host_ptr) {
     if (hipHostMalloc((void**)&d.host_ptr, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
@@ -698,7 +701,8 @@ DeferSlot* defer_acquire(int* ticket) {
   }
   d.host_ptr[0] = 0u; d.host_ptr[1] = 0u;
   d.state = 0; d.result = 0;
-  *ticket = idx;
+  d.generation = (d.generation + 1) & 0xFFFFF;
+  *ticket = d.generation * DEFER_SLOTS + idx;
   return &d;
 }
 
@@ -788,8 +792,11 @@ int grpg_forward_deferred(grpg_alloc_fn geometry_alloc, void* geometry_user, grp
 
 int grpg_frame_status(int ticket, int wait, int* num_rendered) {
   g_last_error.clear();
-  if (ticket < 0 || ticket >= DEFER_SLOTS) return fail(GRPG_ERR_INVALID_ARGUMENT, "no such ticket");
-  const int r = defer_resolve(g_defer[ticket], wait != 0);
+  if (ticket < 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "no such ticket");
+  DeferSlot& slot = g_defer[ticket % DEFER_SLOTS];
+  if (slot.generation != ticket / DEFER_SLOTS || slot.state == 0)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "no such ticket on this thread (unknown, or its slot has been reused)");
+  const int r = defer_resolve(slot, wait != 0);
   if (r >= 0) { if (num_rendered) *num_rendered = r; return GRPG_OK; }
   if (r == GRPG_ERR_CAPACITY)
     g_last_error = "the frame overflowed the capacity it was enqueued with; render it again";

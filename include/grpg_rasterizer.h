@@ -142,8 +142,9 @@ GRPG_API int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_use
  *   GRPG_ERR_NOT_READY  wait == 0 and the count has not arrived yet
  * A caller must not use a deferred frame's outputs before its status is GRPG_OK.  With no history
  * for the shape (or in GRPG_BINNING_EXACT mode) the call runs synchronously and the ticket is
- * resolved on return.  Tickets are per host thread, 64 in flight; an unresolved ticket that comes
- * round again is resolved (waited for) first and then reused.  Pass GRPG_FORWARD_NO_BACKWARD: the
+ * resolved on return.  Tickets are per host thread, 64 in flight; when the ring comes round, an
+ * unresolved frame is resolved (waited for) first and its ticket expires (GRPG_ERR_INVALID_ARGUMENT
+ * from then on).  Pass GRPG_FORWARD_NO_BACKWARD: the
  * blobs of a frame whose count is unknown cannot be handed to grpg_backward.
  */
 GRPG_API int grpg_forward_deferred(grpg_alloc_fn geometry_alloc, void* geometry_user,

@@ -108,9 +108,19 @@ def test_overflowing_frame_is_reported_and_rendered_again(dev):
                 _C.reset_capacity_hints()
 
 
-def test_frame_status_rejects_unknown_tickets(dev):
-    from gaussianrpg_amd.rasterizer import _C
+def test_frame_status_rejects_unknown_and_expired_tickets(dev):
+    from gaussianrpg_amd.rasterizer import _C, frame_ok
     with pytest.raises(RuntimeError):
         _C.frame_status(10 ** 6, True)
     with pytest.raises(RuntimeError):
         _C.frame_status(-1, True)
+    d = hz.toy_scene(500, seed=3, sh_degree=1).to(dev)
+    r = _rasterizer(dev, d, 0, 64, 48)
+    with torch.no_grad():
+        first = r.forward_deferred(**_inputs(d))[0]
+        assert frame_ok(first) is True
+        for _ in range(64):                      # the ring of 64 slots comes round
+            last = r.forward_deferred(**_inputs(d))[0]
+        assert frame_ok(last) is True
+        with pytest.raises(RuntimeError):
+            _C.frame_status(first, True)         # its slot belongs to a later frame now
