@@ -72,7 +72,7 @@ static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 // radix sort geometry
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 8;
-constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 2048 keys per workgroup
 constexpr int RS_MAX_BITS = 8;
 constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
 

@@ -42,39 +42,12 @@ struct SegDesc { uint32_t st, begin, end, pad; };
 // Stand-alone launch for grids of more than 256 super-tiles (hb_count_kernel<true> does this
 // itself otherwise). ----
 __global__ void __launch_bounds__(1024)
-hb_seg_setup_kernel(uint2* __restrict__ cranges, const uint32_t* __restrict__ run_totals,
-                    const uint32_t NS, SegDesc* __restrict__ seg,
+hb_seg_setup_kernel(const uint2* __restrict__ cranges, const uint32_t NS, SegDesc* __restrict__ seg,
                     uint2* __restrict__ st_seg /* [NS] (first segment, count) */,
                     uint32_t* __restrict__ nseg_total, const uint32_t max_seg) {
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (run_totals != nullptr) {
-    // runs from the per-super-tile entry counts (NS <= 256 here): exclusive scan
-    __shared__ uint32_t s_len[256];
-    if (tid < 256) s_len[tid] = tid < NS ? run_totals[tid] : 0u;
-    __syncthreads();
-    if (tid < 64) {
-      uint32_t v[4], sum = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { v[k] = s_len[tid * 4 + k]; sum += v[k]; }
-      uint32_t inc = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= (uint32_t)d) inc += t;
-      }
-      uint32_t ex = inc - sum;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t st = tid * 4 + k;
-        if (st < NS) cranges[st] = v[k] ? make_uint2(ex, ex + v[k]) : make_uint2(0u, 0u);
-        ex += v[k];
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
   if (tid == 0) s_carry = 0;
   __syncthreads();
   for (uint32_t base = 0; base < NS; base += 1024) {
@@ -514,7 +487,7 @@ void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals
     hb_count_kernel<true><<<max_seg, HB_CNT_THREADS, 0, s>>>(seg, nseg_total, ckey_sorted, seg_table,
                                                              run_totals, NS, cranges, st_seg, max_seg);
   } else {
-    hb_seg_setup_kernel<<<1, 1024, 0, s>>>(cranges, run_totals, NS, seg, st_seg, nseg_total, max_seg);
+    hb_seg_setup_kernel<<<1, 1024, 0, s>>>(cranges, NS, seg, st_seg, nseg_total, max_seg);
     hb_count_kernel<false><<<max_seg, HB_CNT_THREADS, 0, s>>>(seg, nseg_total, ckey_sorted, seg_table,
                                                               nullptr, NS, cranges, st_seg, max_seg);
   }
