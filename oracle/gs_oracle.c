@@ -18,9 +18,19 @@
  *   executed here, and the reference ships no golden vectors / asserts for
  *   this path (script/test_gaussian_rasterization.py compares nothing).
  *   What IS pinned, by vectors generated from the importable reference
- *   Python (tests/golden/make_golden.py): SH->RGB (lib/utils/sh_utils.py
- *   eval_sh) and the camera/projection conventions (lib/utils/
- *   graphics_utils.py).  Everything else (EWA, tile binning, blend, all of
+ *   Python (tests/golden/make_golden.py):
+ *     - SH->RGB, computeColorFromSH (lib/utils/sh_utils.py eval_sh;
+ *       ref_sh.npz, tests/test_oracle_golden.py);
+ *     - the camera / projection conventions (lib/utils/graphics_utils.py;
+ *       ref_camera.npz);
+ *     - the quaternion -> R convention of quat_to_R_glm / computeCov3D
+ *       (lib/utils/general_utils.py quaternion_to_matrix_numpy; ref_quat.npz,
+ *       tests/test_reference_pins.py) -- round 3;
+ *     - computeColorFromSH_bwd: dL_dsh and the direction part of dL_dmeans3D
+ *       (torch.autograd through the reference's eval_sh; ref_sh_bwd.npz,
+ *       tests/test_reference_pins.py) -- round 3, the first reference-derived
+ *       pin of anything in the backward.
+ *   Everything else (EWA projection, tile binning, blend, the rest of the
  *   backward) is pinned only by agreement of three independent
  *   implementations: this file, oracle/torch_splat.py (+ fp64 autograd) and
  *   the HIP kernels.

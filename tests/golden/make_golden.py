@@ -123,6 +123,78 @@ def part_a_sky():
     np.savez(os.path.join(HERE, "ref_cube_dir.npz"), x=xx.numpy(), y=yy.numpy(), dirs=dirs)
 
 
+def _extract_functions(path, names):
+    """Execute single functions of a reference module that cannot be imported as a whole here
+    (its imports need roma / cv2 / CUDA): the named FunctionDefs are cut out with ast and executed
+    in the BUILD container only; the fixtures hold inputs and outputs, never source text."""
+    import ast
+    src = open(path).read()
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names), (names, [f.name for f in fns])
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(fns, []), os.path.basename(path), "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def part_a_quat():
+    """Quaternion conventions (lib/utils/general_utils.py): quaternion_to_matrix_numpy (:103-122,
+    numpy) and quaternion_raw_multiply (:220-238, torch, device-free) -> ref_quat.npz.  Pins
+    (i) the (r, x, y, z) -> R convention of computeCov3D (CR/forward.cu:118-152) in gs_oracle.c
+    and of the scene-graph composition, (ii) the Hamilton product obj_rot (x) q of
+    street_gaussian_model.py:330-336 used by oracle/compose_torch.py and grpg_compose."""
+    q2m, qmul = _extract_functions(os.path.join(REF, "lib/utils/general_utils.py"),
+                                   ["quaternion_to_matrix_numpy", "quaternion_raw_multiply"])
+    rng = np.random.RandomState(11)
+    q = rng.randn(64, 4)
+    q[0] = [1, 0, 0, 0]
+    q[1] = [0, 1, 0, 0]
+    q[2] = [0, 0, 1, 0]
+    q[3] = [0, 0, 0, 1]
+    q[4] = [np.cos(0.35), np.sin(0.35), 0, 0]       # rotation about x by 0.7 rad
+    Rm = np.stack([q2m(qi.copy()) for qi in q])      # normalises internally
+    a = torch.tensor(rng.randn(64, 4), dtype=torch.float32)
+    b = torch.tensor(rng.randn(64, 4), dtype=torch.float32)
+    prod = qmul(a, b).numpy()
+    np.savez(os.path.join(HERE, "ref_quat.npz"), q=q, R=Rm, a=a.numpy(), b=b.numpy(), ab=prod)
+
+
+def part_a_sh_bwd():
+    """First reference-derived pin of the BACKWARD: torch.autograd through the reference's own
+    eval_sh (lib/utils/sh_utils.py:57-112) and the direction normalisation its caller applies
+    (street_gaussian_renderer.py:183-187: dir_pp / dir_pp.norm) -> ref_sh_bwd.npz.  The upstream
+    gradient is masked where (eval_sh + 0.5) < 0, which is what the kernel's clamp does
+    (CR/forward.cu:63-70, CR/backward.cu:36-39).  Checked against computeColorFromSH_bwd of
+    gs_oracle.c (CR/backward.cu:20-139): dL_dsh and the direction part of dL_dmeans3D."""
+    sh_utils = _load(os.path.join(REF, "lib/utils/sh_utils.py"), "ref_sh_utils_bwd")
+    g = torch.Generator().manual_seed(4321)
+    N = 128
+    means = (torch.randn(N, 3, generator=g) * 3.0).double()
+    campos = torch.tensor([0.3, -0.2, -0.5]).double()
+    shs = (torch.randn(N, 16, 3, generator=g) * 1.5).double()
+    gcol = torch.randn(N, 3, generator=g).double()
+    out = dict(means3D=means.numpy().astype(np.float32), campos=campos.numpy().astype(np.float32),
+               shs=shs.numpy().astype(np.float32), dL_dcolor=gcol.numpy().astype(np.float32))
+    # float32-representable inputs, float64 autograd (exact reference gradient of those inputs)
+    means = torch.tensor(out["means3D"]).double()
+    campos = torch.tensor(out["campos"]).double()
+    shs = torch.tensor(out["shs"]).double()
+    gcol = torch.tensor(out["dL_dcolor"]).double()
+    for deg in range(4):
+        M = (deg + 1) ** 2
+        m = means.clone().requires_grad_(True)
+        s = shs[:, :M, :].clone().requires_grad_(True)
+        d = m - campos[None]
+        d = d / d.norm(dim=1, keepdim=True)
+        res = sh_utils.eval_sh(deg, s.transpose(1, 2), d)
+        mask = ((res.detach() + 0.5) >= 0).double()
+        (res * gcol * mask).sum().backward()
+        out["dL_dsh_deg%d" % deg] = s.grad.numpy()
+        out["dL_dmeans_deg%d" % deg] = (m.grad.numpy() if m.grad is not None else np.zeros((N, 3)))
+        out["clamped_deg%d" % deg] = (mask.numpy() == 0)
+        out["margin_deg%d" % deg] = np.abs(res.detach().numpy() + 0.5)
+    np.savez(os.path.join(HERE, "ref_sh_bwd.npz"), **out)
+
+
 def scenes():
     """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
     from gaussianrpg_amd import harness as hz
@@ -183,6 +255,8 @@ if __name__ == "__main__":
         part_a()
         part_a_idft()
         part_a_sky()
+        part_a_quat()
+        part_a_sh_bwd()
     else:
         print("no /root/reference here: skipping part A (reference-derived vectors)")
     part_b()

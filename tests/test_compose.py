@@ -127,3 +127,35 @@ def test_composed_argument_errors():
     bad = [models[0], models[1]._replace(features_rest=models[1].features_rest[:, :1])]
     with pytest.raises(RuntimeError, match="same number of SH coefficients"):
         fused(bad, poses)
+
+
+@pytest.mark.gpu
+def test_compose_matches_reference_quaternion_fixture():
+    """grpg_compose against values produced by the reference's own quaternion helpers
+    (tests/golden/ref_quat.npz: quaternion_to_matrix_numpy R/lib/utils/general_utils.py:103-122,
+    quaternion_raw_multiply :220-238): actor means = R(obj_rot) x + t
+    (street_gaussian_model.py:352-356) and rotations = normalize(obj_rot (x) normalize(q)) (:330-336)."""
+    from gaussianrpg_amd.composed import ActorPose, ModelParams, compose
+    z = np.load(os.path.join(GOLDEN, "ref_quat.npz"))
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    n = 500
+    xyz = torch.randn(n, 3, generator=g)
+    for k in range(8):
+        obj_rot, Rref = z["q"][k], z["R"][k]                 # R of the normalised quaternion, float64
+        a, b = z["a"][k], torch.tensor(z["b"][k])            # one fixture row: a (x) b = ab[k]
+        rot_local = b.reshape(1, 4).repeat(n, 1).contiguous()
+        m = ModelParams(xyz, torch.zeros(n, 3), rot_local, torch.zeros(n, 1), torch.zeros(n, 1, 3),
+                        torch.zeros(n, 3, 3))
+        trans = [0.5 * k, -1.0, 3.0]
+        for rot, check in ((obj_rot, "matrix"), (a, "product")):
+            got = compose([ModelParams(*(t.to(dev) for t in m))],
+                          [ActorPose([float(v) for v in rot], trans, 0.0)])
+            if check == "matrix":
+                ref = xyz.double().numpy() @ Rref.T + np.array(trans)
+                np.testing.assert_allclose(got[0].cpu().numpy(), ref, rtol=0, atol=5e-6)
+            else:
+                # the product is bilinear: a (x) (b/|b|) = (a (x) b)/|b|, and the result is normalised
+                ref = z["ab"][k].astype(np.float64)
+                ref = ref / np.linalg.norm(ref)
+                np.testing.assert_allclose(got[2].cpu().numpy(), np.tile(ref, (n, 1)), rtol=0, atol=2e-6)
