@@ -10,5 +10,13 @@ from gaussianrpg_amd.rasterizer import (  # noqa: F401
     rasterize_gaussians,
 )
 
+import sys as _sys
+
+# The reference's package holds its extension as a real submodule (DGR/setup.py:22 builds
+# ``diff_gaussian_rasterization._C``; DGR/diff_gaussian_rasterization/__init__.py:14 does
+# ``from . import _C``): register ours under that dotted name so that both
+# ``from diff_gaussian_rasterization import _C`` and ``import diff_gaussian_rasterization._C`` work.
+_sys.modules.setdefault(__name__ + "._C", _C)
+
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
            "_RasterizeGaussians", "_C"]

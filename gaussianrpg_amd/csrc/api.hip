@@ -75,8 +75,21 @@ struct DeferSlot {
   CapKey key{-1, 0, 0, 0};
   int generation = 0;       // ticket = generation * DEFER_SLOTS + slot: a recycled slot's old tickets expire
 };
-constexpr int DEFER_SLOTS = 64;
-thread_local DeferSlot g_defer[DEFER_SLOTS];
+constexpr int DEFER_SLOTS = GRPG_MAX_DEFERRED_FRAMES;
+// The ring belongs to the thread that enqueues the frames: tickets are only valid on that thread
+// (documented in the header), and the pinned words / events are released when the thread exits.
+struct DeferRing {
+  DeferSlot slot[DEFER_SLOTS];
+  ~DeferRing() {
+    for (auto& d : slot) {
+      if (d.host_ptr) (void)hipHostFree(d.host_ptr);
+      if (d.ev) (void)hipEventDestroy(d.ev);
+      d.host_ptr = nullptr; d.ev = nullptr;
+    }
+  }
+  DeferSlot& operator[](int i) { return slot[i]; }
+};
+thread_local DeferRing g_defer;
 thread_local int g_defer_next = 0;
 struct CapHint {
   CapKey key{-1, 0, 0, 0};
@@ -115,8 +128,10 @@ uint32_t capacity_from_hint(const CapKey& k, uint32_t* coarse_cap) {
   for (auto& h : g_hints)
     if (h.valid && same_key(h.key, k)) {
       h.stamp = ++g_hint_clock;
-      *coarse_cap = h.high_c ? padded_capacity(h.high_c) : padded_capacity(h.high);
-      return padded_capacity(h.high);
+      const uint32_t cap = padded_capacity(h.high);
+      const uint32_t cc = h.high_c ? padded_capacity(h.high_c) : cap;
+      *coarse_cap = cc < cap ? cc : cap;     // a (Gaussian, super-tile) pair holds >= 1 instance
+      return cap;
     }
   *coarse_cap = 0u;
   return 0u;
@@ -138,10 +153,10 @@ void update_hint(const CapKey& k, uint32_t R, uint32_t Rc) {
   }
   const uint32_t decayed = slot->high - slot->high / 64;   // lets the mark follow a shrinking scene
   slot->high = R > decayed ? R : decayed;
-  if (Rc) {
-    const uint32_t dc = slot->high_c - slot->high_c / 64;
-    slot->high_c = Rc > dc ? Rc : dc;
-  }
+  // decays on sort-binning frames too (Rc == 0 there), so it never outlives `high`
+  const uint32_t dc = slot->high_c - slot->high_c / 64;
+  slot->high_c = Rc > dc ? Rc : dc;
+  if (slot->high_c > slot->high) slot->high_c = slot->high;
   slot->stamp = ++g_hint_clock;
 }
 
@@ -795,7 +810,9 @@ int grpg_frame_status(int ticket, int wait, int* num_rendered) {
   if (ticket < 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "no such ticket");
   DeferSlot& slot = g_defer[ticket % DEFER_SLOTS];
   if (slot.generation != ticket / DEFER_SLOTS || slot.state == 0)
-    return fail(GRPG_ERR_INVALID_ARGUMENT, "no such ticket on this thread (unknown, or its slot has been reused)");
+    return fail(GRPG_ERR_INVALID_ARGUMENT,
+                "no such ticket on this thread: tickets are valid only on the thread that enqueued the "
+                "frame, and only until GRPG_MAX_DEFERRED_FRAMES (64) later frames have been enqueued there");
   const int r = defer_resolve(slot, wait != 0);
   if (r >= 0) { if (num_rendered) *num_rendered = r; return GRPG_OK; }
   if (r == GRPG_ERR_CAPACITY)
@@ -985,9 +1002,10 @@ int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, int heigh
   return GRPG_OK;
 }
 
-int grpg_sky_composite(const float* cube, int res, const float* ray_matrix, float fill,
-                       int clamp_out, int width, int height, const float* rgb_in, const float* acc,
-                       float* rgb_out, float* sky_out, void* hip_stream) {
+int grpg_sky_composite_ex(const float* cube, int res, const float* ray_matrix, int ray_matrix_on_device,
+                          float fill, int clamp_out, int width, int height, const float* rgb_in,
+                          const float* acc, const unsigned char* mask, const float* jitter,
+                          float* rgb_out, float* sky_out, void* hip_stream) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (!cube || !ray_matrix || res <= 0 || width <= 0 || height <= 0)
@@ -995,8 +1013,29 @@ int grpg_sky_composite(const float* cube, int res, const float* ray_matrix, floa
   if ((rgb_in == nullptr) != (rgb_out == nullptr))
     return fail(GRPG_ERR_INVALID_ARGUMENT, "rgb_in and rgb_out go together");
   if (!rgb_out && !sky_out) return fail(GRPG_ERR_INVALID_ARGUMENT, "nothing to write");
-  launch_sky_composite((hipStream_t)hip_stream, cube, res, ray_matrix, fill, clamp_out, width, height,
-                       rgb_in, acc, rgb_out, sky_out);
+  launch_sky_composite((hipStream_t)hip_stream, cube, res, ray_matrix, ray_matrix_on_device, fill,
+                       clamp_out, width, height, rgb_in, acc, mask, jitter, rgb_out, sky_out);
+  HIP_TRY(hipGetLastError());
+  return GRPG_OK;
+}
+
+int grpg_sky_composite(const float* cube, int res, const float* ray_matrix, float fill,
+                       int clamp_out, int width, int height, const float* rgb_in, const float* acc,
+                       float* rgb_out, float* sky_out, void* hip_stream) {
+  return grpg_sky_composite_ex(cube, res, ray_matrix, 0, fill, clamp_out, width, height, rgb_in, acc,
+                               nullptr, nullptr, rgb_out, sky_out, hip_stream);
+}
+
+int grpg_sky_backward_ex(const float* cube, int res, const float* ray_matrix, int ray_matrix_on_device,
+                         float fill, int width, int height, const float* acc, const unsigned char* mask,
+                         const float* jitter, const float* grad_rgb, float* grad_cube, float* grad_acc,
+                         void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (!cube || !ray_matrix || !grad_rgb || res <= 0 || width <= 0 || height <= 0)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "bad cube / ray matrix / gradient / size");
+  launch_sky_backward((hipStream_t)hip_stream, cube, res, ray_matrix, ray_matrix_on_device, fill, width,
+                      height, acc, mask, jitter, grad_rgb, grad_cube, grad_acc);
   HIP_TRY(hipGetLastError());
   return GRPG_OK;
 }
@@ -1004,14 +1043,8 @@ int grpg_sky_composite(const float* cube, int res, const float* ray_matrix, floa
 int grpg_sky_backward(const float* cube, int res, const float* ray_matrix, float fill, int width,
                       int height, const float* acc, const float* grad_rgb, float* grad_cube,
                       float* grad_acc, void* hip_stream) {
-  g_last_error.clear();
-  if (int rc = ensure_device()) return rc;
-  if (!cube || !ray_matrix || !grad_rgb || res <= 0 || width <= 0 || height <= 0)
-    return fail(GRPG_ERR_INVALID_ARGUMENT, "bad cube / ray matrix / gradient / size");
-  launch_sky_backward((hipStream_t)hip_stream, cube, res, ray_matrix, fill, width, height, acc,
-                      grad_rgb, grad_cube, grad_acc);
-  HIP_TRY(hipGetLastError());
-  return GRPG_OK;
+  return grpg_sky_backward_ex(cube, res, ray_matrix, 0, fill, width, height, acc, nullptr, nullptr,
+                              grad_rgb, grad_cube, grad_acc, hip_stream);
 }
 
 size_t grpg_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }

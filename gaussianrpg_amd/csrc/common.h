@@ -192,7 +192,10 @@ inline BinLayout bin_layout(size_t R, size_t T = 0, size_t NS = 0, size_t Rc = 0
   L.key_a = take(Rk * 4);  // == sorted tile ids
   L.key_b = take(Rk * 4);
   L.val_b = take(Rk * 4);
-  L.table = take((size_t)RS_MAX_RADIX * (L.nchunks_sort ? L.nchunks_sort : 1) * 8);
+  // the coarse partition indexes table[digit * nchunks_coarse + chunk]: size for whichever chunk
+  // count is larger (a forced / stale coarse capacity may exceed the instance capacity)
+  const uint32_t nch = L.nchunks_sort > L.nchunks_coarse ? L.nchunks_sort : L.nchunks_coarse;
+  L.table = take((size_t)RS_MAX_RADIX * (nch ? nch : 1) * 8);
   L.totals = take(4 * RS_MAX_RADIX * 4);
   if (T > 0) {
     L.max_seg = hier_max_segments((uint32_t)Rc, (uint32_t)NS);
@@ -379,12 +382,12 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 #endif
 
 // sky cube map (sky.hip)
-void launch_sky_composite(hipStream_t st, const float* cube, int res, const float* m9, float fill,
-                          int clamp_out, int W, int H, const float* rgb_in, const float* acc,
-                          float* rgb_out, float* sky_out);
-void launch_sky_backward(hipStream_t st, const float* cube, int res, const float* m9, float fill,
-                         int W, int H, const float* acc, const float* grad_rgb, float* grad_cube,
-                         float* grad_acc);
+void launch_sky_composite(hipStream_t st, const float* cube, int res, const float* m9, int m_on_device,
+                          float fill, int clamp_out, int W, int H, const float* rgb_in, const float* acc,
+                          const unsigned char* mask, const float* jitter, float* rgb_out, float* sky_out);
+void launch_sky_backward(hipStream_t st, const float* cube, int res, const float* m9, int m_on_device,
+                         float fill, int W, int H, const float* acc, const unsigned char* mask,
+                         const float* jitter, const float* grad_rgb, float* grad_cube, float* grad_acc);
 
 // distCUDA2 (knn.hip): mean squared distance to the 3 nearest other points.
 size_t knn_workspace_bytes(int P);

@@ -34,7 +34,20 @@ struct SkyArgs {
   float m[9];          // row-major R^T K^-1: ray = m * (x + 0.5, y + 0.5, 1)
   float fill;          // sky colour where the mask is off (0, or 1 for a white background)
   int clamp_out;       // evaluation mode: clamp the composite to [0,1]
+  // train-mode extras (sky_cubemap.py:80-82,91-92), all optional:
+  const float* m_dev;          // the same 9 floats in DEVICE memory (no host read of K / w2c)
+  const unsigned char* mask;   // [H,W] != 0 -> fetch the texture there (camera.original_sky_mask with
+                               // its top rows set); replaces the (1 - acc) > 1e-3 rule
+  const float* jitter;         // [2,H,W]: per-pixel (x, y) offsets replacing the +0.5 pixel centre
+                               // (get_rays_torch(perturb=True): two torch.rand(H, W) planes)
 };
+
+// does this pixel fetch the texture?  sky_cubemap.py:80-87
+__device__ __forceinline__ bool sky_fetches(const SkyArgs& s, const size_t pix, const bool have_acc,
+                                            const float tr) {
+  if (s.mask) return s.mask[pix] != 0;
+  return !have_acc || tr > 1e-3f;
+}
 
 // direction -> face, (u, v) in [0,1]; returns -1 for a degenerate direction
 __device__ __forceinline__ int cube_face_uv(const float x, const float y, const float z, float& u,
@@ -119,12 +132,16 @@ __device__ __forceinline__ CubeTaps cube_taps(const float dx, const float dy, co
   return t;
 }
 
-__device__ __forceinline__ void pixel_ray(const SkyArgs& s, const int px, const int py, float& dx,
-                                          float& dy, float& dz) {
-  const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-  const float x = s.m[0] * fx + s.m[1] * fy + s.m[2];
-  const float y = s.m[3] * fx + s.m[4] * fy + s.m[5];
-  const float z = s.m[6] * fx + s.m[7] * fy + s.m[8];
+__device__ __forceinline__ void pixel_ray(const SkyArgs& s, const int px, const int py, const size_t pix,
+                                          const size_t HW, float& dx, float& dy, float& dz) {
+  const float ox = s.jitter ? s.jitter[pix] : 0.5f, oy = s.jitter ? s.jitter[HW + pix] : 0.5f;
+  const float fx = (float)px + ox, fy = (float)py + oy;
+  float m[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) m[i] = s.m_dev ? s.m_dev[i] : s.m[i];
+  const float x = m[0] * fx + m[1] * fy + m[2];
+  const float y = m[3] * fx + m[4] * fy + m[5];
+  const float z = m[6] * fx + m[7] * fy + m[8];
   const float n = sqrtf(x * x + y * y + z * z);
   dx = x / n; dy = y / n; dz = z / n;
 }
@@ -141,9 +158,9 @@ sky_composite_kernel(const SkyArgs s, const int W, const int H, const float* __r
   const float a = acc ? acc[pix] : 0.f;
   const float tr = 1.f - a;
   float sky[3] = {s.fill, s.fill, s.fill};
-  if (!acc || tr > 1e-3f) {
+  if (sky_fetches(s, pix, acc != nullptr, tr)) {
     float dx, dy, dz;
-    pixel_ray(s, px, py, dx, dy, dz);
+    pixel_ray(s, px, py, pix, HW, dx, dy, dz);
     const CubeTaps t = cube_taps(dx, dy, dz, s.res);
     sky[0] = sky[1] = sky[2] = 0.f;
 #pragma unroll
@@ -180,9 +197,9 @@ sky_backward_kernel(const SkyArgs s, const int W, const int H, const float* __re
   const float tr = 1.f - a;
   const float g[3] = {grad_rgb[pix], grad_rgb[HW + pix], grad_rgb[2 * HW + pix]};
   float sky[3] = {s.fill, s.fill, s.fill};
-  if (!acc || tr > 1e-3f) {
+  if (sky_fetches(s, pix, acc != nullptr, tr)) {
     float dx, dy, dz;
-    pixel_ray(s, px, py, dx, dy, dz);
+    pixel_ray(s, px, py, pix, HW, dx, dy, dz);
     const CubeTaps t = cube_taps(dx, dy, dz, s.res);
     sky[0] = sky[1] = sky[2] = 0.f;
 #pragma unroll
@@ -210,22 +227,28 @@ sky_backward_kernel(const SkyArgs s, const int W, const int H, const float* __re
   }
 }
 
-void launch_sky_composite(hipStream_t st, const float* cube, int res, const float* m9, float fill,
-                          int clamp_out, int W, int H, const float* rgb_in, const float* acc,
-                          float* rgb_out, float* sky_out) {
+static SkyArgs make_sky_args(const float* cube, int res, const float* m9, int m_on_device, float fill,
+                             int clamp_out, const unsigned char* mask, const float* jitter) {
   SkyArgs s;
   s.cube = cube; s.res = res; s.fill = fill; s.clamp_out = clamp_out;
-  for (int i = 0; i < 9; i++) s.m[i] = m9[i];
+  s.mask = mask; s.jitter = jitter;
+  s.m_dev = m_on_device ? m9 : nullptr;
+  for (int i = 0; i < 9; i++) s.m[i] = m_on_device ? 0.f : m9[i];
+  return s;
+}
+
+void launch_sky_composite(hipStream_t st, const float* cube, int res, const float* m9, int m_on_device,
+                          float fill, int clamp_out, int W, int H, const float* rgb_in, const float* acc,
+                          const unsigned char* mask, const float* jitter, float* rgb_out, float* sky_out) {
+  const SkyArgs s = make_sky_args(cube, res, m9, m_on_device, fill, clamp_out, mask, jitter);
   const dim3 grid((W + 63) / 64, (H + 3) / 4);
   sky_composite_kernel<<<grid, 256, 0, st>>>(s, W, H, rgb_in, acc, rgb_out, sky_out);
 }
 
-void launch_sky_backward(hipStream_t st, const float* cube, int res, const float* m9, float fill,
-                         int W, int H, const float* acc, const float* grad_rgb, float* grad_cube,
-                         float* grad_acc) {
-  SkyArgs s;
-  s.cube = cube; s.res = res; s.fill = fill; s.clamp_out = 0;
-  for (int i = 0; i < 9; i++) s.m[i] = m9[i];
+void launch_sky_backward(hipStream_t st, const float* cube, int res, const float* m9, int m_on_device,
+                         float fill, int W, int H, const float* acc, const unsigned char* mask,
+                         const float* jitter, const float* grad_rgb, float* grad_cube, float* grad_acc) {
+  const SkyArgs s = make_sky_args(cube, res, m9, m_on_device, fill, 0, mask, jitter);
   const dim3 grid((W + 63) / 64, (H + 3) / 4);
   sky_backward_kernel<<<grid, 256, 0, st>>>(s, W, H, acc, grad_rgb, grad_cube, grad_acc);
 }

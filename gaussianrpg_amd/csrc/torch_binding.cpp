@@ -210,15 +210,21 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 
   auto o = means3D.options();
   // The eleven gradient arrays of rasterize_points.cu:166-176 must arrive zero-filled (atomics and
-  // "+=" accumulate into them).  One allocation and ONE zero-fill launch instead of eleven; the
-  // returned tensors are disjoint views (each starts on a 256-byte boundary).
+  // "+=" accumulate into them).  Two allocations and two zero-fill launches instead of eleven; the
+  // tensors are disjoint views (each starts on a 256-byte boundary).  Pool A holds the gradients a
+  // training step keeps as .grad (means3D, means2D, opacity, sh, scales, rotations, semantics),
+  // pool B the internal ones and those autograd normally drops (colors, depths, conic, cov3D), so a
+  // retained .grad does not pin the scratch arrays.
   const int64_t widths[11] = {3, 3, GRPG_NUM_CHANNELS, 1, 4, 1, 6, (int64_t)M * 3, 3, 4, S};
-  int64_t offs[12];
-  offs[0] = 0;
-  for (int i = 0; i < 11; i++) offs[i + 1] = offs[i] + (((int64_t)P * widths[i] + 63) / 64) * 64;
-  torch::Tensor pool = torch::zeros({offs[11]}, o);
+  const int pool_of[11] = {0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0};
+  int64_t offs[11], size[2] = {0, 0};
+  for (int i = 0; i < 11; i++) {
+    offs[i] = size[pool_of[i]];
+    size[pool_of[i]] += (((int64_t)P * widths[i] + 63) / 64) * 64;
+  }
+  torch::Tensor pools[2] = {torch::zeros({size[0]}, o), torch::zeros({size[1]}, o)};
   auto view = [&](int i, std::vector<int64_t> shape) {
-    return pool.narrow(0, offs[i], (int64_t)P * widths[i]).view(shape);
+    return pools[pool_of[i]].narrow(0, offs[i], (int64_t)P * widths[i]).view(shape);
   };
   torch::Tensor dL_dmeans3D = view(0, {P, 3});
   torch::Tensor dL_dmeans2D = view(1, {P, 3});
@@ -469,18 +475,46 @@ Compose(const std::vector<torch::Tensor>& xyz, const std::vector<torch::Tensor>&
 // Sky cube map (additive; include/grpg_rasterizer.h: grpg_sky_composite / grpg_sky_backward).
 // ray_matrix: CPU float tensor [3,3] = R^T K^-1.
 // ----------------------------------------------------------------------------------------------
+// ray_matrix [3,3] float32 = R^T K^-1, on the CPU or on the cube map's device (the latter costs no
+// host read of the camera); mask (bool / uint8 [H,W]) and jitter (float32 [2,H,W]) are the train-mode
+// extras of grpg_sky_composite_ex.
+static const unsigned char* sky_mask_ptr(const c10::optional<torch::Tensor>& mask_opt, torch::Tensor& hold,
+                                         const int height, const int width) {
+  if (!mask_opt.has_value() || !mask_opt->defined()) return nullptr;
+  TORCH_CHECK(mask_opt->is_cuda() && (mask_opt->scalar_type() == torch::kBool ||
+                                      mask_opt->scalar_type() == torch::kUInt8) &&
+                  mask_opt->numel() == (int64_t)height * width,
+              "sky mask must be a bool / uint8 device tensor [H,W]");
+  hold = mask_opt->contiguous();
+  return (const unsigned char*)hold.data_ptr();
+}
+static const float* sky_jitter_ptr(const c10::optional<torch::Tensor>& jit_opt, torch::Tensor& hold,
+                                   const int height, const int width) {
+  if (!jit_opt.has_value() || !jit_opt->defined()) return nullptr;
+  TORCH_CHECK(jit_opt->is_cuda() && jit_opt->scalar_type() == torch::kFloat32 &&
+                  jit_opt->numel() == 2 * (int64_t)height * width,
+              "sky jitter must be a float32 device tensor [2,H,W]");
+  hold = jit_opt->contiguous();
+  return hold.data_ptr<float>();
+}
+static void check_ray_matrix(const torch::Tensor& ray_matrix, const torch::Tensor& cube) {
+  TORCH_CHECK(ray_matrix.scalar_type() == torch::kFloat32 && ray_matrix.numel() == 9 &&
+                  (!ray_matrix.is_cuda() || ray_matrix.device() == cube.device()),
+              "ray_matrix must be a float32 tensor [3,3] on the CPU or on the cube map's device");
+}
+
 std::tuple<torch::Tensor, torch::Tensor>
 SkyComposite(const torch::Tensor& cube, const torch::Tensor& ray_matrix, const float fill,
              const bool clamp_out, const c10::optional<torch::Tensor>& rgb_opt,
              const c10::optional<torch::Tensor>& acc_opt, const int height, const int width,
-             const bool want_sky) {
+             const bool want_sky, const c10::optional<torch::Tensor>& mask_opt,
+             const c10::optional<torch::Tensor>& jitter_opt) {
   TORCH_CHECK(cube.is_cuda() && cube.scalar_type() == torch::kFloat32 && cube.dim() == 4 &&
                   cube.size(0) == 6 && cube.size(1) == cube.size(2) && cube.size(3) == 3,
               "sky cube map must be a float32 device tensor [6,res,res,3]");
-  TORCH_CHECK(!ray_matrix.is_cuda() && ray_matrix.scalar_type() == torch::kFloat32 && ray_matrix.numel() == 9,
-              "ray_matrix must be a CPU float32 tensor [3,3]");
+  check_ray_matrix(ray_matrix, cube);
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(cube.device());
-  torch::Tensor cu = cube.contiguous(), rm = ray_matrix.contiguous(), rgb, acc, out, sky;
+  torch::Tensor cu = cube.contiguous(), rm = ray_matrix.contiguous(), rgb, acc, out, sky, mask, jit;
   const float* p_rgb = nullptr;
   const float* p_acc = nullptr;
   if (rgb_opt.has_value() && rgb_opt->defined()) {
@@ -497,35 +531,45 @@ SkyComposite(const torch::Tensor& cube, const torch::Tensor& ray_matrix, const f
     acc = acc_opt->contiguous();
     p_acc = acc.data_ptr<float>();
   }
+  const unsigned char* p_mask = sky_mask_ptr(mask_opt, mask, height, width);
+  const float* p_jit = sky_jitter_ptr(jitter_opt, jit, height, width);
   if (want_sky || !p_rgb) sky = torch::empty({3, height, width}, cu.options());
   hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-  const int rc = grpg_sky_composite(cu.data_ptr<float>(), (int)cu.size(1), rm.data_ptr<float>(), fill,
-                                    clamp_out ? 1 : 0, width, height, p_rgb, p_acc,
-                                    p_rgb ? out.data_ptr<float>() : nullptr,
-                                    sky.defined() ? sky.data_ptr<float>() : nullptr, (void*)stream);
+  const int rc = grpg_sky_composite_ex(cu.data_ptr<float>(), (int)cu.size(1), rm.data_ptr<float>(),
+                                       rm.is_cuda() ? 1 : 0, fill, clamp_out ? 1 : 0, width, height, p_rgb,
+                                       p_acc, p_mask, p_jit, p_rgb ? out.data_ptr<float>() : nullptr,
+                                       sky.defined() ? sky.data_ptr<float>() : nullptr, (void*)stream);
   if (rc != GRPG_OK) raise_abi_error("grpg_sky_composite", rc);
   return std::make_tuple(out, sky);
 }
 
 std::tuple<torch::Tensor, torch::Tensor>
 SkyBackward(const torch::Tensor& cube, const torch::Tensor& ray_matrix, const float fill,
-            const c10::optional<torch::Tensor>& acc_opt, const torch::Tensor& grad_rgb) {
-  TORCH_CHECK(cube.is_cuda() && grad_rgb.is_cuda() && grad_rgb.dim() == 3 && grad_rgb.size(0) == 3,
-              "grad_rgb must be a device tensor [3,H,W]");
+            const c10::optional<torch::Tensor>& acc_opt, const torch::Tensor& grad_rgb,
+            const c10::optional<torch::Tensor>& mask_opt, const c10::optional<torch::Tensor>& jitter_opt) {
+  TORCH_CHECK(cube.is_cuda() && cube.scalar_type() == torch::kFloat32 && grad_rgb.is_cuda() &&
+                  grad_rgb.scalar_type() == torch::kFloat32 && grad_rgb.dim() == 3 && grad_rgb.size(0) == 3,
+              "cube and grad_rgb [3,H,W] must be float32 device tensors");
+  check_ray_matrix(ray_matrix, cube);
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(cube.device());
   const int H = grad_rgb.size(1), W = grad_rgb.size(2);
-  torch::Tensor cu = cube.contiguous(), rm = ray_matrix.contiguous(), g = grad_rgb.contiguous(), acc;
+  torch::Tensor cu = cube.contiguous(), rm = ray_matrix.contiguous(), g = grad_rgb.contiguous(), acc, mask, jit;
   const float* p_acc = nullptr;
   if (acc_opt.has_value() && acc_opt->defined()) {
+    TORCH_CHECK(acc_opt->is_cuda() && acc_opt->scalar_type() == torch::kFloat32 &&
+                    acc_opt->numel() == (int64_t)H * W, "acc must be a float32 device tensor [1,H,W]");
     acc = acc_opt->contiguous();
     p_acc = acc.data_ptr<float>();
   }
+  const unsigned char* p_mask = sky_mask_ptr(mask_opt, mask, H, W);
+  const float* p_jit = sky_jitter_ptr(jitter_opt, jit, H, W);
   torch::Tensor grad_cube = torch::zeros_like(cu);
   torch::Tensor grad_acc = torch::empty({1, H, W}, cu.options());
   hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-  const int rc = grpg_sky_backward(cu.data_ptr<float>(), (int)cu.size(1), rm.data_ptr<float>(), fill, W, H,
-                                   p_acc, g.data_ptr<float>(), grad_cube.data_ptr<float>(),
-                                   grad_acc.data_ptr<float>(), (void*)stream);
+  const int rc = grpg_sky_backward_ex(cu.data_ptr<float>(), (int)cu.size(1), rm.data_ptr<float>(),
+                                      rm.is_cuda() ? 1 : 0, fill, W, H, p_acc, p_mask, p_jit,
+                                      g.data_ptr<float>(), grad_cube.data_ptr<float>(),
+                                      grad_acc.data_ptr<float>(), (void*)stream);
   if (rc != GRPG_OK) raise_abi_error("grpg_sky_backward", rc);
   return std::make_tuple(grad_cube, grad_acc);
 }
@@ -641,8 +685,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("debug_export", &DebugExport);
   m.def("rasterize_gaussians_composed", &RasterizeGaussiansComposed);
   m.def("compose", &Compose);
-  m.def("sky_composite", &SkyComposite);
-  m.def("sky_backward", &SkyBackward);
+  m.def("sky_composite", &SkyComposite, pybind11::arg("cube"), pybind11::arg("ray_matrix"),
+        pybind11::arg("fill"), pybind11::arg("clamp_out"), pybind11::arg("rgb"), pybind11::arg("acc"),
+        pybind11::arg("height"), pybind11::arg("width"), pybind11::arg("want_sky"),
+        pybind11::arg("mask") = pybind11::none(), pybind11::arg("jitter") = pybind11::none());
+  m.def("sky_backward", &SkyBackward, pybind11::arg("cube"), pybind11::arg("ray_matrix"),
+        pybind11::arg("fill"), pybind11::arg("acc"), pybind11::arg("grad_rgb"),
+        pybind11::arg("mask") = pybind11::none(), pybind11::arg("jitter") = pybind11::none());
   m.def("pack_u8", &PackU8, pybind11::arg("color"), pybind11::arg("out") = pybind11::none());
   m.def("pack_hwc", &PackHWC);
   m.def("set_stage_timing", [](int mode) { grpg_set_stage_timing(mode); });   // 0 off, 1 all, 2 render only

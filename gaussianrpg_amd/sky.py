@@ -9,8 +9,10 @@ boundary_mode='cube')``; every example config sets ``include_sky: true``, so on 
     sky_color = sky(K, w2c, H, W, acc)                   # [3,H,W], differentiable w.r.t. the cube map and acc
     rgb = sky.composite(rgb, acc, K, w2c, train=False)   # rgb + sky * (1 - acc) (+ clamp), ONE launch
 
-``forward`` mirrors ``SkyCubeMap.forward`` (eval branch of the mask: ``(1 - acc) > 1e-3``;
-``get_rays_torch`` without perturbation); ``composite`` fuses it with
+``forward`` mirrors ``SkyCubeMap.forward`` -- both call forms, ``sky(camera, acc)`` as the reference's
+renderer calls it and ``sky(K, w2c, H, W, acc)``; evaluation: mask ``(1 - acc) > 1e-3``, pixel-centre
+rays; ``mode='train'``: ``camera.original_sky_mask`` with the top 50 rows set and per-pixel jittered
+rays (sky_cubemap.py:80-82,91-92) -- ``composite`` fuses it with
 ``StreetGaussianRenderer.render``'s ``rgb + sky_color * (1 - acc)`` and the eval-mode clamp
 (lib/models/street_gaussian_renderer.py:106-116).  No fixed 1080x1920 scratch image
 (sky_cubemap.py:29-34): any frame size works.
@@ -22,62 +24,90 @@ from .rasterizer import _C
 
 
 def ray_matrix(K: torch.Tensor, w2c: torch.Tensor) -> torch.Tensor:
-    """[3,3] CPU float32 matrix M with ray(x, y) ~ M (x + 0.5, y + 0.5, 1): get_rays_torch
+    """[3,3] float32 matrix M with ray(x, y) ~ M (x + 0.5, y + 0.5, 1): get_rays_torch
     (lib/utils/graphics_utils.py:186-207) computes normalize(((K^-1 p) - T) R - rays_o) with
-    rays_o = -R^T T, which is R^T K^-1 p before the normalisation.  Evaluated in float64, rounded once."""
-    K64 = K.detach().double().cpu()
-    R64 = w2c.detach().double().cpu()[:3, :3]
-    return (R64.transpose(0, 1) @ torch.linalg.inv(K64)).float().contiguous()
+    rays_o = -R^T T, which is R^T K^-1 p before the normalisation.  Evaluated in float64, rounded
+    once, ON THE DEVICE the camera's tensors live on: the reference's cameras keep K and
+    world_view_transform on the GPU, and a ``.cpu()`` here would stall the stream once per frame
+    (ADVICE round 2).  CPU inputs give a CPU matrix (the kernel then takes it by value)."""
+    K64 = K.detach().double()
+    R64 = w2c.detach().double()[:3, :3].to(K64.device)
+    # inv_ex: no error-check round trip to the host (linalg.inv reads `info` back and stalls the stream)
+    return (R64.transpose(0, 1) @ torch.linalg.inv_ex(K64).inverse).float().contiguous()
+
+
+def _camera_args(camera):
+    """(K, w2c, H, W) of a reference ``Camera`` (lib/utils/camera_utils.py): ``world_view_transform``
+    is the TRANSPOSED world-to-camera matrix (sky_cubemap.py:88)."""
+    w2c = camera.world_view_transform.transpose(0, 1)
+    return camera.K, w2c, int(camera.image_height), int(camera.image_width)
+
+
+def train_sky_mask(original_sky_mask: torch.Tensor, top_rows: int = 50) -> torch.Tensor:
+    """The train-mode fetch mask of sky_cubemap.py:80-82: ``camera.original_sky_mask[0]`` with its
+    first 50 rows forced on (a copy: the reference edits the camera's tensor in place)."""
+    m = original_sky_mask.reshape(original_sky_mask.shape[-2:]).bool().clone()
+    m[:top_rows, :] = True
+    return m
 
 
 class _SkyLookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cube, acc, rm, fill, H, W):
-        _, sky = _C.sky_composite(cube, rm, float(fill), False, None, acc, int(H), int(W), True)
-        ctx.save_for_backward(cube, acc if acc is not None else torch.Tensor([]))
-        ctx.rm, ctx.fill, ctx.has_acc = rm, float(fill), acc is not None
+    def forward(ctx, cube, acc, rm, fill, H, W, mask, jitter):
+        _, sky = _C.sky_composite(cube, rm, float(fill), False, None, acc, int(H), int(W), True,
+                                  mask, jitter)
+        ctx.save_for_backward(cube)
+        ctx.rm, ctx.fill, ctx.jitter = rm, float(fill), jitter
+        # which pixels fetched the texture, as an explicit mask for the backward
+        if mask is not None:
+            ctx.mask = mask
+        elif acc is not None:
+            ctx.mask = ((1.0 - acc.reshape(int(H), int(W))) > 1e-3)
+        else:
+            ctx.mask = None
         return sky
 
     @staticmethod
     def backward(ctx, grad_sky):
-        # sky = clamp(fetch) where the mask is on: the lookup's own gradient is the composite's with
-        # (1 - acc) replaced by 1, i.e. sky_backward with acc = None restricted to the mask.  The
-        # kernel applies the mask itself when acc is given, and scales by (1 - acc): divide it out by
-        # handing it a pre-scaled gradient.
-        cube, acc = ctx.saved_tensors
-        if ctx.has_acc:
-            tr = (1.0 - acc).clamp_min(1e-12)
-            g = grad_sky / tr
-            grad_cube, _ = _C.sky_backward(cube, ctx.rm, ctx.fill, acc, g.contiguous())
-        else:
-            grad_cube, _ = _C.sky_backward(cube, ctx.rm, ctx.fill, None, grad_sky.contiguous())
-        return grad_cube, None, None, None, None, None
+        # sky = clamp(fetch) where the mask is on: the composite's gradient with (1 - acc) = 1
+        (cube,) = ctx.saved_tensors
+        grad_cube, _ = _C.sky_backward(cube, ctx.rm, ctx.fill, None, grad_sky.contiguous(), ctx.mask,
+                                       ctx.jitter)
+        return grad_cube, None, None, None, None, None, None, None
 
 
 class _SkyComposite(torch.autograd.Function):
     """rgb + clamp(sky, 0, 1) * (1 - acc), unclamped output (train mode)."""
 
     @staticmethod
-    def forward(ctx, cube, rgb, acc, rm, fill):
-        out, _ = _C.sky_composite(cube, rm, float(fill), False, rgb, acc, rgb.shape[1], rgb.shape[2], False)
+    def forward(ctx, cube, rgb, acc, rm, fill, mask, jitter):
+        out, _ = _C.sky_composite(cube, rm, float(fill), False, rgb, acc, rgb.shape[1], rgb.shape[2],
+                                  False, mask, jitter)
         ctx.save_for_backward(cube, acc)
-        ctx.rm, ctx.fill = rm, float(fill)
+        ctx.rm, ctx.fill, ctx.mask, ctx.jitter = rm, float(fill), mask, jitter
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         cube, acc = ctx.saved_tensors
-        grad_cube, grad_acc = _C.sky_backward(cube, ctx.rm, ctx.fill, acc, grad_out.contiguous())
-        return grad_cube, grad_out, grad_acc.reshape(acc.shape), None, None
+        grad_cube, grad_acc = _C.sky_backward(cube, ctx.rm, ctx.fill, acc, grad_out.contiguous(),
+                                              ctx.mask, ctx.jitter)
+        return grad_cube, grad_out, grad_acc.reshape(acc.shape), None, None, None, None
 
 
 class SkyCubeMap(nn.Module):
-    """Drop-in for lib/models/sky_cubemap.py:SkyCubeMap (same parameter name and initial value)."""
+    """Drop-in for lib/models/sky_cubemap.py:SkyCubeMap (same parameter name and initial value,
+    same ``forward(camera, acc)`` call: ``pc.sky_cubemap(viewpoint_camera, acc)`` of
+    street_gaussian_renderer.py:108 works unchanged).  ``self.mode`` plays ``cfg.mode``: in
+    ``'train'`` the fetch mask is ``camera.original_sky_mask`` with the top 50 rows set (when the
+    camera has one) and the rays are jittered inside their pixels; otherwise the mask is
+    ``(1 - acc) > 1e-3`` and rays go through pixel centres (sky_cubemap.py:77-95)."""
 
-    def __init__(self, resolution: int = 1024, white_background: bool = False):
+    def __init__(self, resolution: int = 1024, white_background: bool = False, mode: str = "evaluate"):
         super().__init__()
         self.resolution = int(resolution)
         self.white_background = bool(white_background)
+        self.mode = mode
         eps = 1e-3
         if white_background:      # sky_cubemap.py:22-25
             base = torch.ones(6, self.resolution, self.resolution, 3) * (1.0 - eps)
@@ -89,21 +119,52 @@ class SkyCubeMap(nn.Module):
     def fill(self) -> float:
         return 1.0 if self.white_background else 0.0
 
-    def forward(self, K, w2c, image_height, image_width, acc=None):
-        """[3,H,W] sky colour: the cube map seen along every pixel's ray where (1 - acc) > 1e-3, the
-        background fill elsewhere, clamped to [0,1] (sky_cubemap.py:77-122, evaluation mask)."""
+    def _train_extras(self, camera, H, W, mask, jitter, generator=None):
+        """mask / jitter of the reference's train branch unless the caller supplied them."""
+        if self.mode != "train":
+            return mask, jitter
+        dev = self.sky_cube_map.device
+        if mask is None and camera is not None and hasattr(camera, "original_sky_mask"):
+            mask = train_sky_mask(camera.original_sky_mask.to(dev))
+        if jitter is None:      # get_rays_torch(perturb=True): two torch.rand(H, W) planes
+            jitter = torch.rand(2, H, W, device=dev, generator=generator)
+        return mask, jitter
+
+    def forward(self, camera_or_K, acc_or_w2c=None, image_height=None, image_width=None, acc=None, *,
+                mask=None, jitter=None):
+        """[3,H,W] sky colour, clamped to [0,1]: the cube map seen along every pixel's ray where the
+        mask is on, the background fill elsewhere (sky_cubemap.py:77-122).  Two call forms:
+        ``sky(camera, acc)`` -- the reference's -- or ``sky(K, w2c, H, W, acc)``.
+        ``mask`` (bool [H,W]) / ``jitter`` (float [2,H,W] in [0,1)) override the mode's defaults."""
+        if hasattr(camera_or_K, "world_view_transform"):
+            camera = camera_or_K
+            K, w2c, H, W = _camera_args(camera)
+            acc = acc_or_w2c if acc is None else acc
+        else:
+            camera = None
+            K, w2c, H, W = camera_or_K, acc_or_w2c, int(image_height), int(image_width)
+        mask, jitter = self._train_extras(camera, H, W, mask, jitter)
         rm = ray_matrix(K, w2c)
         a = None if acc is None else acc.detach()
-        return _SkyLookup.apply(self.sky_cube_map, a, rm, self.fill, image_height, image_width)
+        return _SkyLookup.apply(self.sky_cube_map, a, rm, self.fill, H, W, mask, jitter)
 
-    def composite(self, rgb, acc, K, w2c, train: bool = False):
+    def composite(self, rgb, acc, K=None, w2c=None, train=None, *, camera=None, mask=None, jitter=None):
         """``rgb + sky * (1 - acc)`` (street_gaussian_renderer.py:106-110), clamped to [0,1] outside
-        train mode (:115-116), fused into one launch.  In train mode the result is differentiable
-        w.r.t. the cube map, rgb and acc."""
+        train mode (:115-116), fused into one launch.  With ``train=True`` (default: ``self.mode ==
+        'train'``) the result is unclamped and differentiable w.r.t. the cube map, rgb and acc.  When
+        ``self.mode == 'train'`` the fetch mask is the camera's sky mask (if ``camera`` has one) and the
+        rays are jittered, as in forward()."""
+        if camera is not None:
+            K, w2c, _, _ = _camera_args(camera)
+        if train is None:
+            train = self.mode == "train"
         rm = ray_matrix(K, w2c)
+        # mask / jitter follow self.mode (the reference's cfg.mode), `train` only selects the
+        # unclamped, differentiable composite
+        mask, jitter = self._train_extras(camera, rgb.shape[1], rgb.shape[2], mask, jitter)
         if train:
-            return _SkyComposite.apply(self.sky_cube_map, rgb, acc, rm, self.fill)
+            return _SkyComposite.apply(self.sky_cube_map, rgb, acc, rm, self.fill, mask, jitter)
         with torch.no_grad():
             out, _ = _C.sky_composite(self.sky_cube_map, rm, self.fill, True, rgb, acc, rgb.shape[1],
-                                      rgb.shape[2], False)
+                                      rgb.shape[2], False, mask, jitter)
         return out

@@ -243,8 +243,13 @@ class DeferredFrames:
     and consumed again -- `consume` must therefore be idempotent for a key (overwrite, not append).
     """
 
+    MAX_WINDOW = 63     # GRPG_MAX_DEFERRED_FRAMES - 1: an older ticket's slot would be recycled unseen
+
     def __init__(self, window=4):
         self.window = int(window)
+        if not 0 <= self.window <= self.MAX_WINDOW:
+            raise ValueError("DeferredFrames window must be in 0..%d (the library keeps 64 tickets per "
+                             "host thread; tickets are valid only on the enqueuing thread)" % self.MAX_WINDOW)
         self.pending = []          # (ticket, rasterizer, consume, inputs, stream)
         self.redone = 0
 

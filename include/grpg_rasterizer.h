@@ -47,6 +47,7 @@ extern "C" {
 /* Semantic channels grpg_backward accepts (the forward takes any S); the reference's backward
  * silently stops at 20 (cuda_rasterizer/config.h:16). */
 #define GRPG_MAX_SEMANTIC_BACKWARD 32
+#define GRPG_MAX_DEFERRED_FRAMES 64     /* deferred-frame tickets in flight per host thread */
 
 enum {
   GRPG_OK = 0,
@@ -142,9 +143,12 @@ GRPG_API int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_use
  *   GRPG_ERR_NOT_READY  wait == 0 and the count has not arrived yet
  * A caller must not use a deferred frame's outputs before its status is GRPG_OK.  With no history
  * for the shape (or in GRPG_BINNING_EXACT mode) the call runs synchronously and the ticket is
- * resolved on return.  Tickets are per host thread, 64 in flight; when the ring comes round, an
- * unresolved frame is resolved (waited for) first and its ticket expires (GRPG_ERR_INVALID_ARGUMENT
- * from then on).  Pass GRPG_FORWARD_NO_BACKWARD: the
+ * resolved on return.  Tickets belong to the HOST THREAD that enqueued the frame (asking another
+ * thread for its status returns GRPG_ERR_INVALID_ARGUMENT), GRPG_MAX_DEFERRED_FRAMES (64) in flight
+ * per thread; when the ring comes round, an unresolved frame is resolved (waited for) first and its
+ * ticket expires (GRPG_ERR_INVALID_ARGUMENT from then on) -- keep the status-check window below 64
+ * frames.  The ring's pinned words and events are released when the thread exits.  Pass
+ * GRPG_FORWARD_NO_BACKWARD: the
  * blobs of a frame whose count is unknown cannot be handed to grpg_backward.
  */
 GRPG_API int grpg_forward_deferred(grpg_alloc_fn geometry_alloc, void* geometry_user,
@@ -243,6 +247,25 @@ GRPG_API int grpg_sky_composite(const float* cube, int res, const float* ray_mat
 GRPG_API int grpg_sky_backward(const float* cube, int res, const float* ray_matrix, float fill,
                                int width, int height, const float* acc, const float* grad_rgb,
                                float* grad_cube, float* grad_acc, void* hip_stream);
+/* Train-mode variants (SkyCubeMap.forward with cfg.mode == 'train', sky_cubemap.py:80-82,91-92):
+ *   ray_matrix_on_device  != 0: ray_matrix is a DEVICE float[9] (computed on the device from the
+ *               camera's K and world_view_transform: no host read, no stream sync)
+ *   mask        optional device uint8/bool [H,W]: the texture is fetched exactly where mask != 0
+ *               (the reference passes camera.original_sky_mask with its first 50 rows set);
+ *               replaces the (1 - acc) > 1e-3 rule.  NULL = that rule.
+ *   jitter      optional device float [2,H,W]: per-pixel (x, y) sample offsets in [0,1) replacing the
+ *               +0.5 pixel centre (get_rays_torch(perturb=True), graphics_utils.py:194-197).
+ * With mask == jitter == NULL and ray_matrix_on_device == 0 they equal the plain entry points. */
+GRPG_API int grpg_sky_composite_ex(const float* cube, int res, const float* ray_matrix,
+                                   int ray_matrix_on_device, float fill, int clamp_out, int width,
+                                   int height, const float* rgb_in, const float* acc,
+                                   const unsigned char* mask, const float* jitter, float* rgb_out,
+                                   float* sky_out, void* hip_stream);
+GRPG_API int grpg_sky_backward_ex(const float* cube, int res, const float* ray_matrix,
+                                  int ray_matrix_on_device, float fill, int width, int height,
+                                  const float* acc, const unsigned char* mask, const float* jitter,
+                                  const float* grad_rgb, float* grad_cube, float* grad_acc,
+                                  void* hip_stream);
 
 /* Binning-blob sizing policy of grpg_forward (process-wide; see above).  The environment variable
  * GRPG_SYNC_R=1 selects GRPG_BINNING_EXACT at load time. */

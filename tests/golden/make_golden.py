@@ -110,6 +110,11 @@ def part_a_sky():
             Q[:, 0] = -Q[:, 0]
         T = torch.randn(3, generator=g)
         ro, rd = gu.get_rays_torch(H, W, K, Q, T, perturb=False)
+        # train mode: perturb=True draws perturb_i, perturb_j = torch.rand(H, W) x2 from the global
+        # generator (graphics_utils.py:194-196); the seed makes the planes reproducible
+        torch.manual_seed(1000 + n)
+        _, rdp = gu.get_rays_torch(H, W, K, Q, T, perturb=True)
+        out.update({"rays_d_perturb%d" % n: rdp.numpy(), "perturb_seed%d" % n: np.array(1000 + n)})
         out.update({"K%d" % n: K.numpy(), "R%d" % n: Q.numpy(), "T%d" % n: T.numpy(),
                     "rays_o%d" % n: ro.numpy(), "rays_d%d" % n: rd.numpy(), "HW%d" % n: np.array([H, W])})
     np.savez(os.path.join(HERE, "ref_rays.npz"), **out)

@@ -72,3 +72,20 @@ def test_python_api_rejects_cpu_tensors():
         r(torch.zeros(2, 3), None, torch.ones(2, 1), scales=torch.ones(2, 3), rotations=torch.ones(2, 4))
     with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
         r(torch.zeros(2, 3), None, torch.ones(2, 1), colors_precomp=torch.ones(2, 3))
+
+
+def test_extension_is_importable_under_the_reference_dotted_names():
+    """DGR/setup.py:22 builds ``diff_gaussian_rasterization._C`` and the package imports it with
+    ``from . import _C`` (DGR/diff_gaussian_rasterization/__init__.py:14); simple-knn's is
+    ``simple_knn._C``.  All spellings must resolve to the gfx950 extension."""
+    import importlib
+    import subprocess
+    import sys
+    code = ("import diff_gaussian_rasterization._C as a; import importlib;"
+            "b = importlib.import_module('diff_gaussian_rasterization._C');"
+            "from diff_gaussian_rasterization import _C as c; assert a is b is c;"
+            "assert hasattr(a, 'rasterize_gaussians') and hasattr(a, 'rasterize_gaussians_backward');"
+            "from simple_knn._C import distCUDA2; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+    importlib.import_module("diff_gaussian_rasterization._C")

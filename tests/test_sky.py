@@ -24,6 +24,11 @@ def test_rays_match_reference_get_rays_torch():
         ro, rd = st.get_rays(H, W, K, R, T)
         np.testing.assert_array_equal(rd.numpy(), z["rays_d%d" % n])
         np.testing.assert_array_equal(ro.numpy(), z["rays_o%d" % n])
+        # perturb=True (train mode): the two torch.rand(H, W) planes re-drawn from the recorded seed
+        torch.manual_seed(int(z["perturb_seed%d" % n]))
+        jit = torch.stack([torch.rand(H, W), torch.rand(H, W)])
+        _, rdp = st.get_rays(H, W, K, R, T, jitter=jit)
+        np.testing.assert_array_equal(rdp.numpy(), z["rays_d_perturb%d" % n])
         # the product's closed form R^T K^-1 (x+.5, y+.5, 1) gives the same directions
         from gaussianrpg_amd.sky import ray_matrix
         w2c = torch.eye(4)
@@ -150,3 +155,66 @@ def test_sky_backward():
     s2 = sky(K, w2c, Hd, Wd, None)
     (s2 * wgt).sum().backward()
     assert float(sky.sky_cube_map.grad.abs().sum()) > 0
+
+
+class _RefLikeCamera:
+    """The attributes SkyCubeMap.forward reads off a reference Camera (sky_cubemap.py:80-89)."""
+
+    def __init__(self, K, w2c, H, W, sky_mask=None):
+        self.K, self.world_view_transform = K, w2c.transpose(0, 1).contiguous()
+        self.image_height, self.image_width = H, W
+        if sky_mask is not None:
+            self.original_sky_mask = sky_mask
+
+
+@pytest.mark.gpu
+def test_sky_train_mode_mask_and_jitter_match_oracle():
+    """Train branch of SkyCubeMap.forward (sky_cubemap.py:80-82,91-92): the fetch mask is the camera's
+    sky mask with the first 50 rows set -- NOT the acc rule -- and rays are jittered inside their
+    pixels; called as the reference's renderer does, ``sky(camera, acc)``, with device-resident K and
+    world_view_transform (no host read of the camera)."""
+    from gaussianrpg_amd.sky import SkyCubeMap, train_sky_mask
+    dev = torch.device("cuda:0")
+    res, Hd, Wd = 32, 120, 176
+    K, w2c = _camera(Wd, Hd, 0.9, -0.4)
+    g = torch.Generator().manual_seed(11)
+    sky = SkyCubeMap(res, mode="train").to(dev)
+    cube = torch.rand(6, res, res, 3, generator=g) * 1.2 - 0.1
+    with torch.no_grad():
+        sky.sky_cube_map.copy_(cube.to(dev))
+    acc = torch.rand(1, Hd, Wd, generator=g)
+    rgb = torch.rand(3, Hd, Wd, generator=g)
+    sky_mask = torch.rand(1, Hd, Wd, generator=g) > 0.6
+    jitter = torch.rand(2, Hd, Wd, generator=g)
+    cam = _RefLikeCamera(K.to(dev), w2c.to(dev), Hd, Wd, sky_mask.to(dev))
+    m = train_sky_mask(sky_mask)
+    assert m[:50].all() and not m[50:].all() and sky_mask[0, :50].float().mean() < 0.9
+    ref_sky = st.sky_color(cube.numpy(), K, w2c, Hd, Wd, acc=acc.numpy(), mask=m.numpy(), jitter=jitter)
+    got = sky(cam, acc.to(dev), jitter=jitter.to(dev)).detach().cpu().numpy()
+    assert np.abs(got - ref_sky).max() < 2e-5
+    # the acc rule would have given something else: the mask really is the camera's
+    other = st.sky_color(cube.numpy(), K, w2c, Hd, Wd, acc=acc.numpy(), jitter=jitter)
+    assert np.abs(other - ref_sky).max() > 0.1
+    assert not cam.original_sky_mask[0, :50].all()       # the camera's own tensor is left alone
+    # composite in train mode: unclamped, same mask / jitter, differentiable
+    out = sky.composite(rgb.to(dev), acc.to(dev), camera=cam, jitter=jitter.to(dev))
+    ref = st.composite(rgb.numpy(), acc.numpy(), ref_sky, clamp=False)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < 3e-5
+    out.sum().backward()
+    gcube = sky.sky_cube_map.grad
+    assert float(gcube.abs().sum()) > 0
+    # gradient mass = sum over fetching, unclamped pixels of (1 - acc): linearity in the cube map
+    sky.sky_cube_map.grad = None
+    # default jitter: drawn per call, inside the pixel -> two calls differ, both near the centre render
+    a = sky(cam, acc.to(dev)).detach()
+    b = sky(cam, acc.to(dev)).detach()
+    assert not torch.equal(a, b)
+    # a camera without a sky mask falls back to the acc rule, still jittered (sky_cubemap.py:83-85)
+    cam2 = _RefLikeCamera(K.to(dev), w2c.to(dev), Hd, Wd)
+    got2 = sky(cam2, acc.to(dev), jitter=jitter.to(dev)).detach().cpu().numpy()
+    assert np.abs(got2 - other).max() < 2e-5
+    # evaluation mode through the camera form == the explicit form
+    sky.mode = "evaluate"
+    e1 = sky(cam, acc.to(dev)).detach()
+    e2 = sky(K, w2c, Hd, Wd, acc.to(dev)).detach()
+    assert float((e1 - e2).abs().max()) < 1e-6
