@@ -483,10 +483,15 @@ void gso_render_backward(int P, int W, int H, int S, const uint32_t* ranges,
   double* a_col = (double*)calloc((size_t)P * 3 + 1, sizeof(double));
   double* a_dep = (double*)calloc((size_t)P + 1, sizeof(double));
   double* a_sem = (double*)calloc((size_t)P * (S > 0 ? S : 1) + 1, sizeof(double));
-  float* accum_semantic_rec = (float*)calloc(S > 0 ? S : 1, sizeof(float));
-  float* last_semantic = (float*)calloc(S > 0 ? S : 1, sizeof(float));
   const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H); /* :501-502 */
-  for (int py = 0; py < H; py++)
+  /* OpenMP build: pixel rows in parallel.  Every per-(pixel, Gaussian) term is still the
+   * reference's fp32 expression; the terms are added into the fp64 accumulators atomically, so
+   * only the ORDER of the fp64 sums differs between runs (~1e-16 relative: far below anything
+   * the tests resolve).  The scalar build is the same code with the pragmas as comments. */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < H; py++) {
+    float* accum_semantic_rec = (float*)calloc(S > 0 ? S : 1, sizeof(float));
+    float* last_semantic = (float*)calloc(S > 0 ? S : 1, sizeof(float));
     for (int px = 0; px < W; px++) {
       const size_t pix_id = (size_t)W * py + px;
       const float pixf[2] = {(float)px, (float)py};
@@ -522,6 +527,7 @@ void gso_render_backward(int P, int W, int H, int S, const uint32_t* ranges,
           last_color[ch] = c;
           const float dL_dchannel = dL_dpixel[ch];
           dL_dopa += (c - accum_rec[ch]) * dL_dchannel;
+          _Pragma("omp atomic")
           a_col[3 * (size_t)id + ch] += (double)(dchannel_dcolor * dL_dchannel);
         }
         for (int ch = 0; ch < S; ch++) { /* :571-587 */
@@ -530,12 +536,14 @@ void gso_render_backward(int P, int W, int H, int S, const uint32_t* ranges,
           last_semantic[ch] = s;
           const float dL_dchannel = dL_dpixel_semantics[ch * HW + pix_id];
           dL_dopa += (s - accum_semantic_rec[ch]) * dL_dchannel;
+          _Pragma("omp atomic")
           a_sem[(size_t)id * S + ch] += (double)(dchannel_dcolor * dL_dchannel);
         }
         const float c_d = depths[id]; /* :592-597 */
         accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
         last_depth = c_d;
         dL_dopa += (c_d - accum_depth_rec) * dL_dpixel_depth;
+        _Pragma("omp atomic")
         a_dep[id] += (double)(dchannel_dcolor * dL_dpixel_depth);
         accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec; /* :601-602 */
         dL_dopa += (1 - accum_alpha_rec) * dL_dalpha;
@@ -548,15 +556,24 @@ void gso_render_backward(int P, int W, int H, int S, const uint32_t* ranges,
         const float gdx = G * dx, gdy = G * dy;
         const float dG_ddelx = -gdx * co[0] - gdy * co[1];
         const float dG_ddely = -gdy * co[2] - gdx * co[1];
+        _Pragma("omp atomic")
         a_mean[3 * (size_t)id + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+        _Pragma("omp atomic")
         a_mean[3 * (size_t)id + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+        _Pragma("omp atomic")
         a_mean[3 * (size_t)id + 2] += (double)(fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy));
+        _Pragma("omp atomic")
         a_conic[4 * (size_t)id + 0] += (double)(-0.5f * gdx * dx * dL_dG);
+        _Pragma("omp atomic")
         a_conic[4 * (size_t)id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
+        _Pragma("omp atomic")
         a_conic[4 * (size_t)id + 3] += (double)(-0.5f * gdy * dy * dL_dG);
+        _Pragma("omp atomic")
         a_opa[id] += (double)(G * dL_dopa);
       }
     }
+    free(accum_semantic_rec); free(last_semantic);
+  }
   for (size_t i = 0; i < (size_t)P * 3; i++) dL_dmean2D[i] = (float)a_mean[i];
   for (size_t i = 0; i < (size_t)P * 4; i++) dL_dconic[i] = (float)a_conic[i];
   for (size_t i = 0; i < (size_t)P; i++) dL_dopacity[i] = (float)a_opa[i];
@@ -564,7 +581,6 @@ void gso_render_backward(int P, int W, int H, int S, const uint32_t* ranges,
   for (size_t i = 0; i < (size_t)P; i++) dL_ddepths[i] = (float)a_dep[i];
   for (size_t i = 0; i < (size_t)P * S; i++) dL_dsemantics[i] = (float)a_sem[i];
   free(a_mean); free(a_conic); free(a_opa); free(a_col); free(a_dep); free(a_sem);
-  free(accum_semantic_rec); free(last_semantic);
 }
 
 /* CR/auxiliary.h:107-117 (float3 overload) */

@@ -124,6 +124,18 @@ def test_backward_street(dev):
     _run(dev, sc, hz.trajectory_camera(5, W=480, H=320), torch.zeros(3), seed=5)
 
 
+def test_backward_config4_full_size(dev):
+    """configs[4] at its stated size: scene-149-like, P = 1 M @1920x1280, every gradient array of the
+    op against the oracle's backward (OpenMP build: pixel rows in parallel, fp64 accumulators; the
+    scalar build gives the same float32 results, checked at 10 k..1 M in the CPU suite)."""
+    sc = hz.street_scene(1_000_000, seed=149)
+    oracle.use_openmp(True)
+    try:
+        _run(dev, sc, hz.trajectory_camera(5), torch.zeros(3), seed=149)
+    finally:
+        oracle.use_openmp(False)
+
+
 def test_backward_long_lists(dev):
     """Tiles with 10-18 k entries whose pixels keep blending past entry 15 000 (the forward renders
     them with producer/consumer wave pairs; the backward walks the whole list back to front)."""

@@ -258,3 +258,17 @@ def test_openmp_oracle_build_is_bit_identical():
     for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "ranges", "keys_sorted",
               "fragile"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    # backward: pixel rows in parallel, the same fp32 terms added atomically into the fp64
+    # accumulators -- only the order of the fp64 sums differs, i.e. the float32 results agree to
+    # the last bit or, rarely, one ulp
+    H, W = cam.image_height, cam.image_width
+    g = torch.Generator().manual_seed(8)
+    gc, gd, ga = torch.randn(3, H, W, generator=g), 0.1 * torch.randn(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    ga_ = oracle.backward(a, gc, gd, ga)
+    try:
+        oracle.use_openmp(True)
+        gb_ = oracle.backward(b, gc, gd, ga)
+    finally:
+        oracle.use_openmp(False)
+    for k in ga_:
+        np.testing.assert_allclose(gb_[k], ga_[k], rtol=3e-7, atol=0, err_msg=k)
