@@ -13,22 +13,30 @@ trajectory mode.  With N GPUs the frames of the synthetic 200-pose drive are sha
 scaling) and the ONLY collective is the RCCL gather of the uint8 frames to rank 0, inside the
 timed region.  Rank 0 prints one JSON line.
 
-The frame loop alternates over `--streams` HIP streams (default 3) and uses the deferred-count
-entry point (`--deferred 1`, default: GaussianRasterizer.forward_deferred / C ABI
-grpg_forward_deferred): a frame is enqueued without the reference's per-frame host wait for
-num_rendered; every frame's status is checked a few frames behind, inside the timed region, and a
-frame that outgrew the capacity it was enqueued with is rendered again (`frames_rendered_twice` in
-the line's config; normally 0).  The streams, the output buffer and the allocator pools of ALL
-streams exist before the warm-up: the W warm-up frames run through exactly the loop that is timed
-afterwards.
+The frame loop alternates over `--streams` HIP streams (default 3).  `value` goes through the
+UNCHANGED reference surface, `GaussianRasterizer.forward` -> `_C.rasterize_gaussians*` (`--entry
+forward`, default), which returns the exact num_rendered of every frame; the library publishes that
+count right behind preprocess, so the call does not stall the stream.  The same loop through the
+additive deferred-count entry point (`GaussianRasterizer.forward_deferred`, C ABI
+grpg_forward_deferred: status checked a few frames behind, overflowed frames rendered again and
+counted in `frames_rendered_twice`) is timed right after it and reported under `entry_points`
+(`--entry deferred` makes it the headline instead).  The streams, the output buffer and the allocator
+pools of ALL streams exist before the warm-up: the W warm-up frames run through exactly the loop that
+is timed afterwards.
 
 Extra objects in the line:
   roofline        dominant kernel (render_forward_kernel): algorithmic bytes per launch
-                  (44*R + 8*T + 20*N, SURVEY.md §8(d) / DESIGN.md §6) / its average duration measured
-                  with HIP events on the op's own stream during the timed region, vs 8 TB/s.  With
-                  several frames in flight the kernel SHARES the chip with the other frames' kernels,
-                  so its wall duration (and this fraction) is not its speed alone: roofline_serial is
-                  the same kernel timed with one frame in flight.
+                  (44*R + 8*T + 20*N, SURVEY.md §8(d) / DESIGN.md §6) / the kernel's OWN average duration:
+                  HIP events on the op's stream around the launch with one frame in flight (a pass of
+                  20 frames right behind the timed region; agrees with the rocprofv3 average committed
+                  under profiles/), vs 8 TB/s.  `traffic` = HBM bytes per launch from the committed PMC
+                  passes of this round (profiles/round3_traffic.json), null if absent.
+  roofline_overlapped  the same kernel's wall duration INSIDE the timed region, where several
+                  frames share the chip: time-sharing, not the kernel's speed.
+  roofline_valu   the render kernel's real bound: VALU busy time from the committed PMC pass
+                  (SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x shader clock)) / kernel duration,
+                  pair evaluations per second, and the instruction rate against the measured chip-wide
+                  VALU issue peak (tools/ubench/valu_rate.hip, profiles/round3_valu_rate.*).
   frame_roofline  whole-frame B_alg / ms_per_step (the figure BASELINE.json asks for).
   stages_ms(_serial)  per-stage average device time from HIP events on the op's stream.
   frame_latency   the reference's own method (render.py:30-60): synchronize-bracketed wall time per
@@ -57,6 +65,10 @@ from gaussianrpg_amd import harness as hz  # noqa: E402
 from gaussianrpg_amd import trajectory as tj  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+# chip-wide VALU issue peak measured by tools/ubench/valu_rate.hip on an MI355X (profiles/round3_valu_rate.txt):
+# wave64 v_fma_f32 instructions per second with 8 resident waves per SIMD on all 1024 SIMDs
+VALU_PEAK_GINSTR = 848.0
+VALU_CLOCK_GHZ = 2.4           # hipDeviceProp clockRate; SQ_ACTIVE_INST_VALU counts quad-cycles of it
 NUM_FRAMES = 200               # poses of the synthetic drive (BASELINE config 4)
 P_GAUSS = 2_000_000            # "Waymo scene 002 full Street-Gaussians (~2M)" stand-in
 SCENE_SEED = 2
@@ -84,10 +96,13 @@ def parse():
     ap.add_argument("--gather-batch", type=int, default=-1,
                     help="N > 1: frames per asynchronous gather to rank 0 (0 = one gather at the end; "
                          "default: min(25, steps // 5), so that a short run still overlaps its transfers)")
-    ap.add_argument("--deferred", type=int, default=1,
-                    help="1 (default): the frame loop uses forward_deferred -- frames are enqueued without "
-                         "the per-frame wait for num_rendered, their status is checked a few frames "
-                         "behind and an overflowed frame is rendered again; 0: one wait per frame")
+    ap.add_argument("--entry", choices=("forward", "deferred"), default="forward",
+                    help="entry point of the headline loop: forward (default) = GaussianRasterizer.forward, "
+                         "the reference's unchanged surface, exact num_rendered per call; deferred = the "
+                         "additive forward_deferred (status checked a few frames behind, an overflowed frame "
+                         "is rendered again).  The other one is timed too and reported under entry_points")
+    ap.add_argument("--deferred", type=int, default=None, help="legacy alias: 1 = --entry deferred, 0 = forward")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second entry point's timed loop")
     ap.add_argument("--no-delivery", action="store_true",
                     help="skip the host-delivery (rgb8 over PCIe) side measurement")
     ap.add_argument("--binning-mode", type=int, default=0,
@@ -194,7 +209,7 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
     lidar = (torch.rand(1, H, W, generator=g) * 80.0).to(dev)
     lidar[:, ::3] = 0.0
     sky = (torch.rand(1, H, W, generator=g) < 0.2).to(dev)
-    fw, bw, lb, Vs, Rs = [], [], [], [], []
+    fw, bw, lb, ob, Vs, Rs = [], [], [], [], [], []
     from gaussianrpg_amd.rasterizer import _C
     for it in range(warmup + steps):
         cam = hz.trajectory_camera(it % NUM_FRAMES, device=dev)
@@ -225,8 +240,15 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
             gouts = torch.autograd.grad(loss, outs)
             torch.cuda.synchronize()
             t3 = time.perf_counter()
+            # the op's own backward (_C.rasterize_gaussians_backward: gradient pools' zero-fill,
+            # render_backward_kernel, preprocess_backward_kernel), device time between two events
+            eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eb0.record()
             torch.autograd.backward(outs, gouts)
+            eb1.record()
             torch.cuda.synchronize()
+            if it >= warmup:
+                ob.append(eb0.elapsed_time(eb1))
             t4 = None
         n_xy, n_abs = hz.densification_stats(pkg["viewspace_points"], pkg["visibility_filter"])
         assert torch.isfinite(n_xy).all() and torch.isfinite(n_abs).all()
@@ -247,24 +269,28 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
                                          sc.scales, sc.rotations, 1.0, e, kw["viewmatrix"], kw["projmatrix"],
                                          kw["tanfovx"], kw["tanfovy"], H, W, sc.shs, 1, kw["campos"], False, False)
             Rs.append(int(out[0]))
-    fw.sort(), bw.sort(), lb.sort()
+    fw.sort(), bw.sort(), lb.sort(), ob.sort()
     V, R, M, S, N = sum(Vs) / len(Vs), sum(Rs) / len(Rs), 4, 0, W * H
     b_bwd = (28 + 4 * S) * N + (44 + 4 * S) * R + 92 * V + (163 + 24 * M + 4 * S) * P
     bwd_ms = 1e3 * bw[len(bw) // 2]
+    op_bwd_ms = ob[len(ob) // 2]
     return {"config": "configs[4]: train fwd+bwd, scene-149-like P=%d @%dx%d, train-mode arguments, "
                       "loss = L1 + sky(acc) + lidar(depth/acc) (train.py:110-176)" % (P, W, H),
             "steps": steps, "P": P, "V_avg": V, "R_avg": R,
             "forward_ms_median": 1e3 * fw[len(fw) // 2], "backward_ms_median": bwd_ms,
             "loss_backward_ms_median": 1e3 * lb[len(lb) // 2],
-            "timing": "synchronize-bracketed wall time; backward = loss.backward() (the loss' own PyTorch "
-                      "backward + _C.rasterize_gaussians_backward incl. gradient allocation), on every other "
-                      "iteration; loss_backward = the loss' own backward alone (torch.autograd.grad down to "
-                      "the op's outputs) on the iterations in between; the kernels' device times are in "
-                      "profiles/round2_train_summary.txt",
+            "op_backward_device_ms_median": op_bwd_ms,
+            "timing": "forward / backward / loss_backward: synchronize-bracketed wall time (backward = "
+                      "loss.backward(): the loss' own PyTorch backward + _C.rasterize_gaussians_backward incl. "
+                      "gradient allocation, on every other iteration; loss_backward = the loss' own backward "
+                      "alone, on the iterations in between).  op_backward_device = HIP events around the op's "
+                      "backward alone (gradient zero-fill + render_backward_kernel + "
+                      "preprocess_backward_kernel); per-kernel times: profiles/round3_train_summary.txt",
             "backward_algorithmic_bytes": b_bwd,
-            "backward_roofline": {"bound": "hbm", "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9,
+            "backward_roofline": {"bound": "hbm", "achieved": b_bwd / (op_bwd_ms * 1e-3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                                  "frac": b_bwd / (op_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "measured": "algorithmic bytes / op_backward_device_ms_median"}}
 
 
 def main():
@@ -272,6 +298,9 @@ def main():
     if args.cpu_baseline_worker:
         _cpu_baseline_worker(args.cpu_baseline_worker)
         return
+    if args.deferred is not None:
+        args.entry = "deferred" if args.deferred else "forward"
+    use_deferred = [args.entry == "deferred"]     # which entry point frame_loop goes through
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -352,7 +381,7 @@ def main():
             # --deferred (default): the frames go through forward_deferred -- no host wait for
             # num_rendered per frame; every frame's status is checked (4 frames behind, the rest
             # before the loop returns) and a frame that outgrew its capacity is rendered again
-            deferred = tj.DeferredFrames(window=4) if args.deferred else None
+            deferred = tj.DeferredFrames(window=4) if use_deferred[0] else None
             for s in range(n):
                 with torch.cuda.stream(streams[s % ns]):
                     slot = local[s % local.shape[0]]
@@ -441,6 +470,56 @@ def main():
             _C.set_stage_timing(0)
             attempts.append(elapsed)
 
+        # The other entry point through the very same loop (untimed warm-up of W frames first):
+        # reported beside the headline under entry_points, never as `value`.
+        entry_fps = {args.entry: world * K / elapsed}
+        other = "forward" if args.entry == "deferred" else "deferred"
+        if not args.no_secondary:
+            use_deferred[0] = other == "deferred"
+            redone_keep = redone_frames[0]
+            frame_loop(max(Wm, 2 * ns))
+            torch.cuda.synchronize()
+            _C.set_stage_timing(0)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            to0 = time.perf_counter()
+            works = frame_loop(K, do_gather=world > 1)
+            for w_ in works:
+                w_.wait()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt_o = time.perf_counter() - to0
+            if world > 1:
+                te = torch.tensor([dt_o], device=cdev, dtype=torch.float64)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                dt_o = float(te.item())
+            entry_fps[other] = world * K / dt_o
+            redone_other = redone_frames[0] - redone_keep
+            redone_frames[0] = redone_keep
+            use_deferred[0] = args.entry == "deferred"
+        else:
+            redone_other = None
+
+        # SURVEY.md §8(d) "Timing method": hipEvent pair around the op alone (all of its launches,
+        # one frame in flight, eval entry), median / p95 over 50 frames
+        op_events = None
+        if world == 1:
+            evs = []
+            for k in range(51):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                render_frame(frames_of(k))
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in evs[1:])
+            op_events = {"frames": len(ms), "median_ms": ms[len(ms) // 2], "p95_ms": ms[int(len(ms) * 0.95)],
+                         "mean_ms": sum(ms) / len(ms),
+                         "method": "torch.cuda.Event pair on the op's stream around GaussianRasterizer.forward "
+                                   "alone (no clamp / pack), one frame in flight, first frame excluded"}
+
         # the reference's own timer (render.py:30-60): synchronize-bracketed wall time per frame
         latency = None
         if world == 1:
@@ -486,7 +565,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             ts0 = time.perf_counter()
-            if (backend == "nccl" or world == 1) and args.deferred:
+            if (backend == "nccl" or world == 1) and args.entry == "deferred":
                 frames = tj.render_sharded(None, NUM_FRAMES, rank, world, gather=True, num_streams=ns,
                                            gather_batch=args.gather_batch or None, streams=streams,
                                            frame_source=lambda i: (rasterizers[i % NUM_FRAMES], frame_inputs))
@@ -512,7 +591,7 @@ def main():
             del frames
 
         # untimed statistics pass: V and R of the frames this rank rendered
-        Vs, Rs = [], []
+        Vs, Rs, pair_evals = [], [], []
         e = torch.Tensor([])
         sem0 = torch.zeros(P, 0, device=dev)
         for s in range(min(K, 50)):
@@ -523,6 +602,10 @@ def main():
                                          rs.image_width, sc.shs, rs.sh_degree, rs.campos, False, False)
             Rs.append(int(out[0]))
             Vs.append(int((out[5] > 0).sum()))
+            if s < 4:   # (pixel, splat) pairs the blend walks: sum over pixels of the last contributor's index
+                from gaussianrpg_amd.rasterizer import debug_export
+                dbg = debug_export(out[6], out[7], out[8], P, int(out[0]), H, W)
+                pair_evals.append(int(dbg["n_contrib"].to(torch.int64).sum()))
         torch.cuda.synchronize()
 
     train = None
@@ -548,30 +631,74 @@ def main():
         render_ms = stages["render"]
         b_render = 44.0 * R_avg + 8.0 * T_tiles + 20.0 * N
         b_frame = P * (48 + 12 * M) + 40.0 * V_avg + 88.0 * R_avg + 16.0 * T_tiles + 20.0 * N
-        # HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_gpu.sh
-        # (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), if a profile of
-        # this same workload AND this round's kernels has been committed; otherwise null.
-        traffic = None
-        for name in ("round2_traffic.json",):
+        # HBM bytes per launch of the dominant kernel and its VALU counters from the PMC passes of
+        # tools/profile_gpu.sh (separate rocprofv3 --pmc runs; FETCH_SIZE / WRITE_SIZE corrected as
+        # MI355X_MICROARCH.md prescribes), if a profile of this same workload AND this round's kernels
+        # has been committed; otherwise null.  Not measurable inside this process.
+        traffic, pmc, pmc_file = None, None, None
+        for name in ("round3_traffic.json",):
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 wl = tr.get("workload", {})
                 if wl.get("P") == P and wl.get("width") == W and wl.get("height") == H:
-                    traffic = tr["render_forward_kernel"]["hbm_bytes_corrected"]
+                    pmc = tr["render_forward_kernel"]
+                    traffic = pmc["hbm_bytes_corrected"]
+                    pmc_file = "profiles/" + name
                     break
             except Exception:
-                traffic = None
-        roof = None
-        if render_ms:
-            ach = b_render / (render_ms * 1e-3) / 1e9
-            roof = {"kernel": "render_forward_kernel", "bound": "hbm", "achieved": ach,
+                traffic, pmc = None, None
+
+        def hbm_roof(kernel_ms, how):
+            ach = b_render / (kernel_ms * 1e-3) / 1e9
+            return {"kernel": "render_forward_kernel", "bound": "hbm", "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": b_render,
-                    "avg_launch_ms": render_ms,
-                    "frames_in_flight": ("several (deferred count, %d streams): the kernel's wall time is "
-                                         "shared with the other frames' kernels -- see roofline_serial" % ns)
-                    if args.deferred else "at most %d (one host wait per frame)" % ns,
-                    "note": "render is VALU-bound (about 25 flop per pixel-splat pair), see DESIGN.md §6"}
+                    "traffic": traffic, "traffic_source": pmc_file,
+                    "algorithmic_bytes_per_launch": b_render, "avg_launch_ms": kernel_ms,
+                    "measured": how}
+
+        # `roofline`: the kernel's own duration (one frame in flight); `roofline_overlapped`: its wall
+        # duration inside the timed region, where the other frames' kernels share the chip
+        roof = roof_overlapped = roof_valu = None
+        serial_render_ms = stages_iso["render"]
+        if serial_render_ms:
+            roof = hbm_roof(serial_render_ms,
+                            "HIP events on the op's stream around the launch, %d frames with one frame in "
+                            "flight, right behind the timed region" % iso_calls)
+            roof["note"] = ("render is VALU-bound, not HBM-bound (about 25 flop per pixel-splat pair): see "
+                            "roofline_valu and DESIGN.md §6")
+        if render_ms:
+            roof_overlapped = hbm_roof(render_ms,
+                                       "HIP events around the launch INSIDE the timed region: %d streams, "
+                                       "several frames' kernels share the chip (time-sharing, not the "
+                                       "kernel's speed)" % ns)
+        if serial_render_ms:
+            pairs = sum(pair_evals) / len(pair_evals) if pair_evals else None
+            roof_valu = {"kernel": "render_forward_kernel", "bound": "valu",
+                         "pair_evals_per_frame": pairs,
+                         "pair_evals_per_s": pairs / (serial_render_ms * 1e-3) if pairs else None,
+                         "pair_evals_definition": "sum over pixels of n_contrib (list entries a pixel walks "
+                                                  "before it terminates: what the reference's schedule evaluates)"}
+            if pmc and pmc.get("SQ_INSTS_VALU"):
+                simds, clk = 1024, VALU_CLOCK_GHZ * 1e9
+                busy_s = pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (simds * clk)
+                roof_valu.update({
+                    "wave_valu_instructions_per_launch": pmc["SQ_INSTS_VALU"],
+                    "valu_busy_quad_cycles_per_launch": pmc.get("SQ_ACTIVE_INST_VALU"),
+                    "valu_busy_ms": busy_s * 1e3,
+                    "frac": busy_s / (serial_render_ms * 1e-3),
+                    "instr_per_s": pmc["SQ_INSTS_VALU"] / (serial_render_ms * 1e-3),
+                    "peak_instr_per_s": VALU_PEAK_GINSTR * 1e9,
+                    "frac_of_peak_instr_rate": pmc["SQ_INSTS_VALU"] / (serial_render_ms * 1e-3) / (VALU_PEAK_GINSTR * 1e9),
+                    "peak_source": "tools/ubench/valu_rate.hip (profiles/round3_valu_rate.txt): %.0f G wave-instr/s "
+                                   "chip-wide for dependency-free v_fma_f32; v_pk_fma_f32 / v_pk_mul_f32 issue at "
+                                   "about 0.55x and v_exp_f32 at 0.36x that rate, so a mix of them saturates the "
+                                   "VALU below the plain-fma instruction rate (frac = busy time, the real bound)"
+                                   % VALU_PEAK_GINSTR,
+                    "counters_source": pmc_file,
+                    "clock_ghz_assumed": VALU_CLOCK_GHZ})
+        # reference-schedule traffic: what CR/rasterizer_impl.cu moves per frame on top of
+        # the algorithmic bytes -- 64-bit keys + 32-bit values through a 6-pass sort, per-pixel ranges
+        b_ref = b_frame + 128.0 * R_avg + 27.0 * V_avg + 16.0 * P
         ach_f = b_frame / (ms_per_step * 1e-3) / 1e9
         line = {
             "metric": "frames/sec @1920x1280, ~2M Gaussians; achieved HBM GB/s vs peak",
@@ -585,13 +712,30 @@ def main():
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
                        "streams_per_gpu": ns, "binning_mode": "exact" if args.binning_mode else "speculative",
                        "binning_algorithm": "hierarchical" if STAGES is STAGES_HIER else "sort",
-                       "deferred_count": bool(args.deferred), "frames_rendered_twice": redone_frames[0],
+                       "entry_point": ("GaussianRasterizer.forward" if args.entry == "forward"
+                                       else "GaussianRasterizer.forward_deferred"),
+                       "deferred_count": args.entry == "deferred", "frames_rendered_twice": redone_frames[0],
                        "gather_batch_frames": args.gather_batch if world > 1 else None,
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
             "roofline": roof,
+            "roofline_overlapped": roof_overlapped,
+            "roofline_valu": roof_valu,
             "frame_roofline": {"bound": "hbm", "achieved": ach_f, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach_f / HBM_PEAK_GBS,
-                               "algorithmic_bytes_per_frame": b_frame},
+                               "algorithmic_bytes_per_frame": b_frame,
+                               "reference_schedule_bytes_per_frame": b_ref,
+                               "note": "B_alg = P(48+12M) + 40V + 88R + 16T + 20N; B_ref = B_alg + 128R + 27V + 16P "
+                                       "(SURVEY.md §8(d)) is what the reference's own schedule would move"},
+            "entry_points": {
+                "headline": args.entry,
+                "forward": entry_fps.get("forward"),
+                "forward_deferred": entry_fps.get("deferred"),
+                "unit": "frames/s",
+                "frames_rendered_twice_other_entry": redone_other,
+                "what": "the same %d-stream loop through GaussianRasterizer.forward (the reference's unchanged "
+                        "surface: exact num_rendered returned by every call) and through the additive "
+                        "forward_deferred (status checked 4 frames behind)" % ns},
+            "op_device_time": op_events,
             "stages_ms": stages,
             "stages_ms_serial": stages_iso,
             "serial_stage_sum_ms": serial_sum_ms,
@@ -601,13 +745,6 @@ def main():
             "strong_scaling": strong,
             "train": train,
         }
-        if stages_iso["render"]:
-            ach_i = b_render / (stages_iso["render"] * 1e-3) / 1e9
-            line["roofline_serial"] = {"kernel": "render_forward_kernel", "bound": "hbm",
-                                       "achieved": ach_i, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": ach_i / HBM_PEAK_GBS,
-                                       "avg_launch_ms": stages_iso["render"],
-                                       "note": "same kernel timed with one stream (no frame overlap)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(int(R_avg))
         print(json.dumps(line), flush=True)

@@ -3,15 +3,16 @@
 // (cuda_rasterizer/rasterizer_impl.cu:197-343, :396-505, :141-153, :345-392).
 //
 // Forward schedule on the caller's stream:
-//   frame init -> preprocess -> depth sort of the (key,id) pairs, 4 x 8-bit passes -> exclusive
-//   scan of the per-Gaussian tile counts in depth order (num_rendered lands in device memory and
-//   in a pinned host word) -> instance emit -> stable tile partition (ceil(log2 T) bits, <= 2
-//   passes) -> tile ranges -> render (-> semantic render).
+//   frame init -> preprocess (+ per-workgroup sums of the tile counts) -> count publish (num_rendered
+//   and the coarse pair count land in a pinned host word, event) -> depth sort of the (key,id)
+//   pairs -> binning (hierarchical: coarse scan / emit / partition / counts / fill; or sort: offsets
+//   scan / instance emit / stable tile partition / ranges) -> render (-> semantic render).
 // The binning blob is carved for a capacity remembered from earlier frames, every kernel reads the
-// instance count from device memory, and the host waits for the count only AFTER the whole frame
-// is enqueued (it needs it for the return value): no bubble in the stream.  First frame of a
-// shape, exact mode, or capacity overflow: wait first / redo the tail, like the reference's one
-// blocking read (rasterizer_impl.cu:284).
+// instance count from device memory, and the host reads the published count only AFTER the whole
+// frame is enqueued (it needs it for the return value): by then the count -- known 70 us into the
+// frame -- has arrived, so neither the stream nor the host idles.  First frame of a shape / exact
+// mode: read the count first, then carve and enqueue the tail; capacity overflow: redo the tail,
+// like the reference's one blocking read (rasterizer_impl.cu:284).
 // There is no CPU fallback: without a usable HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
@@ -436,10 +437,11 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                       geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
     uint2* rects = hier ? (uint2*)(geom + GL.rects) : nullptr;
     uint2* rect_sorted = (uint2*)(geom + GL.rect_sorted);
+    uint2* pre_counts = (uint2*)(geom + GL.pre_counts);
     if (segs == nullptr) {
       launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                         cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles, rects,
-                        fat_sort ? ds_table : nullptr);
+                        fat_sort ? ds_table : nullptr, pre_counts);
     } else {
       // segment table: host structs -> pinned staging -> the geometry blob (asynchronous copy)
       if (!g_seg_staging)
@@ -462,8 +464,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)nseg,
                              hipMemcpyHostToDevice, stream));
       launch_preprocess_composed(stream, P, D, M, seg_dev, nseg, scale_modifier, cam, radii_int, rec_w,
-                                 key_a, tiles, rects, fat_sort ? ds_table : nullptr);
+                                 key_a, tiles, rects, fat_sort ? ds_table : nullptr, pre_counts);
     }
+    // num_rendered (and the coarse pair count) as sums of the per-Gaussian counts: in the pinned
+    // word ~70 us into the frame, with an event behind it.  The host looks at it only after the
+    // whole frame is enqueued (speculative mode) -- by then it has long arrived, so grpg_forward
+    // returns the exact count without ever idling the stream or itself.
+    launch_publish_counts(stream, pre_counts, (uint32_t)((P + 255) / 256), pub_ptr, &gh->R_pre);
+    HIP_TRY(hipEventRecord(pub_ev, stream));
     STAGE_CHECK("preprocess");
     tm.mark(1);
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key.
@@ -481,15 +489,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     STAGE_CHECK("depth sort");
     tm.begin_tail();
     uint32_t* emit_win = (uint32_t*)(geom + GL.emit_win);
-    // num_rendered from the tile counts (the only way the sort path learns it; the hierarchical path
-    // uses it when it has no capacity to speculate with): scan, count to the pinned word, event
-    auto scan_tiles = [&](uint32_t* word, hipEvent_t ev) -> int {
+    // sort path: exclusive offsets of the per-Gaussian tile counts in depth order (the count itself
+    // is already on its way to the host, see above)
+    auto scan_tiles = [&]() -> int {
       tm.mark(2);
       launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, fat_sort ? sorted_gid : nullptr, tiles,
-                          offsets, block_sums, GL.nblocks_scan, &gh->R, word, emit_win,
+                          offsets, block_sums, GL.nblocks_scan, &gh->R, nullptr, emit_win,
                           GL.emit_win_cap);
       STAGE_CHECK("offsets scan");
-      HIP_TRY(hipEventRecord(ev, stream));   // fires when num_rendered sits in the pinned word
       return GRPG_OK;
     };
     auto render_tail = [&](const uint32_t* point_list, uint32_t cap, bool classified) -> int {
@@ -545,13 +552,12 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     };
     // hierarchical path (hier_binning.hip): everything behind the depth sort.  Stage slots: 2 = scan
     // over the super-tile counts, 3 = coarse emit, 4 = coarse partition + super-tile runs,
-    // 5 = segment counts, tile ranges and the point-list fill.  `publish`: the tile scan stores
-    // num_rendered (and the coarse count) to the pinned word and the event is recorded behind it.
+    // 5 = segment counts, tile ranges and the point-list fill.
     const int sgx = (cam.gx + STILE - 1) / STILE, sgy = (cam.gy + STILE - 1) / STILE;
     const int cbits = bits_for(NS);
     const int cpasses = radix_sort_num_passes(0, cbits);
     const int cbits0 = radix_sort_first_pass_bits(0, cbits);
-    auto tail_hier = [&](char* binp, const BinLayout& L, uint32_t cap, uint32_t ccap, bool publish) -> int {
+    auto tail_hier = [&](char* binp, const BinLayout& L, uint32_t cap, uint32_t ccap) -> int {
       uint32_t* ckey_a = (uint32_t*)(binp + L.key_a);
       uint32_t* ckey_b = (uint32_t*)(binp + L.key_b);
       uint32_t* cval_a = (uint32_t*)(binp + L.val_b);
@@ -586,10 +592,9 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       launch_hier_count(stream, cranges, runs_from_totals ? btotals : nullptr, NS, binp + L.seg_desc, (uint2*)(binp + L.st_seg),
                         (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
                         (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
-                        (uint32_t*)(binp + L.tile_start), ranges, &gh->R, publish ? pub_ptr : nullptr,
+                        (uint32_t*)(binp + L.tile_start), ranges, &gh->R, nullptr,
                         &gh->Rc, (BlobHeader*)binp, cap, ccap, work, heavy_tile_min());
       STAGE_CHECK("tile counts");
-      if (publish) HIP_TRY(hipEventRecord(pub_ev, stream));
       launch_hier_fill(stream, binp + L.seg_desc, (const uint32_t*)(binp + L.nseg), L.max_seg, ckey, cval, rec,
                        cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),
                        (const uint32_t*)(binp + L.tile_start), cap, plist);
@@ -608,14 +613,18 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     };
     const bool spec_mode = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE;
 
-    // Speculative: the whole frame is enqueued, then the one host wait (the device is already busy
-    // with the rest of the frame and the caller can enqueue the next one as soon as we return).
-    // Exact mode / no history: wait for the count first, like the reference (rasterizer_impl.cu:284).
-    bool need_exact = !speculative;
+    // Speculative: the whole frame is enqueued for the remembered capacities, then the host reads
+    // the count (published right behind preprocess: normally there already).  No history / exact
+    // mode: read the count first, carve the blob for it, then enqueue the tail -- like the
+    // reference's one blocking read (rasterizer_impl.cu:284), only much earlier in the frame.
     uint32_t Rc_seen = 0u;   // coarse count of this frame, once the host has seen it
+    auto run_tail = [&]() -> int {
+      if (hier) return tail_hier(bin, BL, Rcap, Ccap);
+      if (int rc = scan_tiles()) return rc;
+      return tail_sort(bin, BL, Rcap);
+    };
     if (speculative) {
-      if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, true)) return rc; }
-      else { if (int rc = scan_tiles(pub_ptr, pub_ev)) return rc; if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+      if (int rc = run_tail()) return rc;
       if (defer) {
         // deferred frame: the count is checked by grpg_frame_status, nothing to wait for here
         defer->state = 1;
@@ -623,35 +632,28 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
         tm.finish();
         return 0;
       }
-      HIP_TRY(hipEventSynchronize(hw->ev));
-      R = hw->host_ptr[0];
-      if (hier) Rc_seen = hw->host_ptr[1];
-      if (hier && Rc_seen > Ccap) {
-        need_exact = true;          // the coarse list itself was clamped: the count is not usable
-      } else if (R > Rcap) {
-        // capacity overflow (the speculative tail clamped its work to the old capacity and its
-        // results are discarded): R is exact; carve the blob for it and redo the tail
-        if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
-        if (int rc = carve(padded_capacity(R), Ccap, true)) return rc;
-        tm.restart_tail();
-        if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, false)) return rc; }
-        else { if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
-      }
     }
-    if (need_exact) {
+    HIP_TRY(hipEventSynchronize(pub_ev));
+    R = (defer ? defer->host_ptr : hw->host_ptr)[0];
+    if (hier) Rc_seen = (defer ? defer->host_ptr : hw->host_ptr)[1];
+    if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+    if (!speculative || R > Rcap || (hier && Rc_seen > Ccap)) {
+      // first frame of a shape / exact mode: carve for the count just read.  Capacity overflow: the
+      // speculative tail clamped its work to the old capacities and its results are discarded; both
+      // counts are exact, so one redo on a larger blob settles it.
       const bool redo = speculative;
+      uint32_t cap = Rcap, ccap = Ccap;
+      if (!speculative) {
+        cap = spec_mode ? padded_capacity(R) : R;
+        ccap = hier ? (spec_mode ? padded_capacity(Rc_seen) : Rc_seen) : cap;
+      } else {
+        if (R > Rcap) cap = padded_capacity(R);
+        if (hier && Rc_seen > Ccap) ccap = padded_capacity(Rc_seen);
+      }
+      if (ccap > cap) ccap = cap;     // a (Gaussian, super-tile) pair holds >= 1 instance
       if (redo) tm.restart_tail();
-      if (int rc = scan_tiles(hw->dev_ptr, hw->ev)) return rc;
-      HIP_TRY(hipEventSynchronize(hw->ev));
-      R = hw->host_ptr[0];
-      if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
-      // the coarse count is unknown here, but never above num_rendered
-      const uint32_t cap = spec_mode ? padded_capacity(R) : R;
-      uint32_t ccap = cap;
-      if (Rc_seen && padded_capacity(Rc_seen) < cap) ccap = padded_capacity(Rc_seen);   // exact, from the scan
       if (int rc = carve(cap, ccap, redo)) return rc;
-      if (hier) { if (int rc = tail_hier(bin, BL, Rcap, Ccap, false)) return rc; }
-      else { if (int rc = tail_sort(bin, BL, Rcap)) return rc; }
+      if (int rc = run_tail()) return rc;
     }
     if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
     update_hint(ck, R, Rc_seen);

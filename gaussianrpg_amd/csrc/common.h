@@ -65,7 +65,8 @@ struct BlobHeader {      // first 256 bytes of every blob
   uint32_t Rc;           // coarse (Gaussian, super-tile) pairs (geometry blob, hierarchical binning)
   uint32_t hier;         // binning blob: 1 = the point list came from the hierarchical path (no
                          // sorted tile keys; tile_start[] instead)
-  uint32_t reserved[54];
+  uint32_t R_pre, Rc_pre;   // geometry blob: the counts as summed right behind preprocess
+  uint32_t reserved[52];
 };
 static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 
@@ -121,6 +122,7 @@ struct GeomLayout {
   size_t rec, key_a, key_b, val_a, val_b, tiles, rects, rect_sorted, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
   size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
+  size_t pre_counts;     // uint2[ceil(P/256)]: per-workgroup (instances, coarse pairs) of preprocess
   size_t zero_begin, zero_end;   // region frame_init clears: ds_table
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
@@ -167,6 +169,7 @@ inline GeomLayout geom_layout(size_t P) {
   L.emit_win_cap = (uint32_t)(P / 8 + 1024);
   L.emit_win = take(((size_t)L.emit_win_cap + 2) * 4);
   L.seg_table = take((size_t)MAX_SEGMENTS * sizeof(SegmentDev));
+  L.pre_counts = take(((P + 255) / 256 + 1) * 8);
   L.total = o;
   return L;
 }
@@ -237,12 +240,16 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles,
                        uint2* rects /* packed tile rectangles (hierarchical binning), or NULL */,
-                       uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */);
+                       uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */,
+                       uint2* pre_counts /* [ceil(P/256)] per-workgroup (instances, coarse pairs), or NULL */);
+// sums pre_counts -> pinned host words [0] num_rendered, [1] coarse pairs (+ two header words)
+void launch_publish_counts(hipStream_t s, const uint2* pre_counts, uint32_t nblocks,
+                           uint32_t* host_word, uint32_t* header_words);
 // Composed variants (preprocess.hip): raw per-model parameters + actor poses instead of flat tensors.
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
                                 uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                                uint32_t* ds_table0);
+                                uint32_t* ds_table0, uint2* pre_counts);
 void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
                     float* scales, float* rotations, float* opacities, float* shs);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,

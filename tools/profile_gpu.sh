@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 STEPS=${STEPS:-20}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- \
-    python $ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
+    python $ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-train --no-strong --no-delivery --no-secondary > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
 echo "stats rc=$?"
 i=0
 for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
@@ -20,7 +20,7 @@ for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/prof_pmc$i -o pmc -- \
-      python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stage-timing --no-train --no-strong --no-delivery > /dev/null 2> $OUT/prof_pmc$i.err
+      python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stage-timing --no-train --no-strong --no-delivery --no-secondary > /dev/null 2> $OUT/prof_pmc$i.err
   echo "pmc$i rc=$?"
 done
 # config 5 (train forward + backward): kernel stats + HBM counters of the backward kernels

@@ -45,7 +45,8 @@ lines += ["", "# PMC (separate rocprofv3 --pmc passes, mean per dispatch).",
 for k in sorted(agg):
     if not any(x in k for x in ("render_forward", "preprocess_kernel", "radix_scatter", "emit_kernel",
                                 "radix_hist", "scan_down", "scan_reduce", "tile_ranges", "depth_scatter",
-                                "depth_hist", "frame_init", "pack_u8", "hb_", "radix_digit_scan")):
+                                "depth_hist", "frame_init", "pack_u8", "hb_", "radix_digit_scan",
+                                "publish_counts", "depth_")):
         continue
     lines.append("== %s" % k)
     for c, v in sorted(agg[k].items()):
@@ -65,6 +66,13 @@ for k in agg:
         # launches); the render kernel is additionally listed under its bare name for bench.py
         entry = {"fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_corrected": 2.0 * f + w,
                  "launches_sampled": len(agg[k]["FETCH_SIZE"])}
+        # instruction counters of the same kernel (other PMC passes), mean per dispatch: bench.py's
+        # roofline_valu reads SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU (quad-cycles) of the render kernel
+        for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES",
+                  "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+            if c in agg[k]:
+                entry[c] = sum(agg[k][c]) / len(agg[k][c])
+        entry["duration_ns_under_pmc"] = sum(agg[k]["duration_ns"]) / len(agg[k]["duration_ns"])
         traffic[k] = entry
         # bare name = the variant the bench loop runs (the one with the most sampled launches)
         if k.startswith("render_forward_kernel") and (
