@@ -32,8 +32,10 @@ HIP_UNITS = {
     "binning.hip": [],
     "hier_binning.hip": [],
     "render_fwd.hip": [],
-    # hardware global_atomic_add_f32 instead of a CAS loop
-    "render_bwd.hip": ["-munsafe-fp-atomics"],
+    # hardware global_atomic_add_f32 instead of a CAS loop; no SLP packing of the scalar gradient
+    # arithmetic: a v_pk_fma_f32 occupies the gfx950 VALU 1.8x as long as a v_fma_f32
+    # (tools/ubench/valu_rate.hip), so pairs only add moves
+    "render_bwd.hip": ["-munsafe-fp-atomics", "-fno-slp-vectorize"],
     # bit-identical to oracle/knn_oracle.py: one rounding per operation
     "knn.hip": ["-ffp-contract=off"],
     # hardware float atomics for the cube-map gradient

@@ -371,7 +371,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
   const size_t N = (size_t)width * height;
 
-  const GeomLayout GL = geom_layout((size_t)P);
+  // an evaluation frame (no backward can follow) carves the blob without the gradient records
+  const GeomLayout GL = geom_layout((size_t)P, (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
   const ImgLayout IL = img_layout(T, N);
   char* geom = geometry_alloc(GL.total, geometry_user);
   char* img = image_alloc(IL.total, image_user);
@@ -932,16 +933,20 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
   const uint32_t* n_contrib = (const uint32_t*)(image_buffer + IL.n_contrib);
 
+  // per-Gaussian gradient records (one 64-byte line each) in the tail of the geometry blob: cleared,
+  // accumulated by the blend backward, fanned out into the caller's arrays by the preprocess backward
+  float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
+  HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
   launch_render_backward(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
                          cam.gy, background, alphas, n_contrib,
                          (const uint32_t*)(image_buffer + IL.work), dL_dpix, dL_dpix_depth, dL_dalphas,
-                         dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                         dL_ddepth, dL_dsemantic);
+                         dL_dpix_semantic, grad_rec, dL_dsemantic);
   STAGE_CHECK("render backward");
   launch_preprocess_backward(stream, P, D, M, means3D, radii_int, colors_precomp ? nullptr : shs,
                              rec, cov3D_precomp ? nullptr : scales, rotations, scale_modifier,
-                             cov3D_precomp, cam, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor,
-                             dL_ddepth, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                             cov3D_precomp, cam, grad_rec, dL_dmean2D, dL_dconic, dL_dopacity,
+                             dL_dmean3D, dL_dcolor, dL_ddepth, dL_dcov3D,
+                             colors_precomp ? nullptr : dL_dsh, dL_dscale, dL_drot);
   STAGE_CHECK("preprocess backward");
   return GRPG_OK;
 }

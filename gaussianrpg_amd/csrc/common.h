@@ -50,6 +50,13 @@ struct RecView {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Gradient record of the blend backward: ONE 64-byte line per Gaussian, so that the 11-lane float
+// atomic of render_bwd.hip is a single memory transaction (five separate arrays: five).  Float index:
+//   0-2 dL_dmean2D (x, y, |x|+|y|)   3-5 dL_dconic (xx, xy, yy)   6-8 dL_dcolor   9 dL_dopacity
+//   10 dL_ddepth   11-15 unused
+// preprocess_bwd.hip reads the record and writes the reference's separate output arrays.
+constexpr int GRAD_STRIDE = 16;
+
 constexpr uint32_t GEOM_MAGIC = 0x47504730u;  // "GPG0"
 constexpr uint32_t BIN_MAGIC = 0x47504231u;
 constexpr uint32_t IMG_MAGIC = 0x47504932u;
@@ -123,6 +130,7 @@ struct GeomLayout {
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
   size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
   size_t pre_counts;     // uint2[ceil(P/256)]: per-workgroup (instances, coarse pairs) of preprocess
+  size_t grad_rec;       // float[P][16]: per-Gaussian gradient accumulators of the backward (train forwards only)
   size_t zero_begin, zero_end;   // region frame_init clears: ds_table
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
@@ -140,7 +148,9 @@ struct ImgLayout {
   size_t ranges, n_contrib, work;
 };
 
-inline GeomLayout geom_layout(size_t P) {
+// with_grad: room for the backward's 64-byte gradient record per Gaussian (GRAD_* below) behind
+// everything else -- an evaluation forward (GRPG_FORWARD_NO_BACKWARD) carves the blob without it
+inline GeomLayout geom_layout(size_t P, bool with_grad = true) {
   GeomLayout L{};
   size_t o = sizeof(BlobHeader);
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -170,6 +180,8 @@ inline GeomLayout geom_layout(size_t P) {
   L.emit_win = take(((size_t)L.emit_win_cap + 2) * 4);
   L.seg_table = take((size_t)MAX_SEGMENTS * sizeof(SegmentDev));
   L.pre_counts = take(((P + 255) / 256 + 1) * 8);
+  L.grad_rec = o;
+  if (with_grad) (void)take(P * GRAD_STRIDE * 4);
   L.total = o;
   return L;
 }
@@ -338,15 +350,15 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             int gy, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
-                            const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dconic,
-                            float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                            const float* dL_dpix_semantic, float* grad_rec /* [P][GRAD_STRIDE], zeroed */,
                             float* dL_dsemantic);
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,
                                 const int* radii, const float* shs, const RecView rec,
                                 const float* scales, const float* rotations, float scale_modifier,
                                 const float* cov3D_precomp, const CameraArgs& cam,
-                                const float* dL_dmean2D, const float* dL_dconic,
-                                float* dL_dmean3D, const float* dL_dcolor, const float* dL_ddepth,
+                                const float* grad_rec /* [P][GRAD_STRIDE] from the blend backward */,
+                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                float* dL_dmean3D, float* dL_dcolor, float* dL_ddepth,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
 
 void launch_frame_init(hipStream_t s, char* geom, char* bin /* may be NULL */, char* img, uint32_t P,

@@ -18,8 +18,9 @@
 //
 // Sigma and A are RECOMPUTED with the forward's own functions (gaussian_math.h, same
 // -ffp-contract=off arithmetic), so nothing but the 48-byte record survives from the forward;
-// the SH clamp mask comes from the record (r[2].w).  HBM-bound streaming kernel: reads (71+12M) B and
-// writes up to (64+12M) B per Gaussian.
+// the SH clamp mask comes from the record (r[2].w).  The blend backward's sums arrive as one 64-byte
+// record per Gaussian; this kernel writes ALL of the op's per-Gaussian gradient arrays, for every
+// Gaussian (zeros for culled ones), so none of them needs a zero-fill.  HBM-bound streaming kernel.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -127,13 +128,45 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                            const float* __restrict__ proj, const float* __restrict__ campos,
                            const float h_x, const float h_y, const float tan_fovx,
-                           const float tan_fovy, const float* __restrict__ dL_dmean2D,
-                           const float* __restrict__ dL_dconics, float* __restrict__ dL_dmeans,
-                           const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                           const float tan_fovy, const float4* __restrict__ grad_rec,
+                           float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconics,
+                           float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans,
+                           float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
                            float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= P || !(radii[idx] > 0)) return;
+  if (idx >= P) return;
+  // Every output array is written for EVERY Gaussian (zeros for a culled one): nothing has to
+  // arrive zero-filled (the reference zero-fills eleven arrays per call, rasterize_points.cu:166-176).
+  if (!(radii[idx] > 0)) {
+    dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
+    reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dL_dopacity[idx] = 0.f;
+    dL_dcolor[3 * idx] = 0.f; dL_dcolor[3 * idx + 1] = 0.f; dL_dcolor[3 * idx + 2] = 0.f;
+    dL_ddepth[idx] = 0.f;
+    dL_dmeans[3 * idx] = 0.f; dL_dmeans[3 * idx + 1] = 0.f; dL_dmeans[3 * idx + 2] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = 0.f;
+    if (dL_dsh != nullptr)
+      for (int e = 0; e < 3 * M; e++) dL_dsh[(size_t)idx * M * 3 + e] = 0.f;
+    if (dL_dscale != nullptr) { dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
+    if (dL_drot != nullptr) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  // the blend backward's per-Gaussian sums: one 64-byte record (common.h GRAD_*), fanned out into the
+  // reference's separate arrays here (dL_dmean2D and dL_dopacity are outputs of the op, the conic /
+  // colour / depth gradients its intermediate results, rasterize_points.cu:166-219)
+  const float4 gr0 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx], gr1 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx + 1],
+               gr2 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx + 2];
+  const float g2x = gr0.x, g2y = gr0.y;
+  const float gxx = gr0.w, gxy = gr1.x, gyy = gr1.y;
+  const float gcr = gr1.z, gcg = gr1.w, gcb = gr2.x;
+  const float gdep = gr2.z;
+  dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = gr0.z;
+  reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(gxx, gxy, 0.f, gyy);
+  dL_dopacity[idx] = gr2.y;
+  dL_dcolor[3 * idx] = gcr; dL_dcolor[3 * idx + 1] = gcg; dL_dcolor[3 * idx + 2] = gcb;
+  dL_ddepth[idx] = gdep;
   const Vec3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
   float c3[6];
   float4 q = make_float4(0, 0, 0, 0);
@@ -151,7 +184,6 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   // ---- conic -> screen covariance S (with the +0.3 dilation):  dL/dS = -K G K, K = adj(S) / det ----
   // the render backward stores HALF of the off-diagonal conic derivative (backward.cu:619-621),
   // so G carries that stored value in both off-diagonal entries
-  const float gxx = dL_dconics[4 * idx], gxy = dL_dconics[4 * idx + 1], gyy = dL_dconics[4 * idx + 3];
   const float a = cv.a + 0.3f, b = cv.b, c = cv.c + 0.3f;
   const float det = a * c - b * b;
   const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
@@ -206,7 +238,6 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
     const float iw = 1.0f / (w + 0.0000001f);
     const float px_w2 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * iw * iw;
     const float py_w2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * iw * iw;
-    const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const float add = (proj[4 * j] * iw - proj[4 * j + 3] * px_w2) * g2x +
@@ -217,15 +248,13 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   // ---- depth = (view m)_z, with view row 3 treated as a divisor of weight depth (backward.cu:384-391) ----
   {
     const float depth = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
-    const float gdep = dL_ddepth[idx];
     gm.x += (view[2] - view[3] * depth) * gdep;
     gm.y += (view[6] - view[7] * depth) * gdep;
     gm.z += (view[10] - view[11] * depth) * gdep;
   }
   if (shs != nullptr) {
     const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
-    const float gr = dL_dcolor[3 * idx], gg = dL_dcolor[3 * idx + 1], gb = dL_dcolor[3 * idx + 2];
-    const Vec3 g = {(clamped & 1u) ? 0.f : gr, (clamped & 2u) ? 0.f : gg, (clamped & 4u) ? 0.f : gb};
+    const Vec3 g = {(clamped & 1u) ? 0.f : gcr, (clamped & 2u) ? 0.f : gcg, (clamped & 4u) ? 0.f : gcb};
     const Vec3 gs = sh_backward(D, shs + (size_t)idx * M * 3,
                                 Vec3{m.x - campos[0], m.y - campos[1], m.z - campos[2]}, g,
                                 dL_dsh + (size_t)idx * M * 3);
@@ -234,7 +263,10 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   dL_dmeans[3 * idx] = gm.x;
   dL_dmeans[3 * idx + 1] = gm.y;
   dL_dmeans[3 * idx + 2] = gm.z;
-  if (scales != nullptr) {
+  if (scales == nullptr) {   // cov3D_precomp: the binding still returns (zero) scale / rotation gradients
+    if (dL_dscale != nullptr) { dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
+    if (dL_drot != nullptr) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
     float ds[3], dr[4];
     cov3d_backward(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q,
                    dcov, ds, dr);
@@ -247,14 +279,16 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 const int* radii, const float* shs, const RecView rec,
                                 const float* scales, const float* rotations, float scale_modifier,
                                 const float* cov3D_precomp, const CameraArgs& cam,
-                                const float* dL_dmean2D, const float* dL_dconic,
-                                float* dL_dmean3D, const float* dL_dcolor, const float* dL_ddepth,
-                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
+                                const float* grad_rec, float* dL_dmean2D, float* dL_dconic,
+                                float* dL_dopacity, float* dL_dmean3D, float* dL_dcolor,
+                                float* dL_ddepth, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                float* dL_drot) {
   if (P <= 0) return;
   preprocess_backward_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, radii, shs, rec, scales, rotations, scale_modifier, cov3D_precomp, cam.view,
-      cam.proj, cam.campos, cam.focal_x, cam.focal_y, cam.tan_fovx, cam.tan_fovy, dL_dmean2D,
-      dL_dconic, dL_dmean3D, dL_dcolor, dL_ddepth, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+      cam.proj, cam.campos, cam.focal_x, cam.focal_y, cam.tan_fovx, cam.tan_fovy,
+      reinterpret_cast<const float4*>(grad_rec), dL_dmean2D, dL_dconic, dL_dopacity, dL_dmean3D,
+      dL_dcolor, dL_ddepth, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
 }
 
 }  // namespace grpg

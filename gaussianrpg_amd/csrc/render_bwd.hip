@@ -25,6 +25,7 @@
 //     the Gaussian: 64-256x fewer atomic operations than the reference.  Summation order differs
 //     from the reference's (unspecified) atomic order, so gradients agree to rounding, not
 //     bitwise -- exactly as two runs of the reference differ from each other.
+#include <cstdio>
 #include <cstdlib>
 
 #include "blend_math.h"
@@ -93,6 +94,48 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_take(const float v) {   // v of the lane CTRL selects (all lanes valid)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// lanes whose bank (group of 4 lanes within a 16-lane row) is in BANKS take `src`, the others keep `old`
+template <int BANKS>
+__device__ __forceinline__ float bank_merge(const float old, const float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src),
+                                                    0xE4 /* quad_perm [0,1,2,3] */, 0xF, BANKS, false));
+}
+
+// Wave totals of 12 quantities by a FOLDING tree: every level halves the number of lanes a
+// quantity's partial sums occupy AND the number of registers, so the deeper levels are shared:
+//   64 -> 32 lanes, 12 -> 6 registers   v_permlane32_swap + add                       (12 instructions)
+//   32 -> 16 lanes,  6 -> 3 registers   v_permlane16_swap + add                       ( 6)
+//   quad level,      3 -> 1 register    two select-pairs + quad_perm adds: lane j of every quad ends
+//                                       up with its quad's sum of quantity j           ( 7)
+//   4 quads -> 1                        row_ror:8 and row_ror:4 adds                  ( 2)
+// 27 VALU instructions (three full row sums before: 37).  Row r (lanes 16 r ...) holds the totals of
+// v[3r], v[3r+1], v[3r+2] in lanes 0, 1, 2 of each of its quads: adjacent lanes, so the 11-lane
+// atomic that follows is one request per row (totals parked in lanes 0 / 4 / 8 cost 3.5x the
+// atomic time: every quad of lanes became a request of its own).
+__device__ __forceinline__ float wave_fold_12(const float (&v)[12], const bool lane_odd, const bool lane_hi2) {
+  float h[6], g[3];
+#pragma unroll
+  for (int k = 0; k < 6; k++) h[k] = halve32(v[k], v[k + 6]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) g[k] = halve16(h[k], h[k + 3]);
+  // lanes 0,2 of a quad: g0 pair sums; lanes 1,3: g1 pair sums
+  const float keep01 = lane_odd ? g[1] : g[0], give01 = lane_odd ? g[0] : g[1];
+  const float e01 = keep01 + dpp_take<0xB1>(give01);          // quad_perm [1,0,3,2]
+  const float e2 = g[2] + dpp_take<0xB1>(g[2]);               // g2 pair sums in every lane
+  // lanes 0,1: quad totals of g0, g1; lanes 2,3: quad total of g2
+  const float keep = lane_hi2 ? e2 : e01, give = lane_hi2 ? e01 : e2;
+  float t = keep + dpp_take<0x4E>(give);                       // quad_perm [2,3,0,1]
+  t += dpp_take<0x128>(t);                                     // row_ror:8  (quads q and q^2)
+  t += dpp_take<0x124>(t);                                     // row_ror:4  (all four quads)
+  return t;
+}
+
+constexpr int BREC = 4;   // float4 per compacted survivor in LDS: record (3) + pre-scaled conic
+
 // One wave, PX pixels per lane: rows y0 + (lane>>4)*PX + k.  bits_mask selects the sub-tile bits
 // of a point-list entry that concern this wave (one bit for a quarter, all four for a whole tile).
 template <int PX, int SMAX>
@@ -105,9 +148,8 @@ __device__ __forceinline__ void backward_rect(
     const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
     const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpix_semantic,
-    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
-    float* __restrict__ dL_dsemantic, const int ablate) {
+    float* __restrict__ grad_rec, float* __restrict__ dL_dsemantic, const int ablate,
+    unsigned long long* __restrict__ stats) {
   constexpr int SM = SMAX > 0 ? SMAX : 1;
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
@@ -123,12 +165,14 @@ __device__ __forceinline__ void backward_rect(
   // Per-pixel state.  The reference carries (last_alpha, last_color) and forms
   //   accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec        (backward.cu:556-561)
   // at the NEXT contributor; the same value is obtained by blending the current contributor into
-  // the accumulator right after it has been used (acc = alpha c + (1 - alpha) acc), which needs no
-  // copy of the previous splat's colour per pixel.  Channels are kept in pairs (r,g) / (b,depth)
-  // so that the updates are v_pk_* instructions.
-  float T[PX], T_final[PX], dLa[PX], bgdot[PX], acc_a[PX];
-  v2f dL_rg[PX], dL_bd[PX], acc_rg[PX], acc_bd[PX];
+  // the accumulator right after it has been used, acc += alpha (c - acc), which needs no copy of
+  // the previous splat's colour per pixel and reuses the difference (c - acc) that dL/dalpha needs
+  // anyway.  Plain (unpacked) fp32 throughout: on gfx950 a v_pk_fma_f32 occupies the VALU 1.8x as
+  // long as a v_fma_f32 (tools/ubench/valu_rate.hip), so packing buys nothing and costs moves.
+  float T[PX], nTfBg[PX], dLa[PX], acc_a[PX];
+  float dLc[PX][4], acc[PX][4];          // channels: r, g, b, depth
   float dLs[PX][SM], acc_s[PX][SM];
+  float pyf[PX];
   uint32_t lastc[PX];
   uint32_t maxlast = 0;
 #pragma unroll
@@ -136,19 +180,19 @@ __device__ __forceinline__ void backward_rect(
     const int py = py0 + k;
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)py * W + px : 0;
-    T_final[k] = inside ? 1.0f - alphas[pix] : 0.f;
-    T[k] = T_final[k];
+    const float T_final = inside ? 1.0f - alphas[pix] : 0.f;
+    T[k] = T_final;
     lastc[k] = inside ? n_contrib[pix] : 0u;
-    const float dLr = inside ? dL_dpix[pix] : 0.f;
-    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
-    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float dLd = inside ? dL_dpix_depth[pix] : 0.f;
-    dL_rg[k] = (v2f){dLr, dLg};
-    dL_bd[k] = (v2f){dLb, dLd};
+    dLc[k][0] = inside ? dL_dpix[pix] : 0.f;
+    dLc[k][1] = inside ? dL_dpix[HW + pix] : 0.f;
+    dLc[k][2] = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    dLc[k][3] = inside ? dL_dpix_depth[pix] : 0.f;
     dLa[k] = inside ? dL_dalphas[pix] : 0.f;
-    bgdot[k] = bg0 * dLr + bg1 * dLg + bg2 * dLb;
-    acc_rg[k] = (v2f){0.f, 0.f};
-    acc_bd[k] = (v2f){0.f, 0.f};
+    // background term of backward.cu:611-614: (-T_final / (1 - alpha)) * (bg . dL_dpixel)
+    nTfBg[k] = -T_final * (bg0 * dLc[k][0] + bg1 * dLc[k][1] + bg2 * dLc[k][2]);
+    pyf[k] = (float)py;
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[k][c] = 0.f;
     acc_a[k] = 0.f;
 #pragma unroll
     for (int c = 0; c < SM; c++) {
@@ -158,22 +202,23 @@ __device__ __forceinline__ void backward_rect(
     maxlast = max(maxlast, lastc[k]);
   }
   maxlast = wave_max_u32(maxlast);   // nothing behind the tile's deepest contributor matters
-  const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:501-502
+  const float nddelx = -(float)(0.5 * W), nddely = -(float)(0.5 * H);   // -ddelx_dx, -ddely_dy (backward.cu:501-502)
 
-  // Gradient scatter: after wave_sum_12 row r of the wave holds the totals of quantities 3r..3r+2
+  // Gradient scatter: wave_fold_12 leaves the total of quantity 3 r + {0, 1, 2} in lanes 0 / 1 / 2 of
+  // row r (lanes 16 r ...):
   //   row 0: dL_dmean2D x, y, |.|   row 1: dL_dconic xx, xy, yy   row 2: dL_dcolor r, g, b
   //   row 3: dL_dopacity, dL_ddepth, -
-  // Lane 16 r + k takes quantity 3 r + k, so ONE global_atomic_add_f32 with 11 active lanes covers a
-  // Gaussian: 5 cache lines per (wave, Gaussian) instead of 11 single-lane atomics.
+  // i.e. float 3 r + k of the Gaussian's 64-byte gradient record (common.h GRAD_*): ONE
+  // global_atomic_add_f32 with 11 active lanes and ONE memory line per (wave, Gaussian) -- the
+  // reference issues 11 atomics per PIXEL and Gaussian; five separate arrays cost five lines per
+  // atomic, and on this part every line is a transaction of its own at the memory side (the XCDs'
+  // L2s are not coherent): 0.28 of 0.96 ms before the record.  The conic moments are accumulated
+  // without their -1/2 (backward.cu:634-636); the issuing lanes apply it to the wave total.
   const int row = lane >> 4, sub = lane & 15;
-  float* sc_ptr = nullptr;
-  uint32_t sc_stride = 0;
-  if (sub < 3) {
-    if (row == 0) { sc_ptr = dL_dmean2D + sub; sc_stride = 3; }
-    else if (row == 1) { sc_ptr = dL_dconic + (sub == 2 ? 3 : sub); sc_stride = 4; }
-    else if (row == 2) { sc_ptr = dL_dcolor + sub; sc_stride = 3; }
-    else if (sub < 2) { sc_ptr = sub == 0 ? dL_dopacity : dL_ddepth; sc_stride = 1; }
-  }
+  const bool lane_odd = (lane & 1) != 0, lane_hi2 = (lane & 2) != 0;
+  const bool sc_lane = sub < 3 && (3 * row + sub) < 11;
+  float* const sc_ptr = grad_rec + (3 * row + sub);
+  const float sc_scale = row == 1 ? -0.5f : 1.0f;
 
   // Back-to-front traversal of list positions [0, count), decoupled like the forward's heavy path
   // (render_fwd.hip): FILL scans 256 entries per step (prefetched one window ahead) and appends
@@ -191,6 +236,8 @@ __device__ __forceinline__ void backward_rect(
     const uint32_t off = (uint32_t)(q * WAVE + lane);
     win[q] = off < in_hi ? point_list[r_begin + in_hi - 1 - off] : 0u;
   }
+  uint32_t st_fill = 0, st_batches = 0, st_iters = 0, st_used = 0, st_rows = 0;   // GRPG_BWD_STATS
+  const unsigned long long st_t0 = stats ? __builtin_readcyclecounter() : 0ull;
   float4 la = make_float4(0, 0, 0, 0), lb = la, lc = la;   // current batch (records arrived)
   uint32_t lpos = 0, lid = 0, ncur = 0;
   for (;;) {
@@ -218,6 +265,7 @@ __device__ __forceinline__ void backward_rect(
         rcount += (uint32_t)__popcll(m);
       }
       in_hi = nxt;
+      st_fill++;
     }
     // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
     // reordering the LDS accesses across this point (costs no instruction)
@@ -274,92 +322,101 @@ __device__ __forceinline__ void backward_rect(
       cnt = (int)__popcll(mask);
       if (keep) {
         const int slot = (int)__popcll(mask & lt);
-        my[slot * REC_F4 + 0] = la;
-        my[slot * REC_F4 + 1] = lb;
-        my[slot * REC_F4 + 2] = make_float4(lc.x, lc.y, __uint_as_float(lpos), __uint_as_float(lid));
+        const SplatQ sq = splat_q(lb.x, lb.y, lb.z);   // once per survivor, not once per (wave, survivor)
+        my[slot * BREC + 0] = la;
+        my[slot * BREC + 1] = lb;
+        my[slot * BREC + 2] = make_float4(lc.x, lc.y, __uint_as_float(lpos), __uint_as_float(lid));
+        my[slot * BREC + 3] = make_float4(sq.A, sq.B, sq.C, 0.f);
       }
     }
     __builtin_amdgcn_wave_barrier();
+    st_batches += ncur > 0 ? 1u : 0u;
+    st_iters += (uint32_t)cnt;
     for (int j = 0; j < cnt; j++) {
-      const float4 a = my[j * REC_F4 + 0];   // px, py, depth, opacity
-      const float4 b = my[j * REC_F4 + 1];   // conic.x, conic.y, conic.z, R
-      const float4 c = my[j * REC_F4 + 2];   // G, B, list position, Gaussian id
+      const float4 a = my[j * BREC + 0];   // px, py, depth, opacity
+      const float4 b = my[j * BREC + 1];   // conic.x, conic.y, conic.z, R
+      const float4 c = my[j * BREC + 2];   // G, B, list position, Gaussian id
+      const float4 q = my[j * BREC + 3];   // pre-scaled conic A, B, C (blend_math.h)
       const uint32_t pos = __float_as_uint(c.z);   // 0-based == the reference's `contributor`
       const uint32_t gid = __float_as_uint(c.w);
       const float dx = a.x - pxf;
-      const SplatTerms st = splat_terms(dx, b.x, b.y, b.z);
-      // packed accumulators: (mean2D x, y), (conic xx, yy), (colour r, g), (colour b, depth)
-      v2f g_mxy = {0.f, 0.f}, g_cxw = {0.f, 0.f}, g_rg = {0.f, 0.f}, g_bd = {0.f, 0.f};
-      float g_mabs = 0.f, g_cy = 0.f, g_op = 0.f;
+      SplatTerms st;                       // == splat_terms(dx, conic): same operations, same bits
+      st.hA = (q.x * dx) * dx;
+      st.bdx = q.y * dx;
+      st.hc = q.z;
+      const float col[4] = {b.w, c.x, c.y, a.z};
+      // per-lane partial sums of the 11 gradient quantities of this splat over the lane's pixels
+      float g_mx = 0.f, g_my = 0.f, g_mabs = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_op = 0.f;
+      float g_c[4] = {0.f, 0.f, 0.f, 0.f};
       float g_s[SM];
 #pragma unroll
       for (int cc = 0; cc < SM; cc++) g_s[cc] = 0.f;
-      const v2f col_rg = {b.w, c.x}, col_bd = {c.y, a.z};
-      const v2f con_xz = {b.x, b.z}, ncy2 = {-b.y, -b.y};
-      const v2f ddel = {ddelx_dx, ddely_dy};
       bool any = false;
 #pragma unroll
       for (int k = 0; k < PX; k++) {
-        const float dy = a.y - (float)(py0 + k);
+        const float dy = a.y - pyf[k];
         float G, alpha;   // identical arithmetic to the forward (blend_math.h)
         const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]) &&
                            !(ablate & 4);
-        if (valid) {
-          any = true;
-          // one reciprocal serves both divisions of backward.cu:547,596 (1 ulp: the recovered T is
-          // the inverse of a rounded product chain anyway)
-          const float om = 1.f - alpha;
-          const float inv_1ma = __builtin_amdgcn_rcpf(om);
-          T[k] = T[k] * inv_1ma;
-          const float dch = alpha * T[k];
-          const v2f dch2 = {dch, dch}, al2 = {alpha, alpha}, om2 = {om, om};
-          // dL/dalpha through the colours behind this splat (acc = what lies behind, blended)
-          const v2f d1 = (col_rg - acc_rg[k]) * dL_rg[k];
-          const v2f d2 = (col_bd - acc_bd[k]) * dL_bd[k];
-          const v2f ds = d1 + d2;
-          float dL_dopa = ds.x + ds.y;
-          g_rg = __builtin_elementwise_fma(dch2, dL_rg[k], g_rg);
-          g_bd = __builtin_elementwise_fma(dch2, dL_bd[k], g_bd);
-          acc_rg[k] = __builtin_elementwise_fma(al2, col_rg, om2 * acc_rg[k]);
-          acc_bd[k] = __builtin_elementwise_fma(al2, col_bd, om2 * acc_bd[k]);
-          if (SMAX > 0) {
+        if (__ballot(valid) == 0ull) continue;   // wave-uniform: no pixel of this row takes the splat
+        any = true;
+        st_rows++;
+        // Branch-free below: a lane that rejects the splat runs the same arithmetic with
+        // alpha = G = 0, which leaves its T and accumulators unchanged (T / (1 - 0), acc + 0 * d)
+        // and contributes exact zeros to every sum.
+        alpha = valid ? alpha : 0.f;
+        G = valid ? G : 0.f;
+        // one reciprocal serves both divisions of backward.cu:547,596 (1 ulp: the recovered T is
+        // the inverse of a rounded product chain anyway)
+        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+        T[k] = T[k] * inv_1ma;
+        const float dch = alpha * T[k];
+        // dL/dalpha through what lies behind this splat: sum_c (c - acc_c) dL_c  (backward.cu:556-602)
+        float dL_dopa = 0.f;
 #pragma unroll
-            for (int cc = 0; cc < SM; cc++) {
-              if (cc < S) {
-                const float sv = semantics[(size_t)gid * S + cc];
-                dL_dopa += (sv - acc_s[k][cc]) * dLs[k][cc];
-                g_s[cc] += dch * dLs[k][cc];
-                acc_s[k][cc] = alpha * sv + om * acc_s[k][cc];
-              }
+        for (int ch = 0; ch < 4; ch++) {
+          const float d = col[ch] - acc[k][ch];
+          dL_dopa = fmaf(d, dLc[k][ch], dL_dopa);
+          g_c[ch] = fmaf(dch, dLc[k][ch], g_c[ch]);
+          acc[k][ch] = fmaf(alpha, d, acc[k][ch]);      // alpha c + (1 - alpha) acc
+        }
+        if (SMAX > 0) {
+#pragma unroll
+          for (int cc = 0; cc < SM; cc++) {
+            if (cc < S) {
+              const float d = semantics[(size_t)gid * S + cc] - acc_s[k][cc];
+              dL_dopa = fmaf(d, dLs[k][cc], dL_dopa);
+              g_s[cc] = fmaf(dch, dLs[k][cc], g_s[cc]);
+              acc_s[k][cc] = fmaf(alpha, d, acc_s[k][cc]);
             }
           }
-          dL_dopa += (1.f - acc_a[k]) * dLa[k];
-          acc_a[k] = alpha + om * acc_a[k];
-          dL_dopa *= T[k];
-          dL_dopa += (-T_final[k] * inv_1ma) * bgdot[k];
-          const float dL_dG = a.w * dL_dopa;
-          const v2f d2v = {dx, dy};
-          const v2f gd = (v2f){G, G} * d2v;                                   // (G dx, G dy)
-          // dG/ddelx = -gdx cx - gdy cy ;  dG/ddely = -gdy cz - gdx cy
-          const v2f dG = __builtin_elementwise_fma((v2f){gd.y, gd.x}, ncy2, -(gd * con_xz));
-          const v2f mxy = ((v2f){dL_dG, dL_dG} * dG) * ddel;
-          g_mxy += mxy;
-          g_mabs += fabsf(mxy.x) + fabsf(mxy.y);
-          const float h = -0.5f * dL_dG;
-          g_cxw = __builtin_elementwise_fma((v2f){h, h}, gd * d2v, g_cxw);    // (gdx dx, gdy dy)
-          g_cy = fmaf(h * gd.x, dy, g_cy);
-          g_op = fmaf(G, dL_dopa, g_op);
         }
+        const float da = 1.f - acc_a[k];
+        dL_dopa = fmaf(da, dLa[k], dL_dopa);
+        acc_a[k] = fmaf(alpha, da, acc_a[k]);           // alpha + (1 - alpha) acc_a
+        dL_dopa = fmaf(inv_1ma, nTfBg[k], dL_dopa * T[k]);
+        g_op = fmaf(G, dL_dopa, g_op);
+        const float dL_dG = a.w * dL_dopa;
+        // t = dL_dG G (dx, dy):  dL_dmean2D = -ddel (conic t),  dL_dconic = -1/2 t (dx, dy)^T
+        const float tdx = dL_dG * (G * dx), tdy = dL_dG * (G * dy);
+        const float mx = nddelx * fmaf(b.y, tdy, b.x * tdx);
+        const float my_ = nddely * fmaf(b.y, tdx, b.z * tdy);
+        g_mx += mx;
+        g_my += my_;
+        g_mabs += fabsf(mx);
+        g_mabs += fabsf(my_);
+        g_cxx = fmaf(tdx, dx, g_cxx);
+        g_cxy = fmaf(tdx, dy, g_cxy);
+        g_cyy = fmaf(tdy, dy, g_cyy);
       }
-      if (__ballot(any) == 0ull) continue;   // wave-uniform: nobody in the tile used this splat
+      if (!any) continue;         // wave-uniform: nobody in the tile used this splat
+      st_used++;
       if (ablate & 2) continue;   // experiment switch (GRPG_BWD_ABLATE): no reduction, no atomics
       {
-        const float q[12] = {g_mxy.x, g_mxy.y, g_mabs, g_cxw.x, g_cy, g_cxw.y, g_rg.x, g_rg.y, g_bd.x, g_op,
-                             g_bd.y, 0.f};
-        float tot[3];
-        wave_sum_12(q, tot);
-        if (sc_ptr && !(ablate & 1))
-          atomicAdd(sc_ptr + (size_t)gid * sc_stride, sub == 0 ? tot[0] : (sub == 1 ? tot[1] : tot[2]));
+        const float qv[12] = {g_mx, g_my, g_mabs, g_cxx, g_cxy, g_cyy, g_c[0], g_c[1], g_c[2], g_op,
+                              g_c[3], 0.f};
+        const float tot = wave_fold_12(qv, lane_odd, lane_hi2);
+        if (sc_lane && !(ablate & 1)) atomicAdd(sc_ptr + gid * (uint32_t)GRAD_STRIDE, tot * sc_scale);
       }
       if (SMAX > 0) {
 #pragma unroll
@@ -374,6 +431,21 @@ __device__ __forceinline__ void backward_rect(
     __builtin_amdgcn_wave_barrier();
     la = na; lb = nb; lc = nc; lpos = npos; lid = nid; ncur = nn;
     if (ncur == 0 && in_hi == 0) break;   // ring empty (rcount == 0 here) and list exhausted
+  }
+  if (stats != nullptr && lane == 0) {   // experiment counters (GRPG_BWD_STATS=1), off in production
+    atomicAdd(&stats[0], 1ull);                            // waves
+    atomicAdd(&stats[1], (unsigned long long)count);       // list entries in reach of the wave
+    atomicAdd(&stats[2], (unsigned long long)st_fill);     // FILL steps (256 entries each)
+    atomicAdd(&stats[3], (unsigned long long)st_batches);  // batches of <= 64 mask survivors
+    atomicAdd(&stats[4], (unsigned long long)st_iters);    // survivors of the rectangle cull = loop trips
+    atomicAdd(&stats[5], (unsigned long long)st_used);     // ... of which some pixel used (reduction + atomic)
+    atomicAdd(&stats[6], (unsigned long long)st_rows);     // gradient blocks executed (rows with a taker)
+    atomicAdd(&stats[7 + (PX == 1 ? 0 : 1)], (unsigned long long)st_iters);   // trips by wave kind
+    const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
+    atomicAdd(&stats[9], dt);                              // sum of wave lifetimes (cycles)
+    atomicMax(&stats[10], dt);                             // longest wave
+    atomicMax(&stats[11], (unsigned long long)st_iters);   // most loop trips in one wave
+    atomicMax(&stats[12], (unsigned long long)count);      // longest list in reach of one wave
   }
 }
 
@@ -392,11 +464,10 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                        const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                        const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
                        const float* __restrict__ dL_dalphas,
-                       const float* __restrict__ dL_dpix_semantic, float* __restrict__ dL_dmean2D,
-                       float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-                       float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth,
-                       float* __restrict__ dL_dsemantic, const int ablate, const int wide_classes) {
-  __shared__ float4 s_rec[RB_WAVES][WAVE * REC_F4];
+                       const float* __restrict__ dL_dpix_semantic, float* __restrict__ grad_rec,
+                       float* __restrict__ dL_dsemantic, const int ablate, const int wide_classes,
+                       unsigned long long* __restrict__ stats) {
+  __shared__ float4 s_rec[RB_WAVES][WAVE * BREC];
   __shared__ uint32_t s_qid[RB_WAVES][BQCAP];
   __shared__ uint32_t s_qpos[RB_WAVES][BQCAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -429,8 +500,8 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 #define RB_CALL(PXV, YOFF, BITS)                                                                  \
   backward_rect<PXV, SMAX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, rb, re, tx * TILE, ty * TILE + (YOFF), (BITS), W, H, \
                            S, point_list, rec, semantics, bg, alphas, n_contrib, dL_dpix,          \
-                           dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic,     \
-                           dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, ablate)
+                           dL_dpix_depth, dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic,     \
+                           ablate, stats)
   if (b < nheavy)
     RB_CALL(1, wave * 4, 1u << (SUBTILE_SHIFT + wave));
   else if (LIGHT_SPLIT == 2)
@@ -445,18 +516,24 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             int gy, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
-                            const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dconic,
-                            float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
-                            float* dL_dsemantic) {
+                            const float* dL_dpix_semantic, float* grad_rec, float* dL_dsemantic) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
   static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 0; }();
+  // GRPG_BWD_STATS=1: per-launch loop counters printed to stderr (synchronises: experiments only)
+  static const int want_stats = [] { const char* e = getenv("GRPG_BWD_STATS"); return e ? atoi(e) : 0; }();
+  static unsigned long long* stats_dev = nullptr;
+  unsigned long long* stats = nullptr;
+  if (want_stats) {
+    if (!stats_dev) (void)hipMalloc((void**)&stats_dev, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(stats_dev, 0, 16 * sizeof(unsigned long long), s);
+    stats = stats_dev;
+  }
 #define RB_ARGS                                                                                  \
   ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
-      dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity,  \
-      dL_dcolor, dL_ddepth, dL_dsemantic, ablate, wide
+      dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic, ablate, wide, stats
   // nheavy + ceil(LIGHT_SPLIT nlight / 4) <= ntiles for LIGHT_SPLIT <= 2 ... not for nheavy ~ ntiles/2:
   // launch nheavy_max + light workgroups = ntiles + ntiles/2 + 1, surplus workgroups exit at once.
   // Light tiles: one wave per tile, 4 pixels per lane (default).  GRPG_BWD_LIGHT=2 selects two
@@ -477,6 +554,16 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
     render_backward_kernel<32, 1><<<ntiles, 256, 0, s>>>(RB_ARGS);   // S <= 32 (reference: 20)
   }
 #undef RB_ARGS
+  if (stats) {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, stats_dev, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[bwd stats] waves %llu entries_in_reach %llu fill_steps %llu batches %llu loop_trips %llu "
+                    "used %llu grad_blocks %llu trips_quarter_waves %llu trips_light_waves %llu | wave cycles: sum %llu "
+                    "max %llu (mean %.0f); max trips/wave %llu; longest list in reach %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[0] ? (double)h[9] / h[0] : 0.0,
+            h[11], h[12]);
+  }
 }
 
 }  // namespace grpg

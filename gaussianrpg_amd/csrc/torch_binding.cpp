@@ -209,20 +209,22 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   if (sh.size(0) != 0) M = sh.size(1);
 
   auto o = means3D.options();
-  // The eleven gradient arrays of rasterize_points.cu:166-176 must arrive zero-filled (atomics and
-  // "+=" accumulate into them).  Two allocations and two zero-fill launches instead of eleven; the
-  // tensors are disjoint views (each starts on a 256-byte boundary).  Pool A holds the gradients a
-  // training step keeps as .grad (means3D, means2D, opacity, sh, scales, rotations, semantics),
-  // pool B the internal ones and those autograd normally drops (colors, depths, conic, cov3D), so a
-  // retained .grad does not pin the scratch arrays.
-  const int64_t widths[11] = {3, 3, GRPG_NUM_CHANNELS, 1, 4, 1, 6, (int64_t)M * 3, 3, 4, S};
+  // The reference zero-fills eleven gradient arrays per call (rasterize_points.cu:166-176) because
+  // its kernels accumulate into them.  Here the blend backward accumulates into per-Gaussian
+  // records inside the geometry blob and the preprocess backward WRITES every element of the ten
+  // non-semantic arrays (zeros for culled Gaussians), so they are carved uninitialised from two
+  // allocations; only dL_dsemantic (float atomics straight into it) is zero-filled.  Pool A holds
+  // the gradients a training step keeps as .grad (means3D, means2D, opacity, sh, scales,
+  // rotations), pool B the internal ones and those autograd normally drops (colors, depths, conic,
+  // cov3D), so a retained .grad does not pin the scratch arrays.
+  const int64_t widths[11] = {3, 3, GRPG_NUM_CHANNELS, 1, 4, 1, 6, (int64_t)M * 3, 3, 4, 0};
   const int pool_of[11] = {0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0};
   int64_t offs[11], size[2] = {0, 0};
   for (int i = 0; i < 11; i++) {
     offs[i] = size[pool_of[i]];
     size[pool_of[i]] += (((int64_t)P * widths[i] + 63) / 64) * 64;
   }
-  torch::Tensor pools[2] = {torch::zeros({size[0]}, o), torch::zeros({size[1]}, o)};
+  torch::Tensor pools[2] = {torch::empty({size[0]}, o), torch::empty({size[1]}, o)};
   auto view = [&](int i, std::vector<int64_t> shape) {
     return pools[pool_of[i]].narrow(0, offs[i], (int64_t)P * widths[i]).view(shape);
   };
@@ -236,7 +238,7 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   torch::Tensor dL_dsh = view(7, {P, M, 3});
   torch::Tensor dL_dscales = view(8, {P, 3});
   torch::Tensor dL_drotations = view(9, {P, 4});
-  torch::Tensor dL_dsemantic = view(10, {P, S});
+  torch::Tensor dL_dsemantic = torch::zeros({P, S}, o);
 
   if (P != 0) {
     torch::Tensor k[16];

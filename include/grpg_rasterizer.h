@@ -287,11 +287,18 @@ GRPG_API int grpg_set_binning_algorithm(int alg);
 
 /*
  * Rasterizer::backward  (rasterizer.h:60-96, rasterizer_impl.cu:396-505).
- * R is the value grpg_forward returned.  geom/binning/image buffers are the blobs it filled.
- * Gradient outputs must arrive ZERO-FILLED (as rasterize_points.cu:166-176 allocates them):
+ * R is the value grpg_forward returned.  geom/binning/image buffers are the blobs it filled -- by
+ * grpg_forward or grpg_forward_flags WITHOUT GRPG_FORWARD_NO_BACKWARD (an evaluation frame's
+ * geometry blob has no room for the gradient records the backward accumulates in its tail; the
+ * geometry blob is therefore written by this call, the other two are only read).
+ * Gradient outputs:
  *   dL_dmean2D[P,3] (.z = sum |d/dx|+|d/dy|, backward.cu:627-628), dL_dconic[P,4] (.x .y .w),
  *   dL_dopacity[P], dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3], dL_dcov3D[P,6],
  *   dL_dsh[P,M,3], dL_dscale[P,3], dL_drot[P,4], dL_dsemantic[P,S].
+ * dL_dsemantic must arrive ZERO-FILLED (float atomics accumulate into it, as in the reference,
+ * rasterize_points.cu:166-176); every element of the other ten arrays is WRITTEN by the call (zeros
+ * for culled Gaussians), so they may arrive uninitialised -- a caller that zero-fills all eleven
+ * like the reference's binding gets the same results.
  * Returns GRPG_OK or a negative GRPG_ERR_*.
  */
 GRPG_API int grpg_backward(int P, int D, int M, int R, int S,
