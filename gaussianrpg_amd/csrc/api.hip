@@ -902,9 +902,12 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   if (P <= 0) return GRPG_OK;
   if (!geom_buffer || !binning_buffer || !image_buffer)
     return fail(GRPG_ERR_BAD_BUFFER, "NULL state buffer");
-  if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dconic ||
-      !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D)
+  // dL_dconic / dL_ddepth (pure intermediates of the reference's binding) and dL_dcolor / dL_dcov3D
+  // (gradients of the OPTIONAL inputs colors_precomp / cov3D_precomp) may be NULL: not written then
+  if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dopacity || !dL_dmean3D)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
+  if ((colors_precomp && !dL_dcolor) || (cov3D_precomp && !dL_dcov3D))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "colors_precomp / cov3D_precomp given without their gradient array");
   if (S > 0 && (!semantics || !dL_dpix_semantic || !dL_dsemantic))
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL semantic pointer with S>0");
   if (S > GRPG_MAX_SEMANTIC_BACKWARD)   // the blend backward carries the channels in registers

@@ -140,13 +140,15 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   // arrive zero-filled (the reference zero-fills eleven arrays per call, rasterize_points.cu:166-176).
   if (!(radii[idx] > 0)) {
     dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
-    reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dL_dconics != nullptr) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     dL_dopacity[idx] = 0.f;
-    dL_dcolor[3 * idx] = 0.f; dL_dcolor[3 * idx + 1] = 0.f; dL_dcolor[3 * idx + 2] = 0.f;
-    dL_ddepth[idx] = 0.f;
+    if (dL_dcolor != nullptr) { dL_dcolor[3 * idx] = 0.f; dL_dcolor[3 * idx + 1] = 0.f; dL_dcolor[3 * idx + 2] = 0.f; }
+    if (dL_ddepth != nullptr) dL_ddepth[idx] = 0.f;
     dL_dmeans[3 * idx] = 0.f; dL_dmeans[3 * idx + 1] = 0.f; dL_dmeans[3 * idx + 2] = 0.f;
+    if (dL_dcov != nullptr) {
 #pragma unroll
-    for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = 0.f;
+      for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = 0.f;
+    }
     if (dL_dsh != nullptr)
       for (int e = 0; e < 3 * M; e++) dL_dsh[(size_t)idx * M * 3 + e] = 0.f;
     if (dL_dscale != nullptr) { dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
@@ -163,10 +165,11 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   const float gcr = gr1.z, gcg = gr1.w, gcb = gr2.x;
   const float gdep = gr2.z;
   dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = gr0.z;
-  reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(gxx, gxy, 0.f, gyy);
+  // the intermediate arrays are optional (NULL: the caller does not read them)
+  if (dL_dconics != nullptr) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(gxx, gxy, 0.f, gyy);
   dL_dopacity[idx] = gr2.y;
-  dL_dcolor[3 * idx] = gcr; dL_dcolor[3 * idx + 1] = gcg; dL_dcolor[3 * idx + 2] = gcb;
-  dL_ddepth[idx] = gdep;
+  if (dL_dcolor != nullptr) { dL_dcolor[3 * idx] = gcr; dL_dcolor[3 * idx + 1] = gcg; dL_dcolor[3 * idx + 2] = gcb; }
+  if (dL_ddepth != nullptr) dL_ddepth[idx] = gdep;
   const Vec3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
   float c3[6];
   float4 q = make_float4(0, 0, 0, 0);
@@ -205,8 +208,10 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   }
   auto aha = [&](const int r, const int c) { return A[0][r] * HA[0][c] + A[1][r] * HA[1][c]; };
   const float dcov[6] = {aha(0, 0), 2.f * aha(0, 1), 2.f * aha(0, 2), aha(1, 1), 2.f * aha(1, 2), aha(2, 2)};
+  if (dL_dcov != nullptr) {
 #pragma unroll
-  for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = dcov[e];
+    for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = dcov[e];
+  }
   const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
   float dA[2][3];
 #pragma unroll

@@ -27,6 +27,7 @@
 //     bitwise -- exactly as two runs of the reference differ from each other.
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "blend_math.h"
 #include "common.h"
@@ -433,19 +434,16 @@ __device__ __forceinline__ void backward_rect(
     if (ncur == 0 && in_hi == 0) break;   // ring empty (rcount == 0 here) and list exhausted
   }
   if (stats != nullptr && lane == 0) {   // experiment counters (GRPG_BWD_STATS=1), off in production
-    atomicAdd(&stats[0], 1ull);                            // waves
-    atomicAdd(&stats[1], (unsigned long long)count);       // list entries in reach of the wave
-    atomicAdd(&stats[2], (unsigned long long)st_fill);     // FILL steps (256 entries each)
-    atomicAdd(&stats[3], (unsigned long long)st_batches);  // batches of <= 64 mask survivors
-    atomicAdd(&stats[4], (unsigned long long)st_iters);    // survivors of the rectangle cull = loop trips
-    atomicAdd(&stats[5], (unsigned long long)st_used);     // ... of which some pixel used (reduction + atomic)
-    atomicAdd(&stats[6], (unsigned long long)st_rows);     // gradient blocks executed (rows with a taker)
-    atomicAdd(&stats[7 + (PX == 1 ? 0 : 1)], (unsigned long long)st_iters);   // trips by wave kind
-    const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
-    atomicAdd(&stats[9], dt);                              // sum of wave lifetimes (cycles)
-    atomicMax(&stats[10], dt);                             // longest wave
-    atomicMax(&stats[11], (unsigned long long)st_iters);   // most loop trips in one wave
-    atomicMax(&stats[12], (unsigned long long)count);      // longest list in reach of one wave
+    // one record of 8 words per wave, no atomics (same-address atomics would dominate the launch)
+    unsigned long long* r = stats + 8ull * ((unsigned long long)blockIdx.x * RB_WAVES + (threadIdx.x >> 6));
+    r[0] = 1ull + (PX == 1 ? 0ull : 2ull);   // wave kind: 1 quarter wave, 3 light wave
+    r[1] = count;                             // list entries in reach of the wave
+    r[2] = ((unsigned long long)st_fill << 32) | st_batches;
+    r[3] = st_iters;                          // survivors of the rectangle cull = loop trips
+    r[4] = st_used;                           // ... of which some pixel used (reduction + atomic)
+    r[5] = st_rows;                           // gradient blocks executed
+    r[6] = __builtin_readcyclecounter() - st_t0;
+    r[7] = st_t0;
   }
 }
 
@@ -526,9 +524,11 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   static const int want_stats = [] { const char* e = getenv("GRPG_BWD_STATS"); return e ? atoi(e) : 0; }();
   static unsigned long long* stats_dev = nullptr;
   unsigned long long* stats = nullptr;
+  const int grid_max = ntiles + ntiles / 2 + 1;
+  const size_t stats_words = 8ull * (size_t)grid_max * RB_WAVES;
   if (want_stats) {
-    if (!stats_dev) (void)hipMalloc((void**)&stats_dev, 16 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(stats_dev, 0, 16 * sizeof(unsigned long long), s);
+    if (!stats_dev) (void)hipMalloc((void**)&stats_dev, stats_words * sizeof(unsigned long long));
+    (void)hipMemsetAsync(stats_dev, 0, stats_words * sizeof(unsigned long long), s);
     stats = stats_dev;
   }
 #define RB_ARGS                                                                                  \
@@ -536,16 +536,17 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
       dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic, ablate, wide, stats
   // nheavy + ceil(LIGHT_SPLIT nlight / 4) <= ntiles for LIGHT_SPLIT <= 2 ... not for nheavy ~ ntiles/2:
   // launch nheavy_max + light workgroups = ntiles + ntiles/2 + 1, surplus workgroups exit at once.
-  // Light tiles: one wave per tile, 4 pixels per lane (default).  GRPG_BWD_LIGHT=2 selects two
-  // waves per light tile at 2 pixels per lane (138 VGPRs / 3 waves per SIMD instead of 178 / 2, or
-  // 128 / 4 with GRPG_BWD_WAVES=4): measured SLOWER (1.25 / 1.36 vs 1.14 ms at config 5) -- the
-  // second wave repeats the tile's list traversal, which outweighs the occupancy.
-  static const int light4 = [] { const char* e = getenv("GRPG_BWD_LIGHT"); return !(e && atoi(e) == 2); }();
+  // Light tiles: two waves per tile at 2 pixels per lane (default): the kernel then fits 128 VGPRs
+  // = 4 waves per SIMD.  One wave at 4 pixels per lane (GRPG_BWD_LIGHT=4: 160 VGPRs, 3 waves per
+  // SIMD) and GRPG_BWD_WAVES=1 (no register cap) measure within 1 % of it under rocprofv3 at
+  // config 5; GRPG_BWD_WAVES=5 (96 VGPRs, 36 spilled) is 8 % slower.
+  static const int light4 = [] { const char* e = getenv("GRPG_BWD_LIGHT"); return e && atoi(e) == 4; }();
   const int grid = light4 ? ntiles : ntiles + ntiles / 2 + 1;
   if (S <= 0) {
-    static const int minw = [] { const char* e = getenv("GRPG_BWD_WAVES"); return e ? atoi(e) : 1; }();
+    static const int minw = [] { const char* e = getenv("GRPG_BWD_WAVES"); return e ? atoi(e) : 4; }();
     if (light4) render_backward_kernel<0, 1><<<grid, 256, 0, s>>>(RB_ARGS);
-    else if (minw >= 4) render_backward_kernel<0, 2, 4><<<grid, 256, 0, s>>>(RB_ARGS);
+    else if (minw >= 5) render_backward_kernel<0, 2, 5><<<grid, 256, 0, s>>>(RB_ARGS);
+    else if (minw == 4) render_backward_kernel<0, 2, 4><<<grid, 256, 0, s>>>(RB_ARGS);
     else render_backward_kernel<0, 2><<<grid, 256, 0, s>>>(RB_ARGS);
   } else if (S <= 4) {
     if (light4) render_backward_kernel<4, 1><<<grid, 256, 0, s>>>(RB_ARGS);
@@ -555,14 +556,25 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   }
 #undef RB_ARGS
   if (stats) {
-    unsigned long long h[16];
+    std::vector<unsigned long long> h(stats_words);
     (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h, stats_dev, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[bwd stats] waves %llu entries_in_reach %llu fill_steps %llu batches %llu loop_trips %llu "
-                    "used %llu grad_blocks %llu trips_quarter_waves %llu trips_light_waves %llu | wave cycles: sum %llu "
-                    "max %llu (mean %.0f); max trips/wave %llu; longest list in reach %llu\n",
-            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[0] ? (double)h[9] / h[0] : 0.0,
-            h[11], h[12]);
+    (void)hipMemcpy(h.data(), stats_dev, stats_words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long waves[2] = {0, 0}, entries = 0, fills = 0, batches = 0, trips[2] = {0, 0}, used = 0, rows = 0;
+    unsigned long long cyc_sum = 0, cyc_max = 0, trips_of_longest = 0, reach_of_longest = 0;
+    for (size_t w = 0; w < stats_words / 8; w++) {
+      const unsigned long long* r = &h[8 * w];
+      if (!r[0]) continue;
+      const int kind = r[0] == 1ull ? 0 : 1;
+      waves[kind]++; entries += r[1]; fills += r[2] >> 32; batches += r[2] & 0xFFFFFFFFull;
+      trips[kind] += r[3]; used += r[4]; rows += r[5]; cyc_sum += r[6];
+      if (r[6] > cyc_max) { cyc_max = r[6]; trips_of_longest = r[3]; reach_of_longest = r[1]; }
+    }
+    fprintf(stderr, "[bwd stats] waves q %llu l %llu; entries_in_reach %llu fill_steps %llu batches %llu; trips q %llu l %llu "
+                    "used %llu grad_blocks %llu | wave cycles: sum %llu mean %.0f max %llu (that wave: %llu trips, %llu entries "
+                    "in reach)\n",
+            waves[0], waves[1], entries, fills, batches, trips[0], trips[1], used, rows, cyc_sum,
+            (waves[0] + waves[1]) ? (double)cyc_sum / (double)(waves[0] + waves[1]) : 0.0, cyc_max, trips_of_longest,
+            reach_of_longest);
   }
 }
 

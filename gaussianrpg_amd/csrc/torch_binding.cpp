@@ -217,7 +217,12 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   // the gradients a training step keeps as .grad (means3D, means2D, opacity, sh, scales,
   // rotations), pool B the internal ones and those autograd normally drops (colors, depths, conic,
   // cov3D), so a retained .grad does not pin the scratch arrays.
-  const int64_t widths[11] = {3, 3, GRPG_NUM_CHANNELS, 1, 4, 1, 6, (int64_t)M * 3, 3, 4, 0};
+  // gradients of absent optional inputs (colors_precomp, cov3D_precomp) and the two pure
+  // intermediates of the reference's binding (dL_dconic, dL_ddepths) are not materialised at all:
+  // the library takes NULL for them
+  const bool want_colors = colors.numel() != 0, want_cov = cov3D_precomp.numel() != 0;
+  const int64_t widths[11] = {3, 3, want_colors ? GRPG_NUM_CHANNELS : 0, 0, 0, 1, want_cov ? 6 : 0,
+                              (int64_t)M * 3, 3, 4, 0};
   const int pool_of[11] = {0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0};
   int64_t offs[11], size[2] = {0, 0};
   for (int i = 0; i < 11; i++) {
@@ -230,11 +235,9 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   };
   torch::Tensor dL_dmeans3D = view(0, {P, 3});
   torch::Tensor dL_dmeans2D = view(1, {P, 3});
-  torch::Tensor dL_dcolors = view(2, {P, GRPG_NUM_CHANNELS});
-  torch::Tensor dL_ddepths = view(3, {P, 1});
-  torch::Tensor dL_dconic = view(4, {P, 2, 2});
+  torch::Tensor dL_dcolors = want_colors ? view(2, {P, GRPG_NUM_CHANNELS}) : torch::empty({0, GRPG_NUM_CHANNELS}, o);
   torch::Tensor dL_dopacity = view(5, {P, 1});
-  torch::Tensor dL_dcov3D = view(6, {P, 6});
+  torch::Tensor dL_dcov3D = want_cov ? view(6, {P, 6}) : torch::empty({0, 6}, o);
   torch::Tensor dL_dsh = view(7, {P, M, 3});
   torch::Tensor dL_dscales = view(8, {P, 3});
   torch::Tensor dL_drotations = view(9, {P, 4});
@@ -269,9 +272,10 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
         p_rot, p_cov, p_view, p_proj, p_cam, tan_fovx, tan_fovy, radii_c.data_ptr<int>(),
         reinterpret_cast<char*>(gb.data_ptr()), reinterpret_cast<char*>(bb.data_ptr()),
         reinterpret_cast<char*>(ib.data_ptr()), g_col, g_dep, g_alp, g_sem,
-        dL_dmeans2D.data_ptr<float>(), dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
-        dL_dcolors.data_ptr<float>(), dL_ddepths.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
-        dL_dcov3D.data_ptr<float>(), M > 0 ? dL_dsh.data_ptr<float>() : nullptr,
+        dL_dmeans2D.data_ptr<float>(), /*dL_dconic=*/nullptr, dL_dopacity.data_ptr<float>(),
+        want_colors ? dL_dcolors.data_ptr<float>() : nullptr, /*dL_ddepth=*/nullptr,
+        dL_dmeans3D.data_ptr<float>(), want_cov ? dL_dcov3D.data_ptr<float>() : nullptr,
+        M > 0 ? dL_dsh.data_ptr<float>() : nullptr,
         dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(),
         S > 0 ? dL_dsemantic.data_ptr<float>() : nullptr, debug ? 1 : 0, (void*)stream);
     if (rc != GRPG_OK) raise_abi_error("grpg_backward", rc);

@@ -298,7 +298,9 @@ GRPG_API int grpg_set_binning_algorithm(int alg);
  * dL_dsemantic must arrive ZERO-FILLED (float atomics accumulate into it, as in the reference,
  * rasterize_points.cu:166-176); every element of the other ten arrays is WRITTEN by the call (zeros
  * for culled Gaussians), so they may arrive uninitialised -- a caller that zero-fills all eleven
- * like the reference's binding gets the same results.
+ * like the reference's binding gets the same results.  dL_dconic and dL_ddepth (intermediates the
+ * reference's binding never returns), dL_dcolor without colors_precomp and dL_dcov3D without
+ * cov3D_precomp may be NULL: they are then not written (saves their HBM traffic).
  * Returns GRPG_OK or a negative GRPG_ERR_*.
  */
 GRPG_API int grpg_backward(int P, int D, int M, int R, int S,

@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 sc = hz.street_scene(args.gaussians, seed=149).to(dev)
 leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.opacity, sc.shs, sc.scales, sc.rotations)]
 target = torch.rand(3, hz.WAYMO_H, hz.WAYMO_W, device=dev)
-fw, bw = [], []
+fw, bw, ob = [], [], []
 for it in range(args.warmup + args.steps):
     cam = hz.trajectory_camera(it % 200, device=dev)
     rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
@@ -30,13 +30,19 @@ for it in range(args.warmup + args.steps):
                                            shs=leaves[2], scales=leaves[3], rotations=leaves[4])
     torch.cuda.synchronize(); t1 = time.perf_counter()
     loss = (color - target).abs().mean() + 0.1 * (depth / (alpha + 1e-10)).mean() + 0.05 * alpha.mean()
+    outs = (color, depth, alpha)
+    gouts = torch.autograd.grad(loss, outs, retain_graph=True)     # the loss' own backward, untimed
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    loss.backward()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.autograd.backward(outs, gouts)                           # the op's backward alone
+    e1.record()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     if it >= args.warmup:
-        fw.append(t1 - t0); bw.append(t3 - t2)
-fw.sort(); bw.sort()
+        fw.append(t1 - t0); bw.append(t3 - t2); ob.append(e0.elapsed_time(e1))
+fw.sort(); bw.sort(); ob.sort()
 print(json.dumps({"config": "configs[4]: train fwd+bwd, scene-149-like P=%d @1920x1280" % args.gaussians,
                   "forward_ms_median": 1e3 * fw[len(fw) // 2], "backward_ms_median": 1e3 * bw[len(bw) // 2],
-                  "backward_includes": "torch loss backward (4 small elementwise kernels) + _C.rasterize_gaussians_backward",
+                  "op_backward_device_ms_median": ob[len(ob) // 2],
+                  "backward_includes": "_C.rasterize_gaussians_backward alone (wall, and device time between two events)",
                   "steps": args.steps}))
