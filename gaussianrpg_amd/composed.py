@@ -8,13 +8,23 @@ inverse DFT of the actor's Fourier colour coefficients (gaussian_model_actor.py:
 ``torch.cat`` over the models -- about twenty small kernels and two extra passes over the op's whole
 input.  ``ComposedRasterizer`` hands the models' RAW parameter tensors and the per-frame poses to
 ``_C.rasterize_gaussians_composed`` instead; the arithmetic happens inside the HIP preprocess and the
-concatenated tensors are never materialised.  Forward only (evaluation, trajectory and simulator
-rendering); training keeps composing in PyTorch, where autograd needs the intermediates, and calls
-the classic ``GaussianRasterizer``.
+concatenated tensors are never materialised.
 
     models = [ModelParams(...background...), ModelParams(...actor 1...), ...]
     poses  = [None, ActorPose(obj_rot, obj_trans, fourier_time), ...]
     color, radii, depth, alpha = ComposedRasterizer(raster_settings)(models, poses)
+
+Evaluation (``torch.no_grad()`` or nothing requires grad): forward only.  TRAINING (round 3): when
+any raw parameter tensor -- or an actor's ``obj_rot`` / ``obj_trans`` given as a tensor -- requires
+grad, the call goes through an autograd function whose backward (C ABI ``grpg_backward_composed``)
+returns the gradients with respect to the RAW parameters (``_xyz``, ``_scaling``, ``_rotation``,
+``_opacity``, ``_features_dc``, ``_features_rest``) and the poses: the chain rule through exp /
+sigmoid / normalize, the Fourier DC sum, the rigid transform and the quaternion product runs inside
+the preprocess backward kernel.  ``means2D`` (zeros ``[P,3]`` requiring grad, as
+street_gaussian_renderer.py:157-162 creates it) receives the densification statistic.  Not fused
+(stay in the caller's PyTorch): the flip augmentation of actors (street_gaussian_model.py:286-293),
+the semantic concatenation (:420-435) and pose-correction modules -- a corrected pose is simply an
+``obj_rot`` / ``obj_trans`` tensor with a graph behind it.
 """
 import math
 from typing import List, NamedTuple, Optional, Sequence
@@ -43,10 +53,16 @@ class ModelParams(NamedTuple):
 class ActorPose(NamedTuple):
     """Pose of one actor for one frame: ``obj_rot`` (w,x,y,z) and ``obj_trans`` in world space, ego
     pose already applied (street_gaussian_model.py:268-273); ``fourier_time`` =
-    fourier_scale * (frame - start_frame) / (end_frame - start_frame) (gaussian_model_actor.py:74-75)."""
+    fourier_scale * (frame - start_frame) / (end_frame - start_frame) (gaussian_model_actor.py:74-75).
+    ``obj_rot`` / ``obj_trans`` are sequences of floats or tensors ([4] / [3]); tensors that require
+    grad (optimised tracking, street_gaussian_model.py:319-320) receive gradients in training."""
     obj_rot: Sequence[float]
     obj_trans: Sequence[float]
     fourier_time: float = 0.0
+
+
+def _floats(v):
+    return [float(x) for x in (v.detach().cpu().tolist() if isinstance(v, torch.Tensor) else v)]
 
 
 def idft_weights(time: float, dim: int) -> List[float]:
@@ -90,7 +106,7 @@ def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
             rows.append([0.0] * 8)
             times.append(0.0)
         else:
-            rows.append([1.0] + [float(v) for v in p.obj_rot] + [float(v) for v in p.obj_trans])
+            rows.append([1.0] + _floats(p.obj_rot) + _floats(p.obj_trans))
             times.append(float(p.fourier_time))
     pose_t = torch.tensor(rows, dtype=torch.float32).reshape(len(models), 8)
     idft_t = _idft_rows(times, dims)
@@ -106,20 +122,77 @@ def compose(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]])
     return _C.compose(*lists, pose_t, idft_t)
 
 
+class _ComposedRasterize(torch.autograd.Function):
+    """Training path: forward = _C.rasterize_gaussians_composed(for_backward=True), backward =
+    _C.rasterize_gaussians_composed_backward (C ABI grpg_backward_composed)."""
+
+    @staticmethod
+    def forward(ctx, rs, nm, pose_t, idft_t, pose_rot, pose_trans, means2D, *flat):
+        lists = [list(flat[f * nm:(f + 1) * nm]) for f in range(6)]
+        num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians_composed(
+            rs.bg, *lists, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug, True)
+        ctx.rs, ctx.nm, ctx.num_rendered = rs, nm, num_rendered
+        ctx.pose_t, ctx.idft_t = pose_t, idft_t
+        ctx.pose_dev = (None if pose_rot is None else pose_rot.device,
+                        None if pose_trans is None else pose_trans.device)
+        ctx.save_for_backward(radii, alpha, geom, binning, img, *flat)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        rs, nm = ctx.rs, ctx.nm
+        radii, alpha, geom, binning, img = ctx.saved_tensors[:5]
+        flat = ctx.saved_tensors[5:]
+        lists = [list(flat[f * nm:(f + 1) * nm]) for f in range(6)]
+        zeros = lambda t: torch.zeros_like(t)   # noqa: E731  (an output the loss does not touch)
+        gx, gs, gr, go, gdc, gfr, g_means2D, g_poses = _C.rasterize_gaussians_composed_backward(
+            rs.bg, *lists, ctx.pose_t, ctx.idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, rs.sh_degree, rs.campos, radii, alpha, geom, ctx.num_rendered,
+            binning, img, g_color if g_color is not None else zeros(alpha).expand(3, -1, -1).contiguous(),
+            g_depth if g_depth is not None else zeros(alpha),
+            g_alpha if g_alpha is not None else zeros(alpha), rs.debug)
+        need = ctx.needs_input_grad
+        g_rot = g_poses[:, 0:4].to(ctx.pose_dev[0]) if need[4] else None
+        g_trans = g_poses[:, 4:7].to(ctx.pose_dev[1]) if need[5] else None
+        grads = [g for per_field in (gx, gs, gr, go, gdc, gfr) for g in per_field]
+        flat_grads = tuple(g if n else None for g, n in zip(grads, need[7:]))
+        return (None, None, None, None, g_rot, g_trans, g_means2D if need[6] else None) + flat_grads
+
+
 class ComposedRasterizer(nn.Module):
     """``GaussianRasterizer`` for a scene graph: takes per-model raw parameters + per-frame actor
-    poses, returns ``(color, radii, depth, alpha)`` like the classic module (no semantics)."""
+    poses, returns ``(color, radii, depth, alpha)`` like the classic module (no semantics).
+    Differentiable with respect to the raw parameters, tensor-valued poses and ``means2D``."""
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
 
-    @torch.no_grad()
-    def forward(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
+    def forward(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]], means2D=None):
         rs = self.raster_settings
         lists, pose_t, idft_t = _pack(models, poses)
-        num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians_composed(
-            rs.bg, *lists, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
-            rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug)
-        self.num_rendered = num_rendered
-        return color, radii, depth, alpha
+        flat = [t for per_field in lists for t in per_field]
+        pose_tensors = [t for p in poses if p is not None for t in (p.obj_rot, p.obj_trans)
+                        if isinstance(t, torch.Tensor)]
+        train = torch.is_grad_enabled() and any(
+            t.requires_grad for t in flat + pose_tensors + ([means2D] if means2D is not None else []))
+        if not train:
+            with torch.no_grad():
+                num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians_composed(
+                    rs.bg, *lists, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                    rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug)
+            self.num_rendered = num_rendered
+            return color, radii, depth, alpha
+        # poses as [n,4] / [n,3] tensors that keep their graph (rows of static models: constants)
+        pose_rot = pose_trans = None
+        if pose_tensors:
+            one = torch.tensor([1.0, 0.0, 0.0, 0.0])
+            zero3 = torch.zeros(3)
+            dev = pose_tensors[0].device
+            as_t = lambda v, d: v.to(dev).float() if isinstance(v, torch.Tensor) else \
+                torch.tensor([float(x) for x in v], device=dev)   # noqa: E731
+            pose_rot = torch.stack([one.to(dev) if p is None else as_t(p.obj_rot, dev) for p in poses])
+            pose_trans = torch.stack([zero3.to(dev) if p is None else as_t(p.obj_trans, dev) for p in poses])
+        return _ComposedRasterize.apply(rs, len(models), pose_t, idft_t, pose_rot, pose_trans, means2D, *flat)

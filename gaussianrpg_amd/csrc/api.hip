@@ -332,6 +332,7 @@ namespace {
 // Pinned staging for the composed forward's segment table (thread-local; the frame's one host wait
 // guarantees the previous upload has been consumed before the buffer is reused).
 thread_local SegmentDev* g_seg_staging = nullptr;
+thread_local grpg_model_segment_grad* g_seg_grad_staging = nullptr;
 
 // Shared body of grpg_forward (segs == NULL: flat input tensors) and grpg_forward_composed (segs:
 // per-model raw parameters, P = sum of their counts, the flat pointers are NULL).
@@ -823,14 +824,14 @@ int grpg_frame_status(int ticket, int wait, int* num_rendered) {
   return r;
 }
 
-int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
-                          grpg_alloc_fn binning_alloc, void* binning_user,
-                          grpg_alloc_fn image_alloc, void* image_user,
-                          const grpg_model_segment* segments, int num_segments, int D, int M,
-                          const float* background, int width, int height, float scale_modifier,
-                          const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                          float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
-                          float* out_alpha, int* radii, int debug, void* hip_stream) {
+int grpg_forward_composed_flags(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                                grpg_alloc_fn binning_alloc, void* binning_user,
+                                grpg_alloc_fn image_alloc, void* image_user,
+                                const grpg_model_segment* segments, int num_segments, int D, int M,
+                                const float* background, int width, int height, float scale_modifier,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
+                                float* out_alpha, int* radii, int debug, void* hip_stream, unsigned flags) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   long long P = 0;
@@ -841,7 +842,98 @@ int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
                       image_user, (int)P, D, M, 0, background, width, height, nullptr, nullptr, nullptr,
                       nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
                       projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
-                      radii, debug, hip_stream, segments, num_segments, GRPG_FORWARD_NO_BACKWARD);
+                      radii, debug, hip_stream, segments, num_segments, flags);
+}
+
+int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                          grpg_alloc_fn binning_alloc, void* binning_user,
+                          grpg_alloc_fn image_alloc, void* image_user,
+                          const grpg_model_segment* segments, int num_segments, int D, int M,
+                          const float* background, int width, int height, float scale_modifier,
+                          const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                          float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
+                          float* out_alpha, int* radii, int debug, void* hip_stream) {
+  return grpg_forward_composed_flags(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                                     image_user, segments, num_segments, D, M, background, width, height,
+                                     scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+                                     out_color, out_depth, out_alpha, radii, debug, hip_stream,
+                                     GRPG_FORWARD_NO_BACKWARD);
+}
+
+int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_segment_grad* grads,
+                           int num_segments, int D, int M, int R, const float* background, int width,
+                           int height, float scale_modifier, const float* viewmatrix,
+                           const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                           const int* radii, const float* alphas, char* geom_buffer, char* binning_buffer,
+                           char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth,
+                           const float* dL_dalphas, float* dL_dmean2D, float* dL_dposes, int debug,
+                           void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  long long Pll = 0;
+  if (int rc = check_segments(segments, num_segments, M, &Pll)) return rc;
+  const int P = (int)Pll;
+  if (M < 1 || M > 16 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M <= 16");
+  if (!grads || !geom_buffer || !binning_buffer || !image_buffer)
+    return fail(GRPG_ERR_BAD_BUFFER, "NULL gradient table / state buffer");
+  if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dposes || !radii ||
+      !background || !viewmatrix || !projmatrix || !campos)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL pointer");
+  for (int i = 0; i < num_segments; i++) {
+    const grpg_model_segment_grad& g = grads[i];
+    if (!g.xyz || !g.scaling || !g.rotation || !g.opacity || !g.features_dc || (M > 1 && !g.features_rest))
+      return fail(GRPG_ERR_INVALID_ARGUMENT, "segment gradient with a NULL array");
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const CameraArgs cam = make_camera(viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy);
+  const uint32_t T = (uint32_t)cam.gx * (uint32_t)cam.gy;
+  const GeomLayout GL = geom_layout((size_t)P);
+  const ImgLayout IL = img_layout(T, (size_t)width * height);
+  const RecView rec = {(const float4*)(geom_buffer + GL.rec)};
+  const uint32_t* point_list = (const uint32_t*)(binning_buffer + bin_layout(0).val_a);
+  const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
+  const uint32_t* n_contrib = (const uint32_t*)(image_buffer + IL.n_contrib);
+  (void)R;
+  // tables: the segments (as in the forward; re-uploaded: the caller may hand over other arrays of
+  // the same values) and the six output pointers per segment, through pinned staging
+  if (!g_seg_staging)
+    HIP_TRY(hipHostMalloc((void**)&g_seg_staging, sizeof(SegmentDev) * MAX_SEGMENTS, hipHostMallocDefault));
+  if (!g_seg_grad_staging)
+    HIP_TRY(hipHostMalloc((void**)&g_seg_grad_staging, sizeof(grpg_model_segment_grad) * MAX_SEGMENTS,
+                          hipHostMallocDefault));
+  uint32_t start = 0;
+  for (int i = 0; i < num_segments; i++) {
+    SegmentDev& d = g_seg_staging[i];
+    const grpg_model_segment& g = segments[i];
+    d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
+    d.fdc = g.features_dc; d.frest = g.features_rest;
+    d.start = start; d.count = (uint32_t)g.count;
+    d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
+    for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];
+    for (int k = 0; k < 3; k++) d.trans[k] = g.obj_trans[k];
+    d.pad0 = 0.f;
+    for (int k = 0; k < MAX_FOURIER; k++) d.idft[k] = g.idft[k];
+    start += (uint32_t)g.count;
+    g_seg_grad_staging[i] = grads[i];
+  }
+  SegmentDev* seg_dev = (SegmentDev*)(geom_buffer + GL.seg_table);
+  void* seg_grad_dev = (void*)(geom_buffer + GL.seg_grad_table);
+  HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)num_segments,
+                         hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(seg_grad_dev, g_seg_grad_staging,
+                         sizeof(grpg_model_segment_grad) * (size_t)num_segments, hipMemcpyHostToDevice, stream));
+  float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
+  HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
+  launch_render_backward(stream, ranges, point_list, rec, nullptr, 0, width, height, cam.gx, cam.gy,
+                         background, alphas, n_contrib, (const uint32_t*)(image_buffer + IL.work), dL_dpix,
+                         dL_dpix_depth, dL_dalphas, nullptr, grad_rec, nullptr);
+  STAGE_CHECK("render backward");
+  launch_preprocess_backward_composed(stream, P, D, M, seg_dev, seg_grad_dev, num_segments, radii, rec,
+                                      scale_modifier, cam, grad_rec, dL_dmean2D,
+                                      (float*)(geom_buffer + GL.pose_acc), dL_dposes);
+  STAGE_CHECK("preprocess backward (composed)");
+  return GRPG_OK;
 }
 
 int grpg_compose(const grpg_model_segment* segments, int num_segments, int M, float* means3D,

@@ -131,6 +131,8 @@ struct GeomLayout {
   size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
   size_t pre_counts;     // uint2[ceil(P/256)]: per-workgroup (instances, coarse pairs) of preprocess
   size_t grad_rec;       // float[P][16]: per-Gaussian gradient accumulators of the backward (train forwards only)
+  size_t seg_grad_table; // composed training backward: six output pointers per segment
+  size_t pose_acc;       // ... and the per-actor sums [MAX_SEGMENTS][16]
   size_t zero_begin, zero_end;   // region frame_init clears: ds_table
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
@@ -182,6 +184,10 @@ inline GeomLayout geom_layout(size_t P, bool with_grad = true) {
   L.pre_counts = take(((P + 255) / 256 + 1) * 8);
   L.grad_rec = o;
   if (with_grad) (void)take(P * GRAD_STRIDE * 4);
+  L.seg_grad_table = o;
+  if (with_grad) (void)take((size_t)MAX_SEGMENTS * 6 * sizeof(float*));
+  L.pose_acc = o;
+  if (with_grad) (void)take((size_t)MAX_SEGMENTS * 16 * 4);
   L.total = o;
   return L;
 }
@@ -360,6 +366,16 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                 float* dL_dmean3D, float* dL_dcolor, float* dL_ddepth,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
+
+// training backward of the fused composition (preprocess_bwd.hip): seg_grads = device array of
+// num_segments records of six float* (xyz, scaling, rotation, opacity, features_dc, features_rest)
+constexpr int POSE_ACC_FLOATS = 16;
+void launch_preprocess_backward_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs,
+                                         const void* seg_grads, int nseg, const int* radii,
+                                         const RecView rec, float scale_modifier, const CameraArgs& cam,
+                                         const float* grad_rec, float* dL_dmean2D,
+                                         float* pose_acc /* [nseg][POSE_ACC_FLOATS] scratch */,
+                                         float* dL_dposes /* [nseg][8] */);
 
 void launch_frame_init(hipStream_t s, char* geom, char* bin /* may be NULL */, char* img, uint32_t P,
                        uint32_t V_init, uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S,

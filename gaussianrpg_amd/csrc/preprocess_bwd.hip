@@ -26,6 +26,7 @@
 #pragma clang fp contract(off)
 
 #include "gaussian_math.h"
+#include "compose_math.h"
 
 namespace grpg {
 
@@ -120,6 +121,110 @@ __device__ __forceinline__ void cov3d_backward(const float s0, const float s1, c
   drot[3] = 2.f * (r * A10 + x * S02 + y * S12) - 4.f * z * (G[0][0] + G[1][1]);
 }
 
+// Gradient of one visible Gaussian given its ACTIVATED parameters (mean m, 3-D covariance c3 --
+// recomputed by the caller with the forward's own function -- and, when it came from scale /
+// rotation, s and q), the blend backward's sums for it, and its SH coefficients.  Outputs: gm
+// (dL/dmean), dcov (dL/dSigma, 6 values), ds / dr (dL/dscale, dL/dq; only when from_sr) and, through
+// dsh, dL/dsh (M x 3; NULL = colours were precomputed).  Shared by the flat kernel and the
+// composed one (raw scene-graph parameters).
+struct BlendGrad {   // one Gaussian's 64-byte gradient record (common.h GRAD_*)
+  float g2x, g2y, gabs, gxx, gxy, gyy, gcr, gcg, gcb, gop, gdep;
+};
+__device__ __forceinline__ BlendGrad load_blend_grad(const float4* __restrict__ grad_rec, const int idx) {
+  const float4 gr0 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx], gr1 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx + 1],
+               gr2 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx + 2];
+  return BlendGrad{gr0.x, gr0.y, gr0.z, gr0.w, gr1.x, gr1.y, gr1.z, gr1.w, gr2.x, gr2.y, gr2.z};
+}
+
+__device__ __forceinline__ void preprocess_backward_core(
+    const Vec3 m, const float* c3, const bool from_sr, const float s0, const float s1, const float s2,
+    const float scale_modifier, const float4 q, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, const float h_x, const float h_y,
+    const float tan_fovx, const float tan_fovy, const BlendGrad& bg, const uint32_t clamped, const int D,
+    const float* __restrict__ sh, float* __restrict__ dsh, Vec3& gm_out, float* dcov, float* ds, float* dr) {
+  Cov2D cv;
+  cov2d_project(m.x, m.y, m.z, view, h_x, h_y, tan_fovx, tan_fovy, c3, cv);
+
+  // ---- conic -> screen covariance S (with the +0.3 dilation):  dL/dS = -K G K, K = adj(S) / det ----
+  // the render backward stores HALF of the off-diagonal conic derivative (backward.cu:619-621),
+  // so G carries that stored value in both off-diagonal entries
+  const float gxx = bg.gxx, gxy = bg.gxy, gyy = bg.gyy;
+  const float a = cv.a + 0.3f, b = cv.b, c = cv.c + 0.3f;
+  const float det = a * c - b * b;
+  const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
+  // adj(S) G adj(S), adj(S) = [[c, -b], [-b, a]]
+  const float p0 = c * gxx - b * gxy, p1 = c * gxy - b * gyy;   // first row of adj G
+  const float q0 = a * gxy - b * gxx, q1 = a * gyy - b * gxy;   // second row of adj G
+  float Haa = -(p0 * c - p1 * b) * inv_det2;      // dL/da
+  float Hcc = -(q1 * a - q0 * b) * inv_det2;      // dL/dc
+  float Hab = -(p1 * a - p0 * b) * inv_det2;      // dL/d(one off-diagonal entry); dL/db = 2 Hab
+  if (!(inv_det2 != 0.f)) { Haa = 0.f; Hcc = 0.f; Hab = 0.f; }
+
+  // ---- S = A V A^T:  dL/dV = A^T H A (off-diagonals counted twice),  dL/dA = 2 H A V ----
+  const float A[2][3] = {{cv.T00, cv.T01, cv.T02}, {cv.T10, cv.T11, cv.T12}};
+  float HA[2][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    HA[0][j] = Haa * A[0][j] + Hab * A[1][j];
+    HA[1][j] = Hab * A[0][j] + Hcc * A[1][j];
+  }
+  auto aha = [&](const int r, const int cc) { return A[0][r] * HA[0][cc] + A[1][r] * HA[1][cc]; };
+  dcov[0] = aha(0, 0); dcov[1] = 2.f * aha(0, 1); dcov[2] = 2.f * aha(0, 2);
+  dcov[3] = aha(1, 1); dcov[4] = 2.f * aha(1, 2); dcov[5] = aha(2, 2);
+  const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+  float dA[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      dA[i][j] = 2.f * (HA[i][0] * V[0][j] + HA[i][1] * V[1][j] + HA[i][2] * V[2][j]);
+
+  // ---- A = J W: the view rotation's rows are (v0 v4 v8), (v1 v5 v9), (v2 v6 v10) ----
+  const Vec3 W0 = {view[0], view[4], view[8]}, W1 = {view[1], view[5], view[9]}, W2 = {view[2], view[6], view[10]};
+  const Vec3 dA0 = {dA[0][0], dA[0][1], dA[0][2]}, dA1 = {dA[1][0], dA[1][1], dA[1][2]};
+  const float dJ00 = dot3(W0, dA0), dJ02 = dot3(W2, dA0);
+  const float dJ11 = dot3(W1, dA1), dJ12 = dot3(W2, dA1);
+  // J00 = hx / tz, J02 = -hx tx / tz^2, J11 = hy / tz, J12 = -hy ty / tz^2; no gradient through a
+  // tx / ty the forward clamped to the frustum guard band
+  const float itz = 1.f / cv.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+  const float pass_x = (cv.txtz < -cv.limx || cv.txtz > cv.limx) ? 0.f : 1.f;
+  const float pass_y = (cv.tytz < -cv.limy || cv.tytz > cv.limy) ? 0.f : 1.f;
+  const Vec3 dt = {pass_x * (-h_x * itz2) * dJ02, pass_y * (-h_y * itz2) * dJ12,
+                   -h_x * itz2 * dJ00 - h_y * itz2 * dJ11 + (2.f * h_x * cv.tx) * itz3 * dJ02 +
+                       (2.f * h_y * cv.ty) * itz3 * dJ12};
+  // t = W m + translation
+  Vec3 gm = {W0.x * dt.x + W1.x * dt.y + W2.x * dt.z, W0.y * dt.x + W1.y * dt.y + W2.y * dt.z,
+             W0.z * dt.x + W1.z * dt.y + W2.z * dt.z};
+
+  // ---- mean2D = ndc2pix(proj m / w):  d(p_k / w)/dm_j = (P_kj - P_3j p_k / w) / w ----
+  {
+    const float w = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
+    const float iw = 1.0f / (w + 0.0000001f);
+    const float px_w2 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * iw * iw;
+    const float py_w2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * iw * iw;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float add = (proj[4 * j] * iw - proj[4 * j + 3] * px_w2) * bg.g2x +
+                        (proj[4 * j + 1] * iw - proj[4 * j + 3] * py_w2) * bg.g2y;
+      if (j == 0) gm.x += add; else if (j == 1) gm.y += add; else gm.z += add;
+    }
+  }
+  // ---- depth = (view m)_z, with view row 3 treated as a divisor of weight depth (backward.cu:384-391) ----
+  {
+    const float depth = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
+    gm.x += (view[2] - view[3] * depth) * bg.gdep;
+    gm.y += (view[6] - view[7] * depth) * bg.gdep;
+    gm.z += (view[10] - view[11] * depth) * bg.gdep;
+  }
+  if (sh != nullptr) {
+    const Vec3 g = {(clamped & 1u) ? 0.f : bg.gcr, (clamped & 2u) ? 0.f : bg.gcg, (clamped & 4u) ? 0.f : bg.gcb};
+    const Vec3 gs = sh_backward(D, sh, Vec3{m.x - campos[0], m.y - campos[1], m.z - campos[2]}, g, dsh);
+    gm.x += gs.x; gm.y += gs.y; gm.z += gs.z;
+  }
+  gm_out = gm;
+  if (from_sr) cov3d_backward(s0, s1, s2, scale_modifier, q, dcov, ds, dr);
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(const int P, const int D, const int M, const float* __restrict__ means3D,
                            const int* __restrict__ radii, const float* __restrict__ shs,
@@ -157,127 +262,263 @@ preprocess_backward_kernel(const int P, const int D, const int M, const float* _
   }
   // the blend backward's per-Gaussian sums: one 64-byte record (common.h GRAD_*), fanned out into the
   // reference's separate arrays here (dL_dmean2D and dL_dopacity are outputs of the op, the conic /
-  // colour / depth gradients its intermediate results, rasterize_points.cu:166-219)
-  const float4 gr0 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx], gr1 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx + 1],
-               gr2 = grad_rec[(GRAD_STRIDE / 4) * (size_t)idx + 2];
-  const float g2x = gr0.x, g2y = gr0.y;
-  const float gxx = gr0.w, gxy = gr1.x, gyy = gr1.y;
-  const float gcr = gr1.z, gcg = gr1.w, gcb = gr2.x;
-  const float gdep = gr2.z;
-  dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = gr0.z;
-  // the intermediate arrays are optional (NULL: the caller does not read them)
-  if (dL_dconics != nullptr) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(gxx, gxy, 0.f, gyy);
-  dL_dopacity[idx] = gr2.y;
-  if (dL_dcolor != nullptr) { dL_dcolor[3 * idx] = gcr; dL_dcolor[3 * idx + 1] = gcg; dL_dcolor[3 * idx + 2] = gcb; }
-  if (dL_ddepth != nullptr) dL_ddepth[idx] = gdep;
+  // colour / depth gradients its intermediate results, rasterize_points.cu:166-219); the
+  // intermediate arrays are optional (NULL: the caller does not read them)
+  const BlendGrad bgr = load_blend_grad(grad_rec, idx);
+  dL_dmean2D[3 * idx] = bgr.g2x; dL_dmean2D[3 * idx + 1] = bgr.g2y; dL_dmean2D[3 * idx + 2] = bgr.gabs;
+  if (dL_dconics != nullptr) reinterpret_cast<float4*>(dL_dconics)[idx] = make_float4(bgr.gxx, bgr.gxy, 0.f, bgr.gyy);
+  dL_dopacity[idx] = bgr.gop;
+  if (dL_dcolor != nullptr) { dL_dcolor[3 * idx] = bgr.gcr; dL_dcolor[3 * idx + 1] = bgr.gcg; dL_dcolor[3 * idx + 2] = bgr.gcb; }
+  if (dL_ddepth != nullptr) dL_ddepth[idx] = bgr.gdep;
+
   const Vec3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
   float c3[6];
   float4 q = make_float4(0, 0, 0, 0);
-  if (cov3D_precomp != nullptr) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const bool from_sr = cov3D_precomp == nullptr;
+  if (!from_sr) {
 #pragma unroll
     for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
   } else {
     q = load_quat(rotations, idx);
-    cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2],
-                         scale_modifier, q, c3);
+    s0 = scales[3 * idx]; s1 = scales[3 * idx + 1]; s2 = scales[3 * idx + 2];
+    cov3d_from_scale_rot(s0, s1, s2, scale_modifier, q, c3);
   }
-  Cov2D cv;
-  cov2d_project(m.x, m.y, m.z, view, h_x, h_y, tan_fovx, tan_fovy, c3, cv);
-
-  // ---- conic -> screen covariance S (with the +0.3 dilation):  dL/dS = -K G K, K = adj(S) / det ----
-  // the render backward stores HALF of the off-diagonal conic derivative (backward.cu:619-621),
-  // so G carries that stored value in both off-diagonal entries
-  const float a = cv.a + 0.3f, b = cv.b, c = cv.c + 0.3f;
-  const float det = a * c - b * b;
-  const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
-  // adj(S) G adj(S), adj(S) = [[c, -b], [-b, a]]
-  const float p0 = c * gxx - b * gxy, p1 = c * gxy - b * gyy;   // first row of adj G
-  const float q0 = a * gxy - b * gxx, q1 = a * gyy - b * gxy;   // second row of adj G
-  float Haa = -(p0 * c - p1 * b) * inv_det2;      // dL/da
-  float Hcc = -(q1 * a - q0 * b) * inv_det2;      // dL/dc
-  float Hab = -(p1 * a - p0 * b) * inv_det2;      // dL/d(one off-diagonal entry); dL/db = 2 Hab
-  if (!(inv_det2 != 0.f)) { Haa = 0.f; Hcc = 0.f; Hab = 0.f; }
-
-  // ---- S = A V A^T:  dL/dV = A^T H A (off-diagonals counted twice),  dL/dA = 2 H A V ----
-  const float A[2][3] = {{cv.T00, cv.T01, cv.T02}, {cv.T10, cv.T11, cv.T12}};
-  float HA[2][3];
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    HA[0][j] = Haa * A[0][j] + Hab * A[1][j];
-    HA[1][j] = Hab * A[0][j] + Hcc * A[1][j];
-  }
-  auto aha = [&](const int r, const int c) { return A[0][r] * HA[0][c] + A[1][r] * HA[1][c]; };
-  const float dcov[6] = {aha(0, 0), 2.f * aha(0, 1), 2.f * aha(0, 2), aha(1, 1), 2.f * aha(1, 2), aha(2, 2)};
+  const uint32_t clamped = shs != nullptr ? __float_as_uint(rec.colour(idx).w) : 0u;
+  Vec3 gm;
+  float dcov[6], ds[3] = {0.f, 0.f, 0.f}, dr[4] = {0.f, 0.f, 0.f, 0.f};
+  preprocess_backward_core(m, c3, from_sr, s0, s1, s2, scale_modifier, q, view, proj, campos, h_x, h_y,
+                           tan_fovx, tan_fovy, bgr, clamped, D,
+                           shs != nullptr ? shs + (size_t)idx * M * 3 : nullptr,
+                           shs != nullptr ? dL_dsh + (size_t)idx * M * 3 : nullptr, gm, dcov, ds, dr);
+  // coefficients above the active degree get no gradient (the training schedule raises sh_degree
+  // step by step while M stays (max_degree + 1)^2): written as zeros, nothing arrives zero-filled
+  if (shs != nullptr)
+    for (int e = 3 * (D + 1) * (D + 1); e < 3 * M; e++) dL_dsh[(size_t)idx * M * 3 + e] = 0.f;
   if (dL_dcov != nullptr) {
 #pragma unroll
     for (int e = 0; e < 6; e++) dL_dcov[6 * idx + e] = dcov[e];
   }
-  const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
-  float dA[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-      dA[i][j] = 2.f * (HA[i][0] * V[0][j] + HA[i][1] * V[1][j] + HA[i][2] * V[2][j]);
-
-  // ---- A = J W: the view rotation's rows are (v0 v4 v8), (v1 v5 v9), (v2 v6 v10) ----
-  const Vec3 W0 = {view[0], view[4], view[8]}, W1 = {view[1], view[5], view[9]}, W2 = {view[2], view[6], view[10]};
-  const Vec3 dA0 = {dA[0][0], dA[0][1], dA[0][2]}, dA1 = {dA[1][0], dA[1][1], dA[1][2]};
-  const float dJ00 = dot3(W0, dA0), dJ02 = dot3(W2, dA0);
-  const float dJ11 = dot3(W1, dA1), dJ12 = dot3(W2, dA1);
-  // J00 = hx / tz, J02 = -hx tx / tz^2, J11 = hy / tz, J12 = -hy ty / tz^2; no gradient through a
-  // tx / ty the forward clamped to the frustum guard band
-  const float itz = 1.f / cv.tz, itz2 = itz * itz, itz3 = itz2 * itz;
-  const float pass_x = (cv.txtz < -cv.limx || cv.txtz > cv.limx) ? 0.f : 1.f;
-  const float pass_y = (cv.tytz < -cv.limy || cv.tytz > cv.limy) ? 0.f : 1.f;
-  const Vec3 dt = {pass_x * (-h_x * itz2) * dJ02, pass_y * (-h_y * itz2) * dJ12,
-                   -h_x * itz2 * dJ00 - h_y * itz2 * dJ11 + (2.f * h_x * cv.tx) * itz3 * dJ02 +
-                       (2.f * h_y * cv.ty) * itz3 * dJ12};
-  // t = W m + translation
-  Vec3 gm = {W0.x * dt.x + W1.x * dt.y + W2.x * dt.z, W0.y * dt.x + W1.y * dt.y + W2.y * dt.z,
-             W0.z * dt.x + W1.z * dt.y + W2.z * dt.z};
-
-  // ---- mean2D = ndc2pix(proj m / w):  d(p_k / w)/dm_j = (P_kj - P_3j p_k / w) / w ----
-  {
-    const float w = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
-    const float iw = 1.0f / (w + 0.0000001f);
-    const float px_w2 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * iw * iw;
-    const float py_w2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * iw * iw;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const float add = (proj[4 * j] * iw - proj[4 * j + 3] * px_w2) * g2x +
-                        (proj[4 * j + 1] * iw - proj[4 * j + 3] * py_w2) * g2y;
-      if (j == 0) gm.x += add; else if (j == 1) gm.y += add; else gm.z += add;
-    }
-  }
-  // ---- depth = (view m)_z, with view row 3 treated as a divisor of weight depth (backward.cu:384-391) ----
-  {
-    const float depth = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
-    gm.x += (view[2] - view[3] * depth) * gdep;
-    gm.y += (view[6] - view[7] * depth) * gdep;
-    gm.z += (view[10] - view[11] * depth) * gdep;
-  }
-  if (shs != nullptr) {
-    const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
-    const Vec3 g = {(clamped & 1u) ? 0.f : gcr, (clamped & 2u) ? 0.f : gcg, (clamped & 4u) ? 0.f : gcb};
-    const Vec3 gs = sh_backward(D, shs + (size_t)idx * M * 3,
-                                Vec3{m.x - campos[0], m.y - campos[1], m.z - campos[2]}, g,
-                                dL_dsh + (size_t)idx * M * 3);
-    gm.x += gs.x; gm.y += gs.y; gm.z += gs.z;
-  }
   dL_dmeans[3 * idx] = gm.x;
   dL_dmeans[3 * idx + 1] = gm.y;
   dL_dmeans[3 * idx + 2] = gm.z;
-  if (scales == nullptr) {   // cov3D_precomp: the binding still returns (zero) scale / rotation gradients
-    if (dL_dscale != nullptr) { dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
-    if (dL_drot != nullptr) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
-    float ds[3], dr[4];
-    cov3d_backward(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q,
-                   dcov, ds, dr);
-    dL_dscale[3 * idx] = ds[0]; dL_dscale[3 * idx + 1] = ds[1]; dL_dscale[3 * idx + 2] = ds[2];
-    reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+  if (dL_dscale != nullptr) { dL_dscale[3 * idx] = ds[0]; dL_dscale[3 * idx + 1] = ds[1]; dL_dscale[3 * idx + 2] = ds[2]; }
+  if (dL_drot != nullptr) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Training backward of the FUSED scene-graph composition: the same
+// per-Gaussian core on values recomputed by compose_one(), then the chain rule through the
+// activations and the rigid actor transform down to the models' RAW parameters and the actors'
+// tracked poses -- what autograd would do through lib/models/street_gaussian_model.py:296-453:
+//   _scaling   s = exp(r)                 dL/dr = dL/ds * s
+//   _opacity   o = sigmoid(r)             dL/dr = dL/do * o (1 - o)
+//   _rotation  q = r / |r|                dL/dr = (g - q (q.g)) / |r|
+//     actor:   q = p / |p|, p = a (x) ql  (a = obj_rot as given, ql = r / |r|): through the
+//              normalisation, then the Hamilton product (bilinear) to ql and to a
+//   _xyz       actor: m = R(a / |a|) x + t     dL/dx = R^T g,  dL/dt = sum g,  dL/dR = sum g x^T
+//   _features_dc  sh_0 = sum_c dc_c idft_c     dL/ddc_c = dL/dsh_0 * idft_c;  _features_rest = sh_1..
+// Per actor the sums over its Gaussians (dL/dt 3, dL/dR 9, dL/da of the product 4) go to
+// pose_acc[segment][16] (LDS-aggregated per workgroup, then one float atomic per value);
+// pose_finish_kernel turns them into dL/d obj_rot (through R(a/|a|) and the normalisation) and
+// dL/d obj_trans.
+// ------------------------------------------------------------------------------------------
+struct SegmentGradDev {
+  float* xyz;
+  float* scaling;
+  float* rotation;
+  float* opacity;
+  float* fdc;
+  float* frest;
+};
+
+constexpr int POSE_ACC = 16;   // per segment: dL/dt (3), dL/dR row-major (9), dL/da product path (4)
+
+template <bool M4>
+__global__ void __launch_bounds__(256)
+preprocess_backward_composed_kernel(const int P, const int D, const int M,
+                                    const SegmentDev* __restrict__ segs,
+                                    const SegmentGradDev* __restrict__ gsegs, const int nseg,
+                                    const int* __restrict__ radii, const RecView rec,
+                                    const float scale_modifier, const float* __restrict__ view,
+                                    const float* __restrict__ proj, const float* __restrict__ campos,
+                                    const float h_x, const float h_y, const float tan_fovx,
+                                    const float tan_fovy, const float4* __restrict__ grad_rec,
+                                    float* __restrict__ dL_dmean2D, float* __restrict__ pose_acc) {
+  // one actor's sums, aggregated over the workgroup when all of its Gaussians belong to one segment
+  __shared__ float s_pose[POSE_ACC];
+  __shared__ int s_seg0;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < POSE_ACC) s_pose[threadIdx.x] = 0.f;
+  const int last = min(P, (int)(blockIdx.x + 1) * 256) - 1;
+  const SegmentDev* sg_first = find_segment(segs, nseg, (uint32_t)(blockIdx.x * 256));
+  const bool uniform = sg_first == find_segment(segs, nseg, (uint32_t)last);
+  if (threadIdx.x == 0) s_seg0 = (int)(sg_first - segs);
+  __syncthreads();
+  float pv[POSE_ACC];
+#pragma unroll
+  for (int i = 0; i < POSE_ACC; i++) pv[i] = 0.f;
+  const SegmentDev* sgp = nullptr;
+  if (idx < P) {
+    const SegmentDev& sg = *find_segment(segs, nseg, (uint32_t)idx);
+    sgp = &sg;
+    const SegmentGradDev& go = gsegs[&sg - segs];
+    const uint32_t j = (uint32_t)idx - sg.start;
+    const int F = sg.fourier_dim;
+    const bool vis = radii[idx] > 0;
+    if (!vis) {
+      dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
+      go.xyz[3 * j] = 0.f; go.xyz[3 * j + 1] = 0.f; go.xyz[3 * j + 2] = 0.f;
+      go.scaling[3 * j] = 0.f; go.scaling[3 * j + 1] = 0.f; go.scaling[3 * j + 2] = 0.f;
+      reinterpret_cast<float4*>(go.rotation)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      go.opacity[j] = 0.f;
+      for (int e = 0; e < 3 * F; e++) go.fdc[(size_t)j * F * 3 + e] = 0.f;
+      for (int e = 0; e < 3 * (M - 1); e++) go.frest[(size_t)j * (M - 1) * 3 + e] = 0.f;
+    } else {
+      const Activated a = compose_one(sg, j);
+      const BlendGrad bgr = load_blend_grad(grad_rec, idx);
+      dL_dmean2D[3 * idx] = bgr.g2x; dL_dmean2D[3 * idx + 1] = bgr.g2y; dL_dmean2D[3 * idx + 2] = bgr.gabs;
+      float c3[6];
+      cov3d_from_scale_rot(a.s0, a.s1, a.s2, scale_modifier, a.q, c3);
+      float sh[M4 ? 12 : 48], dsh[M4 ? 12 : 48];
+      compose_features(sg, j, a, M, sh);
+#pragma unroll
+      for (int e = 0; e < (M4 ? 12 : 48); e++) dsh[e] = 0.f;
+      const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
+      Vec3 gm;
+      float dcov[6], ds[3], dr[4];
+      preprocess_backward_core(Vec3{a.mx, a.my, a.mz}, c3, true, a.s0, a.s1, a.s2, scale_modifier, a.q, view,
+                               proj, campos, h_x, h_y, tan_fovx, tan_fovy, bgr, clamped, D, sh, dsh, gm, dcov,
+                               ds, dr);
+      // ---- activations ----
+      go.scaling[3 * j] = ds[0] * a.s0; go.scaling[3 * j + 1] = ds[1] * a.s1; go.scaling[3 * j + 2] = ds[2] * a.s2;
+      go.opacity[j] = bgr.gop * (a.opacity * (1.0f - a.opacity));
+      for (int c = 0; c < F; c++) {
+        go.fdc[((size_t)j * F + c) * 3 + 0] = dsh[0] * sg.idft[c];
+        go.fdc[((size_t)j * F + c) * 3 + 1] = dsh[1] * sg.idft[c];
+        go.fdc[((size_t)j * F + c) * 3 + 2] = dsh[2] * sg.idft[c];
+      }
+      for (int e = 0; e < 3 * (M - 1); e++) go.frest[(size_t)j * (M - 1) * 3 + e] = dsh[3 + e];
+      // ---- rotation: raw r -> ql = r / |r| [-> p = a (x) ql -> q = p / |p|] ----
+      const float4 rq = load_quat(sg.rotation, (int)j);
+      const float rn = fmaxf(sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w), 1e-12f);
+      const float4 ql = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+      float4 gql = make_float4(dr[0], dr[1], dr[2], dr[3]);   // dL/dq of the quaternion the op used
+      if (sg.rigid) {
+        const float aw = sg.rot[0], ax = sg.rot[1], ay = sg.rot[2], az = sg.rot[3];
+        const float ow = aw * ql.x - ax * ql.y - ay * ql.z - az * ql.w;
+        const float ox = aw * ql.y + ax * ql.x + ay * ql.w - az * ql.z;
+        const float oy = aw * ql.z - ax * ql.w + ay * ql.x + az * ql.y;
+        const float oz = aw * ql.w + ax * ql.z - ay * ql.y + az * ql.x;
+        const float pn = fmaxf(sqrtf(ow * ow + ox * ox + oy * oy + oz * oz), 1e-12f);
+        // through q = p / |p| (a.q is that q)
+        const float along = a.q.x * gql.x + a.q.y * gql.y + a.q.z * gql.z + a.q.w * gql.w;
+        const float gw = (gql.x - a.q.x * along) / pn, gx = (gql.y - a.q.y * along) / pn,
+                    gy = (gql.z - a.q.z * along) / pn, gz = (gql.w - a.q.w * along) / pn;
+        // through the Hamilton product (general_utils.py:220-238): p = a (x) b, b = ql
+        gql = make_float4(aw * gw + ax * gx + ay * gy + az * gz, -ax * gw + aw * gx + az * gy - ay * gz,
+                          -ay * gw - az * gx + aw * gy + ax * gz, -az * gw + ay * gx - ax * gy + aw * gz);
+        pv[12] = ql.x * gw + ql.y * gx + ql.z * gy + ql.w * gz;
+        pv[13] = -ql.y * gw + ql.x * gx - ql.w * gy + ql.z * gz;
+        pv[14] = -ql.z * gw + ql.w * gx + ql.x * gy - ql.y * gz;
+        pv[15] = -ql.w * gw - ql.z * gx + ql.y * gy + ql.x * gz;
+      }
+      {
+        const float along = ql.x * gql.x + ql.y * gql.y + ql.z * gql.z + ql.w * gql.w;
+        reinterpret_cast<float4*>(go.rotation)[j] =
+            make_float4((gql.x - ql.x * along) / rn, (gql.y - ql.y * along) / rn, (gql.z - ql.z * along) / rn,
+                        (gql.w - ql.w * along) / rn);
+      }
+      // ---- mean: world == local, or m = R(a / |a|) x + t ----
+      if (sg.rigid) {
+        const float x = sg.xyz[3 * j], y = sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
+        const float on = sqrtf(sg.rot[0] * sg.rot[0] + sg.rot[1] * sg.rot[1] + sg.rot[2] * sg.rot[2] +
+                               sg.rot[3] * sg.rot[3]);
+        const float r = sg.rot[0] / on, qx = sg.rot[1] / on, qy = sg.rot[2] / on, qz = sg.rot[3] / on;
+        const float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - r * qz), R02 = 2.f * (qx * qz + r * qy);
+        const float R10 = 2.f * (qx * qy + r * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - r * qx);
+        const float R20 = 2.f * (qx * qz - r * qy), R21 = 2.f * (qy * qz + r * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
+        go.xyz[3 * j] = R00 * gm.x + R10 * gm.y + R20 * gm.z;
+        go.xyz[3 * j + 1] = R01 * gm.x + R11 * gm.y + R21 * gm.z;
+        go.xyz[3 * j + 2] = R02 * gm.x + R12 * gm.y + R22 * gm.z;
+        pv[0] = gm.x; pv[1] = gm.y; pv[2] = gm.z;
+        pv[3] = gm.x * x; pv[4] = gm.x * y; pv[5] = gm.x * z;
+        pv[6] = gm.y * x; pv[7] = gm.y * y; pv[8] = gm.y * z;
+        pv[9] = gm.z * x; pv[10] = gm.z * y; pv[11] = gm.z * z;
+      } else {
+        go.xyz[3 * j] = gm.x; go.xyz[3 * j + 1] = gm.y; go.xyz[3 * j + 2] = gm.z;
+      }
+    }
   }
+  // ---- the actor's sums ----
+  const bool rigid_lane = sgp != nullptr && sgp->rigid != 0;
+  if (uniform) {
+    if (segs[s_seg0].rigid) {
+#pragma unroll
+      for (int i = 0; i < POSE_ACC; i++) {
+        float v = pv[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&s_pose[i], v);
+      }
+      __syncthreads();
+      if (threadIdx.x < POSE_ACC && s_pose[threadIdx.x] != 0.f)
+        atomicAdd(&pose_acc[(size_t)s_seg0 * POSE_ACC + threadIdx.x], s_pose[threadIdx.x]);
+    }
+  } else if (rigid_lane) {   // a workgroup across a model boundary (at most nseg - 1 of them)
+    const size_t sidx = (size_t)(sgp - segs);
+#pragma unroll
+    for (int i = 0; i < POSE_ACC; i++)
+      if (pv[i] != 0.f) atomicAdd(&pose_acc[sidx * POSE_ACC + i], pv[i]);
+  }
+}
+
+// pose_acc -> dL/d obj_rot (w, x, y, z), dL/d obj_trans: [segment][8] (last value unused)
+__global__ void pose_finish_kernel(const SegmentDev* __restrict__ segs, const int nseg,
+                                   const float* __restrict__ pose_acc, float* __restrict__ dL_dposes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  float* o = dL_dposes + 8 * (size_t)i;
+  if (!segs[i].rigid) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = 0.f;
+    return;
+  }
+  const float* p = pose_acc + (size_t)i * POSE_ACC;
+  const float G00 = p[3], G01 = p[4], G02 = p[5], G10 = p[6], G11 = p[7], G12 = p[8], G20 = p[9],
+              G21 = p[10], G22 = p[11];
+  const float aw = segs[i].rot[0], ax = segs[i].rot[1], ay = segs[i].rot[2], az = segs[i].rot[3];
+  const float on = sqrtf(aw * aw + ax * ax + ay * ay + az * az);
+  const float r = aw / on, x = ax / on, y = ay / on, z = az / on;
+  // dL/d(normalised quaternion) through R (general_utils.py:125-146)
+  const float gr = 2.f * (-z * G01 + y * G02 + z * G10 - x * G12 - y * G20 + x * G21);
+  const float gx = 2.f * (y * G01 + z * G02 + y * G10 - 2.f * x * G11 - r * G12 + z * G20 + r * G21 - 2.f * x * G22);
+  const float gy = 2.f * (-2.f * y * G00 + x * G01 + r * G02 + x * G10 + z * G12 - r * G20 + z * G21 - 2.f * y * G22);
+  const float gz = 2.f * (-2.f * z * G00 - r * G01 + x * G02 + r * G10 - 2.f * z * G11 + y * G12 + x * G20 + y * G21);
+  const float along = r * gr + x * gx + y * gy + z * gz;
+  o[0] = (gr - r * along) / on + p[12];
+  o[1] = (gx - x * along) / on + p[13];
+  o[2] = (gy - y * along) / on + p[14];
+  o[3] = (gz - z * along) / on + p[15];
+  o[4] = p[0]; o[5] = p[1]; o[6] = p[2];
+  o[7] = 0.f;
+}
+
+void launch_preprocess_backward_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs,
+                                         const void* seg_grads, int nseg, const int* radii,
+                                         const RecView rec, float scale_modifier, const CameraArgs& cam,
+                                         const float* grad_rec, float* dL_dmean2D, float* pose_acc,
+                                         float* dL_dposes) {
+  if (P <= 0) return;
+  (void)hipMemsetAsync(pose_acc, 0, (size_t)nseg * POSE_ACC * sizeof(float), s);
+#define PBC_LAUNCH(M4)                                                                              \
+  preprocess_backward_composed_kernel<M4><<<(P + 255) / 256, 256, 0, s>>>(                           \
+      P, D, M, segs, reinterpret_cast<const SegmentGradDev*>(seg_grads), nseg, radii, rec,            \
+      scale_modifier, cam.view, cam.proj, cam.campos, cam.focal_x, cam.focal_y, cam.tan_fovx,         \
+      cam.tan_fovy, reinterpret_cast<const float4*>(grad_rec), dL_dmean2D, pose_acc)
+  if (M == 4) PBC_LAUNCH(true); else PBC_LAUNCH(false);
+#undef PBC_LAUNCH
+  pose_finish_kernel<<<(nseg + 63) / 64, 64, 0, s>>>(segs, nseg, pose_acc, dL_dposes);
 }
 
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,

@@ -420,7 +420,7 @@ RasterizeGaussiansComposed(const torch::Tensor& background, const std::vector<to
                            const float scale_modifier, const torch::Tensor& viewmatrix,
                            const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
                            const int image_height, const int image_width, const int degree,
-                           const torch::Tensor& campos, const bool debug) {
+                           const torch::Tensor& campos, const bool debug, const bool for_backward) {
   SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
   const torch::Tensor& like = xyz[0];
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
@@ -444,15 +444,77 @@ RasterizeGaussiansComposed(const torch::Tensor& background, const std::vector<to
   int rendered;
   {
     pybind11::gil_scoped_release nogil;
-    rendered = grpg_forward_composed(
+    rendered = grpg_forward_composed_flags(
         resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, pk.segs.data(),
         (int)pk.segs.size(), degree, pk.M, p_bg, W, H, scale_modifier, p_view, p_proj, p_cam, tan_fovx,
         tan_fovy, out_color.data_ptr<float>(), out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
-        radii.data_ptr<int>(), debug ? 1 : 0, (void*)stream);
+        radii.data_ptr<int>(), debug ? 1 : 0, (void*)stream, for_backward ? 0u : GRPG_FORWARD_NO_BACKWARD);
   }
   if (rendered < 0) raise_abi_error("grpg_forward_composed", rendered);
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, geomBuffer, binningBuffer,
                          imgBuffer);
+}
+
+// Training backward of the fused composition (grpg_backward_composed): gradients with respect to
+// every model's RAW parameter tensors, means2D [P,3] (densification statistic) and the poses [n,8].
+std::tuple<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>,
+           std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>,
+           torch::Tensor, torch::Tensor>
+RasterizeGaussiansComposedBackward(
+    const torch::Tensor& background, const std::vector<torch::Tensor>& xyz,
+    const std::vector<torch::Tensor>& scaling, const std::vector<torch::Tensor>& rotation,
+    const std::vector<torch::Tensor>& opacity, const std::vector<torch::Tensor>& features_dc,
+    const std::vector<torch::Tensor>& features_rest, const torch::Tensor& poses, const torch::Tensor& idft,
+    const float scale_modifier, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+    const float tan_fovx, const float tan_fovy, const int degree, const torch::Tensor& campos,
+    const torch::Tensor& radii, const torch::Tensor& alphas, const torch::Tensor& geomBuffer, const int R,
+    const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+    const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_depth,
+    const torch::Tensor& dL_dout_alpha, const bool debug) {
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
+  const torch::Tensor& like = xyz[0];
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
+  const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+  const size_t n = xyz.size();
+  auto o = like.options().dtype(torch::kFloat32);
+  std::vector<torch::Tensor> g_xyz(n), g_scaling(n), g_rotation(n), g_opacity(n), g_fdc(n), g_frest(n);
+  std::vector<grpg_model_segment_grad> gs(n);
+  for (size_t i = 0; i < n; i++) {   // every element is written by the kernel: no zero-fill
+    g_xyz[i] = torch::empty(xyz[i].sizes(), o);
+    g_scaling[i] = torch::empty(scaling[i].sizes(), o);
+    g_rotation[i] = torch::empty(rotation[i].sizes(), o);
+    g_opacity[i] = torch::empty(opacity[i].sizes(), o);
+    g_fdc[i] = torch::empty(features_dc[i].sizes(), o);
+    g_frest[i] = torch::empty(features_rest[i].sizes(), o);
+    gs[i] = grpg_model_segment_grad{g_xyz[i].data_ptr<float>(), g_scaling[i].data_ptr<float>(),
+                                    g_rotation[i].data_ptr<float>(), g_opacity[i].data_ptr<float>(),
+                                    g_fdc[i].data_ptr<float>(),
+                                    g_frest[i].numel() ? g_frest[i].data_ptr<float>() : nullptr};
+  }
+  torch::Tensor dL_dmeans2D = torch::empty({pk.P, 3}, o);
+  torch::Tensor dL_dposes = torch::empty({(int64_t)n, 8}, o);
+  torch::Tensor k[7];
+  const float* p_bg = fptr(background, like, "background", k[0]);
+  const float* p_view = fptr(viewmatrix, like, "viewmatrix", k[1]);
+  const float* p_proj = fptr(projmatrix, like, "projmatrix", k[2]);
+  const float* p_cam = fptr(campos, like, "campos", k[3]);
+  const float* g_col = fptr(dL_dout_color, like, "dL_dout_color", k[4]);
+  const float* g_dep = fptr(dL_dout_depth, like, "dL_dout_depth", k[5]);
+  const float* g_alp = fptr(dL_dout_alpha, like, "dL_dout_alpha", k[6]);
+  torch::Tensor k_alpha;
+  const float* p_alpha = fptr(alphas, like, "alphas", k_alpha);
+  TORCH_CHECK(radii.scalar_type() == torch::kInt32 && radii.device() == like.device(),
+              "radii must be int32 on the device");
+  torch::Tensor radii_c = radii.contiguous();
+  torch::Tensor gb = geomBuffer.contiguous(), bb = binningBuffer.contiguous(), ib = imageBuffer.contiguous();
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const int rc = grpg_backward_composed(
+      pk.segs.data(), gs.data(), (int)n, degree, pk.M, R, p_bg, W, H, scale_modifier, p_view, p_proj, p_cam,
+      tan_fovx, tan_fovy, radii_c.data_ptr<int>(), p_alpha, reinterpret_cast<char*>(gb.data_ptr()),
+      reinterpret_cast<char*>(bb.data_ptr()), reinterpret_cast<char*>(ib.data_ptr()), g_col, g_dep, g_alp,
+      dL_dmeans2D.data_ptr<float>(), dL_dposes.data_ptr<float>(), debug ? 1 : 0, (void*)stream);
+  if (rc != GRPG_OK) raise_abi_error("grpg_backward_composed", rc);
+  return std::make_tuple(g_xyz, g_scaling, g_rotation, g_opacity, g_fdc, g_frest, dL_dmeans2D, dL_dposes);
 }
 
 // (means3D [P,3], scales [P,3], rotations [P,4], opacity [P,1], shs [P,M,3]): what the reference's
@@ -689,7 +751,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);
   // additions (not in the reference module)
   m.def("debug_export", &DebugExport);
-  m.def("rasterize_gaussians_composed", &RasterizeGaussiansComposed);
+  m.def("rasterize_gaussians_composed", &RasterizeGaussiansComposed, pybind11::arg("bg"), pybind11::arg("xyz"),
+        pybind11::arg("scaling"), pybind11::arg("rotation"), pybind11::arg("opacity"),
+        pybind11::arg("features_dc"), pybind11::arg("features_rest"), pybind11::arg("poses"),
+        pybind11::arg("idft"), pybind11::arg("scale_modifier"), pybind11::arg("viewmatrix"),
+        pybind11::arg("projmatrix"), pybind11::arg("tan_fovx"), pybind11::arg("tan_fovy"),
+        pybind11::arg("image_height"), pybind11::arg("image_width"), pybind11::arg("degree"),
+        pybind11::arg("campos"), pybind11::arg("debug"), pybind11::arg("for_backward") = false);
+  m.def("rasterize_gaussians_composed_backward", &RasterizeGaussiansComposedBackward);
   m.def("compose", &Compose);
   m.def("sky_composite", &SkyComposite, pybind11::arg("cube"), pybind11::arg("ray_matrix"),
         pybind11::arg("fill"), pybind11::arg("clamp_out"), pybind11::arg("rgb"), pybind11::arg("acc"),

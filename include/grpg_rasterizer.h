@@ -175,8 +175,10 @@ GRPG_API int grpg_frame_status(int ticket, int wait, int* num_rendered);
  * gaussian_model.py:224-251, gaussian_model_actor.py:73-82) -- about 20 small kernels and two
  * extra passes over the op's whole input.  grpg_forward_composed takes the models' RAW parameter
  * arrays and the per-frame actor poses instead and does that arithmetic inside preprocess; the
- * concatenated tensors never exist.  Forward only (eval / trajectory rendering, S = 0); training
- * keeps composing in PyTorch, where autograd needs the intermediates.
+ * concatenated tensors never exist.  S = 0.  Training: grpg_forward_composed_flags(flags = 0) +
+ * grpg_backward_composed return the gradients with respect to the RAW parameters and the poses
+ * (round 3; the flip augmentation of street_gaussian_model.py:286-293, the semantic concatenation
+ * :420-435 and pose-correction modules stay in the caller's PyTorch).
  *
  * A segment describes one model, in the order the reference concatenates them (background first,
  * then the visible actors, street_gaussian_model.py:232-262).  All pointers are device pointers to
@@ -212,6 +214,47 @@ GRPG_API int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_
                  float tan_fovx, float tan_fovy,
                  float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
                  void* hip_stream);
+
+/* grpg_forward_composed with the flags of grpg_forward_flags: flags == 0 keeps what a later
+ * grpg_backward_composed needs (n_contrib, room for the gradient records); grpg_forward_composed
+ * itself passes GRPG_FORWARD_NO_BACKWARD. */
+GRPG_API int grpg_forward_composed_flags(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 const grpg_model_segment* segments, int num_segments, int D, int M,
+                 const float* background, int width, int height, float scale_modifier,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy,
+                 float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
+                 void* hip_stream, unsigned flags);
+
+/*
+ * Training backward of the fused composition: the blend backward, the preprocess backward on the
+ * activated values recomputed from the RAW parameters, and the chain rule through the activations
+ * (exp / sigmoid / normalize), the Fourier DC sum, the actors' rigid transform and quaternion
+ * product -- i.e. what autograd does through lib/models/street_gaussian_model.py:296-453 -- down to
+ * the models' raw parameter arrays and the actors' poses.  `segments` as given to the forward;
+ * `grads[i]` holds six device arrays shaped like segment i's parameters, every element of which is
+ * WRITTEN (zeros for culled Gaussians).  dL_dmean2D [P,3] as in grpg_backward (densification
+ * statistic); dL_dposes device [num_segments][8]: dL/d obj_rot (w,x,y,z), dL/d obj_trans (x,y,z),
+ * one unused value -- zeros for static models.  S = 0.
+ */
+typedef struct grpg_model_segment_grad {
+  float* xyz;
+  float* scaling;
+  float* rotation;
+  float* opacity;
+  float* features_dc;
+  float* features_rest;        /* NULL when M == 1 */
+} grpg_model_segment_grad;
+GRPG_API int grpg_backward_composed(const grpg_model_segment* segments,
+                 const grpg_model_segment_grad* grads, int num_segments, int D, int M, int R,
+                 const float* background, int width, int height, float scale_modifier,
+                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii, const float* alphas,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer,
+                 const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                 float* dL_dmean2D, float* dL_dposes, int debug, void* hip_stream);
 
 /* The composition alone: writes the activated, concatenated tensors the reference's properties
  * return (get_xyz [P,3], get_scaling [P,3], get_rotation [P,4], get_opacity [P], get_features

@@ -98,6 +98,8 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0):
         _grad_close("dL_dcolors", col.grad.cpu(), ref["dL_dcolors"])
     else:
         _grad_close("dL_dsh", shs.grad.cpu(), ref["dL_dsh"])
+        nact = (sc.sh_degree + 1) ** 2
+        assert float(shs.grad[:, nact:].abs().max() if shs.shape[1] > nact else 0.0) == 0.0
     if use_cov:
         _grad_close("dL_dcov3D", covd.grad.cpu(), ref["dL_dcov3D"])
     else:
@@ -117,6 +119,16 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0):
 def test_backward_sh_scale_rot(dev, deg):
     sc = hz.toy_scene(1500, seed=30 + deg, sh_degree=deg, scale=0.1)
     _run(dev, sc, hz.trajectory_camera(0, W=112, H=80), torch.tensor([0.3, 0.1, 0.6]), seed=deg)
+
+
+def test_backward_active_degree_below_max(dev):
+    """Training raises the active SH degree step by step while the tensors keep (max_degree + 1)^2
+    coefficients (gaussian_model.py:oneupSHdegree): with 16 coefficients stored and degree 1 active,
+    coefficients 4..15 must come back with an exactly zero gradient (the op writes every element of
+    its gradient arrays itself -- nothing arrives zero-filled), the rest must match the oracle."""
+    sc = hz.toy_scene(1500, seed=41, sh_degree=3, scale=0.1)._replace(sh_degree=1)
+    assert sc.shs.shape[1] == 16
+    _run(dev, sc, hz.trajectory_camera(0, W=112, H=80), torch.tensor([0.2, 0.3, 0.1]), seed=9)
 
 
 def test_backward_street(dev):
