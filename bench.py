@@ -67,8 +67,7 @@ from gaussianrpg_amd import trajectory as tj  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 # chip-wide VALU issue peak measured by tools/ubench/valu_rate.hip on an MI355X (profiles/round3_valu_rate.txt):
 # wave64 v_fma_f32 instructions per second with 8 resident waves per SIMD on all 1024 SIMDs
-VALU_PEAK_GINSTR = 848.0
-VALU_CLOCK_GHZ = 2.4           # hipDeviceProp clockRate; SQ_ACTIVE_INST_VALU counts quad-cycles of it
+VALU_PEAK_GINSTR = 825.0
 NUM_FRAMES = 200               # poses of the synthetic drive (BASELINE config 4)
 P_GAUSS = 2_000_000            # "Waymo scene 002 full Street-Gaussians (~2M)" stand-in
 SCENE_SEED = 2
@@ -679,23 +678,31 @@ def main():
                          "pair_evals_definition": "sum over pixels of n_contrib (list entries a pixel walks "
                                                   "before it terminates: what the reference's schedule evaluates)"}
             if pmc and pmc.get("SQ_INSTS_VALU"):
-                simds, clk = 1024, VALU_CLOCK_GHZ * 1e9
-                busy_s = pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (simds * clk)
+                # VALU busy share from counters alone, no clock assumed: SQ_ACTIVE_INST_VALU counts
+                # quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+                busy = None
+                if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+                    busy = (pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
                 roof_valu.update({
                     "wave_valu_instructions_per_launch": pmc["SQ_INSTS_VALU"],
                     "valu_busy_quad_cycles_per_launch": pmc.get("SQ_ACTIVE_INST_VALU"),
-                    "valu_busy_ms": busy_s * 1e3,
-                    "frac": busy_s / (serial_render_ms * 1e-3),
+                    "kernel_cycles_per_launch": pmc["GRBM_GUI_ACTIVE"] / 8.0 if pmc.get("GRBM_GUI_ACTIVE") else None,
+                    "frac": busy,
+                    "frac_definition": "share of the kernel's cycles in which a SIMD's vector ALU is executing, averaged "
+                                       "over the 1024 SIMDs: (SQ_ACTIVE_INST_VALU x 4 / 1024) / (GRBM_GUI_ACTIVE / 8), "
+                                       "both from the committed PMC passes of this workload",
+                    "cycles_per_valu_instruction": (pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / pmc["SQ_INSTS_VALU"]
+                                                    if pmc.get("SQ_ACTIVE_INST_VALU") else None),
                     "instr_per_s": pmc["SQ_INSTS_VALU"] / (serial_render_ms * 1e-3),
                     "peak_instr_per_s": VALU_PEAK_GINSTR * 1e9,
                     "frac_of_peak_instr_rate": pmc["SQ_INSTS_VALU"] / (serial_render_ms * 1e-3) / (VALU_PEAK_GINSTR * 1e9),
                     "peak_source": "tools/ubench/valu_rate.hip (profiles/round3_valu_rate.txt): %.0f G wave-instr/s "
-                                   "chip-wide for dependency-free v_fma_f32; v_pk_fma_f32 / v_pk_mul_f32 issue at "
-                                   "about 0.55x and v_exp_f32 at 0.36x that rate, so a mix of them saturates the "
-                                   "VALU below the plain-fma instruction rate (frac = busy time, the real bound)"
+                                   "chip-wide for dependency-free v_fma_f32 (2.25 cycles per instruction and SIMD at "
+                                   "the 1.8-2.2 GHz the part sustains under full VALU load); v_pk_fma_f32 / "
+                                   "v_pk_mul_f32 need 4.15 cycles and v_exp_f32 8.1, so a mix of them saturates the "
+                                   "VALU below the plain-fma instruction rate: frac (busy cycles) is the bound"
                                    % VALU_PEAK_GINSTR,
-                    "counters_source": pmc_file,
-                    "clock_ghz_assumed": VALU_CLOCK_GHZ})
+                    "counters_source": pmc_file})
         # reference-schedule traffic: what CR/rasterizer_impl.cu moves per frame on top of
         # the algorithmic bytes -- 64-bit keys + 32-bit values through a 6-pass sort, per-pixel ranges
         b_ref = b_frame + 128.0 * R_avg + 27.0 * V_avg + 16.0 * P

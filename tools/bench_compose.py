@@ -80,5 +80,52 @@ def run_fused(f):
 
 a = hz.time_frames(run_ref, 60)
 b = hz.time_frames(run_fused, 60)
+
+# training step (forward + backward to the RAW parameters): PyTorch composition with autograd + the
+# classic op, against the fused op's own backward (grpg_backward_composed)
+train_models = [ModelParams(*(t.clone().requires_grad_(True) for t in m)) for m in models]
+
+
+def train_ref(f):
+    global models
+    keep, models = models, train_models
+    try:
+        x, s, r, o, sh = torch_compose(poses_at(f))
+    finally:
+        models = keep
+    m2d = torch.zeros(x.shape[0], 3, device=dev, requires_grad=True)
+    c, _, d, al, _ = GaussianRasterizer(rss[f])(means3D=x, means2D=m2d, opacities=o, shs=sh, scales=s, rotations=r)
+    (c.mean() + 0.1 * d.mean() + al.mean()).backward()
+
+
+def train_fused(f):
+    P = sum(m.xyz.shape[0] for m in train_models)
+    m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+    c, _, d, al = ComposedRasterizer(rss[f])(train_models, poses_at(f), means2D=m2d)
+    (c.mean() + 0.1 * d.mean() + al.mean()).backward()
+
+
+def zero_grads():
+    for m in train_models:
+        for t in m:
+            t.grad = None
+
+
+def time_train(fn, n=24):
+    ts = []
+    for k in range(n):
+        zero_grads()
+        torch.cuda.synchronize(); t0 = time.time()
+        fn(k)
+        torch.cuda.synchronize(); ts.append((time.time() - t0) * 1e3)
+    ts = sorted(ts[2:])
+    return {"iterations": len(ts), "median_ms": ts[len(ts) // 2], "p95_ms": ts[int(0.95 * len(ts))]}
+
+
+ta = time_train(train_ref)
+tb = time_train(train_fused)
 print(json.dumps({"what": "scene-graph composition + forward op, 1.9 M background + 10 actors x 10 k, 1920x1280",
-                  "torch_composition_then_op_ms": a, "fused_composed_op_ms": b}))
+                  "torch_composition_then_op_ms": a, "fused_composed_op_ms": b,
+                  "train_step": {"what": "forward + backward down to the raw parameters (loss = mean colour + "
+                                         "0.1 mean depth + mean alpha), synchronize-bracketed wall time",
+                                 "torch_composition_autograd_plus_op_ms": ta, "fused_composed_op_ms": tb}}))
