@@ -211,36 +211,22 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   auto o = means3D.options();
   // The reference zero-fills eleven gradient arrays per call (rasterize_points.cu:166-176) because
   // its kernels accumulate into them.  Here the blend backward accumulates into per-Gaussian
-  // records inside the geometry blob and the preprocess backward WRITES every element of the ten
-  // non-semantic arrays (zeros for culled Gaussians), so they are carved uninitialised from two
-  // allocations; only dL_dsemantic (float atomics straight into it) is zero-filled.  Pool A holds
-  // the gradients a training step keeps as .grad (means3D, means2D, opacity, sh, scales,
-  // rotations), pool B the internal ones and those autograd normally drops (colors, depths, conic,
-  // cov3D), so a retained .grad does not pin the scratch arrays.
-  // gradients of absent optional inputs (colors_precomp, cov3D_precomp) and the two pure
-  // intermediates of the reference's binding (dL_dconic, dL_ddepths) are not materialised at all:
-  // the library takes NULL for them
+  // records inside the geometry blob and the preprocess backward WRITES every element of the
+  // non-semantic arrays (zeros for culled Gaussians): they are allocated uninitialised, each as a
+  // tensor of its own (autograd's AccumulateGrad can then adopt them as .grad without a copy, which
+  // it cannot do with views into a pool -- 92 MB of clones per step at P = 1 M); only dL_dsemantic
+  // (float atomics straight into it) is zero-filled.  Gradients of absent optional inputs
+  // (colors_precomp, cov3D_precomp) and the two pure intermediates of the reference's binding
+  // (dL_dconic, dL_ddepths) are not materialised at all: the library takes NULL for them.
   const bool want_colors = colors.numel() != 0, want_cov = cov3D_precomp.numel() != 0;
-  const int64_t widths[11] = {3, 3, want_colors ? GRPG_NUM_CHANNELS : 0, 0, 0, 1, want_cov ? 6 : 0,
-                              (int64_t)M * 3, 3, 4, 0};
-  const int pool_of[11] = {0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0};
-  int64_t offs[11], size[2] = {0, 0};
-  for (int i = 0; i < 11; i++) {
-    offs[i] = size[pool_of[i]];
-    size[pool_of[i]] += (((int64_t)P * widths[i] + 63) / 64) * 64;
-  }
-  torch::Tensor pools[2] = {torch::empty({size[0]}, o), torch::empty({size[1]}, o)};
-  auto view = [&](int i, std::vector<int64_t> shape) {
-    return pools[pool_of[i]].narrow(0, offs[i], (int64_t)P * widths[i]).view(shape);
-  };
-  torch::Tensor dL_dmeans3D = view(0, {P, 3});
-  torch::Tensor dL_dmeans2D = view(1, {P, 3});
-  torch::Tensor dL_dcolors = want_colors ? view(2, {P, GRPG_NUM_CHANNELS}) : torch::empty({0, GRPG_NUM_CHANNELS}, o);
-  torch::Tensor dL_dopacity = view(5, {P, 1});
-  torch::Tensor dL_dcov3D = want_cov ? view(6, {P, 6}) : torch::empty({0, 6}, o);
-  torch::Tensor dL_dsh = view(7, {P, M, 3});
-  torch::Tensor dL_dscales = view(8, {P, 3});
-  torch::Tensor dL_drotations = view(9, {P, 4});
+  torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o);
+  torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
+  torch::Tensor dL_dcolors = torch::empty({want_colors ? P : 0, GRPG_NUM_CHANNELS}, o);
+  torch::Tensor dL_dopacity = torch::empty({P, 1}, o);
+  torch::Tensor dL_dcov3D = torch::empty({want_cov ? P : 0, 6}, o);
+  torch::Tensor dL_dsh = torch::empty({P, M, 3}, o);
+  torch::Tensor dL_dscales = torch::empty({P, 3}, o);
+  torch::Tensor dL_drotations = torch::empty({P, 4}, o);
   torch::Tensor dL_dsemantic = torch::zeros({P, S}, o);
 
   if (P != 0) {
