@@ -332,7 +332,32 @@ namespace {
 // Pinned staging for the composed forward's segment table (thread-local; the frame's one host wait
 // guarantees the previous upload has been consumed before the buffer is reused).
 thread_local SegmentDev* g_seg_staging = nullptr;
-thread_local grpg_model_segment_grad* g_seg_grad_staging = nullptr;
+
+// grpg_backward_composed returns without a host wait, so the pinned tables its asynchronous copies
+// read must outlive the call: a ring of slots, each guarded by an event recorded behind its copies
+// (a slot comes round again 8 backward calls later; its event has long fired by then).
+struct BwdStagingSlot {
+  SegmentDev* segs = nullptr;
+  grpg_model_segment_grad* grads = nullptr;
+  hipEvent_t ev = nullptr;
+  bool used = false;
+};
+constexpr int BWD_STAGING_SLOTS = 8;
+thread_local BwdStagingSlot g_bwd_staging[BWD_STAGING_SLOTS];
+thread_local int g_bwd_staging_next = 0;
+BwdStagingSlot* bwd_staging_acquire() {
+  BwdStagingSlot& b = g_bwd_staging[g_bwd_staging_next];
+  g_bwd_staging_next = (g_bwd_staging_next + 1) % BWD_STAGING_SLOTS;
+  if (!b.segs) {
+    if (hipHostMalloc((void**)&b.segs, sizeof(SegmentDev) * MAX_SEGMENTS, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&b.grads, sizeof(grpg_model_segment_grad) * MAX_SEGMENTS, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  }
+  if (b.used) (void)hipEventSynchronize(b.ev);
+  b.used = true;
+  return &b;
+}
 
 // Shared body of grpg_forward (segs == NULL: flat input tensors) and grpg_forward_composed (segs:
 // per-model raw parameters, P = sum of their counts, the flat pointers are NULL).
@@ -897,14 +922,11 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
   (void)R;
   // tables: the segments (as in the forward; re-uploaded: the caller may hand over other arrays of
   // the same values) and the six output pointers per segment, through pinned staging
-  if (!g_seg_staging)
-    HIP_TRY(hipHostMalloc((void**)&g_seg_staging, sizeof(SegmentDev) * MAX_SEGMENTS, hipHostMallocDefault));
-  if (!g_seg_grad_staging)
-    HIP_TRY(hipHostMalloc((void**)&g_seg_grad_staging, sizeof(grpg_model_segment_grad) * MAX_SEGMENTS,
-                          hipHostMallocDefault));
+  BwdStagingSlot* stg = bwd_staging_acquire();
+  if (!stg) return fail(GRPG_ERR_HIP, "pinned staging allocation failed");
   uint32_t start = 0;
   for (int i = 0; i < num_segments; i++) {
-    SegmentDev& d = g_seg_staging[i];
+    SegmentDev& d = stg->segs[i];
     const grpg_model_segment& g = segments[i];
     d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
     d.fdc = g.features_dc; d.frest = g.features_rest;
@@ -915,14 +937,15 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
     d.pad0 = 0.f;
     for (int k = 0; k < MAX_FOURIER; k++) d.idft[k] = g.idft[k];
     start += (uint32_t)g.count;
-    g_seg_grad_staging[i] = grads[i];
+    stg->grads[i] = grads[i];
   }
   SegmentDev* seg_dev = (SegmentDev*)(geom_buffer + GL.seg_table);
   void* seg_grad_dev = (void*)(geom_buffer + GL.seg_grad_table);
-  HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)num_segments,
+  HIP_TRY(hipMemcpyAsync(seg_dev, stg->segs, sizeof(SegmentDev) * (size_t)num_segments,
                          hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(seg_grad_dev, g_seg_grad_staging,
-                         sizeof(grpg_model_segment_grad) * (size_t)num_segments, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(seg_grad_dev, stg->grads, sizeof(grpg_model_segment_grad) * (size_t)num_segments,
+                         hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipEventRecord(stg->ev, stream));
   float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
   HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
   launch_render_backward(stream, ranges, point_list, rec, nullptr, 0, width, height, cam.gx, cam.gy,
