@@ -21,10 +21,10 @@ returns the gradients with respect to the RAW parameters (``_xyz``, ``_scaling``
 ``_opacity``, ``_features_dc``, ``_features_rest``) and the poses: the chain rule through exp /
 sigmoid / normalize, the Fourier DC sum, the rigid transform and the quaternion product runs inside
 the preprocess backward kernel.  ``means2D`` (zeros ``[P,3]`` requiring grad, as
-street_gaussian_renderer.py:157-162 creates it) receives the densification statistic.  Not fused
-(stay in the caller's PyTorch): the flip augmentation of actors (street_gaussian_model.py:286-293),
-the semantic concatenation (:420-435) and pose-correction modules -- a corrected pose is simply an
-``obj_rot`` / ``obj_trans`` tensor with a graph behind it.
+street_gaussian_renderer.py:157-162 creates it) receives the densification statistic.  The flip
+augmentation of rigid actors (street_gaussian_model.py:286-293) is ``ModelParams.flip``.  Not fused
+(stay in the caller's PyTorch): the semantic concatenation (:420-435) and pose-correction modules
+-- a corrected pose is simply an ``obj_rot`` / ``obj_trans`` tensor with a graph behind it.
 """
 import math
 from typing import List, NamedTuple, Optional, Sequence
@@ -41,13 +41,17 @@ class ModelParams(NamedTuple):
     """Raw (pre-activation) parameters of one Gaussian model, as the reference stores them
     (gaussian_model.py:36-47): ``_xyz [N,3]``, ``_scaling [N,3]`` (log), ``_rotation [N,4]``,
     ``_opacity [N,1]`` (logit), ``_features_dc [N,F,3]`` (F = fourier_dim, 1 for the background),
-    ``_features_rest [N,M-1,3]``."""
+    ``_features_rest [N,M-1,3]``.  ``flip`` (optional, bool ``[N]``): this iteration's flip mask of a
+    rigid actor -- the training symmetry prior, ``torch.rand_like(xyz[:, 0]) < flip_prob``
+    (street_gaussian_model.py:286-293); flipped Gaussians have their local y mirrored and their local
+    rotation pre-multiplied by the quaternion of diag(-1, 1, -1) (:57-61, :332, :360)."""
     xyz: torch.Tensor
     scaling: torch.Tensor
     rotation: torch.Tensor
     opacity: torch.Tensor
     features_dc: torch.Tensor
     features_rest: torch.Tensor
+    flip: Optional[torch.Tensor] = None
 
 
 class ActorPose(NamedTuple):
@@ -110,7 +114,9 @@ def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
             times.append(float(p.fourier_time))
     pose_t = torch.tensor(rows, dtype=torch.float32).reshape(len(models), 8)
     idft_t = _idft_rows(times, dims)
-    lists = [[getattr(m, f) for m in models] for f in ModelParams._fields]
+    lists = [[getattr(m, f) for m in models] for f in ModelParams._fields[:6]]
+    none = torch.empty(0, dtype=torch.bool)
+    lists.append([none if m.flip is None else m.flip for m in models])
     return lists, pose_t, idft_t
 
 
@@ -127,13 +133,13 @@ class _ComposedRasterize(torch.autograd.Function):
     _C.rasterize_gaussians_composed_backward (C ABI grpg_backward_composed)."""
 
     @staticmethod
-    def forward(ctx, rs, nm, pose_t, idft_t, pose_rot, pose_trans, means2D, *flat):
+    def forward(ctx, rs, nm, pose_t, idft_t, flips, pose_rot, pose_trans, means2D, *flat):
         lists = [list(flat[f * nm:(f + 1) * nm]) for f in range(6)]
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians_composed(
-            rs.bg, *lists, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.bg, *lists, flips, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
             rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug, True)
         ctx.rs, ctx.nm, ctx.num_rendered = rs, nm, num_rendered
-        ctx.pose_t, ctx.idft_t = pose_t, idft_t
+        ctx.pose_t, ctx.idft_t, ctx.flips = pose_t, idft_t, flips
         ctx.pose_dev = (None if pose_rot is None else pose_rot.device,
                         None if pose_trans is None else pose_trans.device)
         ctx.save_for_backward(radii, alpha, geom, binning, img, *flat)
@@ -148,17 +154,17 @@ class _ComposedRasterize(torch.autograd.Function):
         lists = [list(flat[f * nm:(f + 1) * nm]) for f in range(6)]
         zeros = lambda t: torch.zeros_like(t)   # noqa: E731  (an output the loss does not touch)
         gx, gs, gr, go, gdc, gfr, g_means2D, g_poses = _C.rasterize_gaussians_composed_backward(
-            rs.bg, *lists, ctx.pose_t, ctx.idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
+            rs.bg, *lists, ctx.flips, ctx.pose_t, ctx.idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
             rs.tanfovx, rs.tanfovy, rs.sh_degree, rs.campos, radii, alpha, geom, ctx.num_rendered,
             binning, img, g_color if g_color is not None else zeros(alpha).expand(3, -1, -1).contiguous(),
             g_depth if g_depth is not None else zeros(alpha),
             g_alpha if g_alpha is not None else zeros(alpha), rs.debug)
         need = ctx.needs_input_grad
-        g_rot = g_poses[:, 0:4].to(ctx.pose_dev[0]) if need[4] else None
-        g_trans = g_poses[:, 4:7].to(ctx.pose_dev[1]) if need[5] else None
+        g_rot = g_poses[:, 0:4].to(ctx.pose_dev[0]) if need[5] else None
+        g_trans = g_poses[:, 4:7].to(ctx.pose_dev[1]) if need[6] else None
         grads = [g for per_field in (gx, gs, gr, go, gdc, gfr) for g in per_field]
-        flat_grads = tuple(g if n else None for g, n in zip(grads, need[7:]))
-        return (None, None, None, None, g_rot, g_trans, g_means2D if need[6] else None) + flat_grads
+        flat_grads = tuple(g if n else None for g, n in zip(grads, need[8:]))
+        return (None, None, None, None, None, g_rot, g_trans, g_means2D if need[7] else None) + flat_grads
 
 
 class ComposedRasterizer(nn.Module):
@@ -173,7 +179,8 @@ class ComposedRasterizer(nn.Module):
     def forward(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]], means2D=None):
         rs = self.raster_settings
         lists, pose_t, idft_t = _pack(models, poses)
-        flat = [t for per_field in lists for t in per_field]
+        flips = lists[6]
+        flat = [t for per_field in lists[:6] for t in per_field]
         pose_tensors = [t for p in poses if p is not None for t in (p.obj_rot, p.obj_trans)
                         if isinstance(t, torch.Tensor)]
         train = torch.is_grad_enabled() and any(
@@ -195,4 +202,4 @@ class ComposedRasterizer(nn.Module):
                 torch.tensor([float(x) for x in v], device=dev)   # noqa: E731
             pose_rot = torch.stack([one.to(dev) if p is None else as_t(p.obj_rot, dev) for p in poses])
             pose_trans = torch.stack([zero3.to(dev) if p is None else as_t(p.obj_trans, dev) for p in poses])
-        return _ComposedRasterize.apply(rs, len(models), pose_t, idft_t, pose_rot, pose_trans, means2D, *flat)
+        return _ComposedRasterize.apply(rs, len(models), pose_t, idft_t, flips, pose_rot, pose_trans, means2D, *flat)

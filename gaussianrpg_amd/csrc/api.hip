@@ -478,7 +478,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
         SegmentDev& d = g_seg_staging[i];
         const grpg_model_segment& g = segs[i];
         d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
-        d.fdc = g.features_dc; d.frest = g.features_rest;
+        d.fdc = g.features_dc; d.frest = g.features_rest; d.flip = g.flip; d.pad1 = nullptr;
         d.start = start; d.count = (uint32_t)g.count;
         d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
         for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];
@@ -929,7 +929,7 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
     SegmentDev& d = stg->segs[i];
     const grpg_model_segment& g = segments[i];
     d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
-    d.fdc = g.features_dc; d.frest = g.features_rest;
+    d.fdc = g.features_dc; d.frest = g.features_rest; d.flip = g.flip; d.pad1 = nullptr;
     d.start = start; d.count = (uint32_t)g.count;
     d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
     for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];
@@ -976,7 +976,7 @@ int grpg_compose(const grpg_model_segment* segments, int num_segments, int M, fl
     SegmentDev& d = host[(size_t)i];
     const grpg_model_segment& g = segments[i];
     d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
-    d.fdc = g.features_dc; d.frest = g.features_rest;
+    d.fdc = g.features_dc; d.frest = g.features_rest; d.flip = g.flip; d.pad1 = nullptr;
     d.start = start; d.count = (uint32_t)g.count;
     d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
     for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];

@@ -115,6 +115,8 @@ struct SegmentDev {
   const float* opacity;
   const float* fdc;
   const float* frest;
+  const unsigned char* flip; // per-Gaussian flip mask (training symmetry prior) or NULL
+  const void* pad1;
   uint32_t start, count;     // index range [start, start + count) in concatenation order
   int fourier_dim, rigid;
   float rot[4];

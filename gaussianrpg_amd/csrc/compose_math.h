@@ -20,8 +20,8 @@ namespace grpg {
 //                                                        general_utils.py:220-238
 //   actor colour = cat(sum_c _features_dc[:, c] * IDFT(time)[c], _features_rest)
 //                                                        lib/models/gaussian_model_actor.py:73-82
-// (the training-time flip augmentation, street_gaussian_model.py:286-293, is not part of
-// evaluation: flip_prob applies in train mode only).  One rounding per operation, no contraction:
+// The training-time flip augmentation (street_gaussian_model.py:286-293; flip_prob applies in
+// train mode only) is the optional per-Gaussian `flip` mask of a segment.  One rounding per operation, no contraction:
 // grpg_compose and grpg_forward_composed see bit-identical values.
 // ------------------------------------------------------------------------------------------
 struct Activated {
@@ -42,14 +42,20 @@ __device__ __forceinline__ const SegmentDev* find_segment(const SegmentDev* __re
 
 __device__ __forceinline__ Activated compose_one(const SegmentDev& sg, const uint32_t j) {
   Activated a;
-  const float x = sg.xyz[3 * j], y = sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
+  // symmetry prior of rigid actors in training (street_gaussian_model.py:57-61,286-293,332,360): a
+  // flipped Gaussian has its local y mirrored and its local rotation pre-multiplied by the
+  // quaternion of diag(-1, 1, -1) = (0, 0, 1, 0) -- a signed permutation, exact in fp32
+  const bool flip = sg.flip != nullptr && sg.flip[j] != 0;
+  const float x = sg.xyz[3 * j], y = flip ? -sg.xyz[3 * j + 1] : sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
   a.s0 = expf(sg.scaling[3 * j]);
   a.s1 = expf(sg.scaling[3 * j + 1]);
   a.s2 = expf(sg.scaling[3 * j + 2]);
   a.opacity = 1.0f / (1.0f + expf(-sg.opacity[j]));
   const float4 rq = load_quat(sg.rotation, (int)j);
   const float rn = fmaxf(sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w), 1e-12f);
-  const float4 ql = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+  const float4 qn_ = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+  // (0,0,1,0) (x) (w,x,y,z) = (-y, z, w, -x)
+  const float4 ql = flip ? make_float4(-qn_.z, qn_.w, qn_.x, -qn_.y) : qn_;
   if (sg.rigid) {
     // quaternion_to_matrix normalises obj_rots first (general_utils.py:126-128)
     const float on = sqrtf(sg.rot[0] * sg.rot[0] + sg.rot[1] * sg.rot[1] + sg.rot[2] * sg.rot[2] +

@@ -400,9 +400,11 @@ preprocess_backward_composed_kernel(const int P, const int D, const int M,
       }
       for (int e = 0; e < 3 * (M - 1); e++) go.frest[(size_t)j * (M - 1) * 3 + e] = dsh[3 + e];
       // ---- rotation: raw r -> ql = r / |r| [-> p = a (x) ql -> q = p / |p|] ----
+      const bool flip = sg.flip != nullptr && sg.flip[j] != 0;
       const float4 rq = load_quat(sg.rotation, (int)j);
       const float rn = fmaxf(sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w), 1e-12f);
-      const float4 ql = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+      const float4 qn_ = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+      const float4 ql = flip ? make_float4(-qn_.z, qn_.w, qn_.x, -qn_.y) : qn_;   // as in compose_one
       float4 gql = make_float4(dr[0], dr[1], dr[2], dr[3]);   // dL/dq of the quaternion the op used
       if (sg.rigid) {
         const float aw = sg.rot[0], ax = sg.rot[1], ay = sg.rot[2], az = sg.rot[3];
@@ -424,14 +426,17 @@ preprocess_backward_composed_kernel(const int P, const int D, const int M,
         pv[15] = -ql.w * gw - ql.z * gx + ql.y * gy + ql.x * gz;
       }
       {
-        const float along = ql.x * gql.x + ql.y * gql.y + ql.z * gql.z + ql.w * gql.w;
+        // back through the flip's signed permutation ql = (-n.y', n.z', n.w', -n.x') of the normalised
+        // local quaternion n = (w, x, y, z): dL/dn = (g_y, -g_z, -g_w, g_x) in (w, x, y, z) order
+        const float4 gn = flip ? make_float4(gql.z, -gql.w, -gql.x, gql.y) : gql;
+        const float along = qn_.x * gn.x + qn_.y * gn.y + qn_.z * gn.z + qn_.w * gn.w;
         reinterpret_cast<float4*>(go.rotation)[j] =
-            make_float4((gql.x - ql.x * along) / rn, (gql.y - ql.y * along) / rn, (gql.z - ql.z * along) / rn,
-                        (gql.w - ql.w * along) / rn);
+            make_float4((gn.x - qn_.x * along) / rn, (gn.y - qn_.y * along) / rn, (gn.z - qn_.z * along) / rn,
+                        (gn.w - qn_.w * along) / rn);
       }
       // ---- mean: world == local, or m = R(a / |a|) x + t ----
       if (sg.rigid) {
-        const float x = sg.xyz[3 * j], y = sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
+        const float x = sg.xyz[3 * j], y = flip ? -sg.xyz[3 * j + 1] : sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
         const float on = sqrtf(sg.rot[0] * sg.rot[0] + sg.rot[1] * sg.rot[1] + sg.rot[2] * sg.rot[2] +
                                sg.rot[3] * sg.rot[3]);
         const float r = sg.rot[0] / on, qx = sg.rot[1] / on, qy = sg.rot[2] / on, qz = sg.rot[3] / on;
@@ -439,14 +444,14 @@ preprocess_backward_composed_kernel(const int P, const int D, const int M,
         const float R10 = 2.f * (qx * qy + r * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - r * qx);
         const float R20 = 2.f * (qx * qz - r * qy), R21 = 2.f * (qy * qz + r * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
         go.xyz[3 * j] = R00 * gm.x + R10 * gm.y + R20 * gm.z;
-        go.xyz[3 * j + 1] = R01 * gm.x + R11 * gm.y + R21 * gm.z;
+        go.xyz[3 * j + 1] = (flip ? -1.f : 1.f) * (R01 * gm.x + R11 * gm.y + R21 * gm.z);
         go.xyz[3 * j + 2] = R02 * gm.x + R12 * gm.y + R22 * gm.z;
         pv[0] = gm.x; pv[1] = gm.y; pv[2] = gm.z;
         pv[3] = gm.x * x; pv[4] = gm.x * y; pv[5] = gm.x * z;
         pv[6] = gm.y * x; pv[7] = gm.y * y; pv[8] = gm.y * z;
         pv[9] = gm.z * x; pv[10] = gm.z * y; pv[11] = gm.z * z;
       } else {
-        go.xyz[3 * j] = gm.x; go.xyz[3 * j + 1] = gm.y; go.xyz[3 * j + 2] = gm.z;
+        go.xyz[3 * j] = gm.x; go.xyz[3 * j + 1] = flip ? -gm.y : gm.y; go.xyz[3 * j + 2] = gm.z;
       }
     }
   }

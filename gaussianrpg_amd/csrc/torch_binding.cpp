@@ -342,8 +342,10 @@ SegmentPack pack_segments(const std::vector<torch::Tensor>& xyz, const std::vect
                           const std::vector<torch::Tensor>& opacity,
                           const std::vector<torch::Tensor>& features_dc,
                           const std::vector<torch::Tensor>& features_rest,
+                          const std::vector<torch::Tensor>& flip,
                           const torch::Tensor& poses, const torch::Tensor& idft) {
   const size_t n = xyz.size();
+  TORCH_CHECK(flip.size() == n, "one flip mask (or an empty tensor) per model");
   TORCH_CHECK(n > 0 && n <= GRPG_MAX_SEGMENTS, "need 1..", GRPG_MAX_SEGMENTS, " models");
   TORCH_CHECK(scaling.size() == n && rotation.size() == n && opacity.size() == n &&
                   features_dc.size() == n && features_rest.size() == n,
@@ -380,6 +382,15 @@ SegmentPack pack_segments(const std::vector<torch::Tensor>& xyz, const std::vect
     g.features_dc = fptr(features_dc[i], like, "features_dc", k[4]);
     g.features_rest = fptr(features_rest[i], like, "features_rest", k[5]);
     for (auto& t : k) pk.keep.push_back(t);
+    g.flip = nullptr;
+    if (flip[i].numel() != 0) {   // training symmetry prior: bool / uint8 [N] on the device
+      TORCH_CHECK(flip[i].is_cuda() && flip[i].device() == like.device() && flip[i].numel() == cnt &&
+                      (flip[i].scalar_type() == torch::kBool || flip[i].scalar_type() == torch::kUInt8),
+                  "model ", i, ": flip must be a bool / uint8 device tensor [N]");
+      torch::Tensor fc = flip[i].contiguous();
+      pk.keep.push_back(fc);
+      g.flip = reinterpret_cast<const unsigned char*>(fc.data_ptr());
+    }
     g.count = (int)cnt;
     g.fourier_dim = F;
     const float* pr = pc.data_ptr<float>() + 8 * i;
@@ -402,12 +413,13 @@ RasterizeGaussiansComposed(const torch::Tensor& background, const std::vector<to
                            const std::vector<torch::Tensor>& opacity,
                            const std::vector<torch::Tensor>& features_dc,
                            const std::vector<torch::Tensor>& features_rest,
+                           const std::vector<torch::Tensor>& flip,
                            const torch::Tensor& poses, const torch::Tensor& idft,
                            const float scale_modifier, const torch::Tensor& viewmatrix,
                            const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
                            const int image_height, const int image_width, const int degree,
                            const torch::Tensor& campos, const bool debug, const bool for_backward) {
-  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, flip, poses, idft);
   const torch::Tensor& like = xyz[0];
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
   const int H = image_height, W = image_width;
@@ -450,14 +462,15 @@ RasterizeGaussiansComposedBackward(
     const torch::Tensor& background, const std::vector<torch::Tensor>& xyz,
     const std::vector<torch::Tensor>& scaling, const std::vector<torch::Tensor>& rotation,
     const std::vector<torch::Tensor>& opacity, const std::vector<torch::Tensor>& features_dc,
-    const std::vector<torch::Tensor>& features_rest, const torch::Tensor& poses, const torch::Tensor& idft,
+    const std::vector<torch::Tensor>& features_rest, const std::vector<torch::Tensor>& flip,
+    const torch::Tensor& poses, const torch::Tensor& idft,
     const float scale_modifier, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
     const float tan_fovx, const float tan_fovy, const int degree, const torch::Tensor& campos,
     const torch::Tensor& radii, const torch::Tensor& alphas, const torch::Tensor& geomBuffer, const int R,
     const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
     const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_depth,
     const torch::Tensor& dL_dout_alpha, const bool debug) {
-  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, flip, poses, idft);
   const torch::Tensor& like = xyz[0];
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
   const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
@@ -509,8 +522,8 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Te
 Compose(const std::vector<torch::Tensor>& xyz, const std::vector<torch::Tensor>& scaling,
         const std::vector<torch::Tensor>& rotation, const std::vector<torch::Tensor>& opacity,
         const std::vector<torch::Tensor>& features_dc, const std::vector<torch::Tensor>& features_rest,
-        const torch::Tensor& poses, const torch::Tensor& idft) {
-  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, poses, idft);
+        const std::vector<torch::Tensor>& flip, const torch::Tensor& poses, const torch::Tensor& idft) {
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, flip, poses, idft);
   const torch::Tensor& like = xyz[0];
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
   auto o = like.options().dtype(torch::kFloat32);
@@ -739,7 +752,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("debug_export", &DebugExport);
   m.def("rasterize_gaussians_composed", &RasterizeGaussiansComposed, pybind11::arg("bg"), pybind11::arg("xyz"),
         pybind11::arg("scaling"), pybind11::arg("rotation"), pybind11::arg("opacity"),
-        pybind11::arg("features_dc"), pybind11::arg("features_rest"), pybind11::arg("poses"),
+        pybind11::arg("features_dc"), pybind11::arg("features_rest"), pybind11::arg("flip"), pybind11::arg("poses"),
         pybind11::arg("idft"), pybind11::arg("scale_modifier"), pybind11::arg("viewmatrix"),
         pybind11::arg("projmatrix"), pybind11::arg("tan_fovx"), pybind11::arg("tan_fovy"),
         pybind11::arg("image_height"), pybind11::arg("image_width"), pybind11::arg("degree"),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRPG_ABI_VERSION 2
+#define GRPG_ABI_VERSION 3
 
 /* Exported symbol (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -177,8 +177,8 @@ GRPG_API int grpg_frame_status(int ticket, int wait, int* num_rendered);
  * arrays and the per-frame actor poses instead and does that arithmetic inside preprocess; the
  * concatenated tensors never exist.  S = 0.  Training: grpg_forward_composed_flags(flags = 0) +
  * grpg_backward_composed return the gradients with respect to the RAW parameters and the poses
- * (round 3; the flip augmentation of street_gaussian_model.py:286-293, the semantic concatenation
- * :420-435 and pose-correction modules stay in the caller's PyTorch).
+ * (round 3; the semantic concatenation of street_gaussian_model.py:420-435 and pose-correction
+ * modules stay in the caller's PyTorch; the flip augmentation :286-293 is the segment's `flip` mask).
  *
  * A segment describes one model, in the order the reference concatenates them (background first,
  * then the visible actors, street_gaussian_model.py:232-262).  All pointers are device pointers to
@@ -201,6 +201,11 @@ typedef struct grpg_model_segment {
   float obj_rot[4];            /* (w,x,y,z), ego pose already applied (:268-273) */
   float obj_trans[3];
   float idft[GRPG_MAX_FOURIER];/* IDFT(time, fourier_dim), lib/utils/sh_utils.py:120-130 */
+  const unsigned char* flip;   /* ABI 3: [count] device bytes, != 0 = this Gaussian is flipped this iteration
+                                  (training symmetry prior of rigid actors, street_gaussian_model.py:
+                                  286-293: local y mirrored, local rotation pre-multiplied by the
+                                  quaternion of diag(-1,1,-1)); NULL = none (evaluation, flip_prob 0,
+                                  deformable actors) */
 } grpg_model_segment;
 
 /* Same outputs, blobs and return value as grpg_forward on the concatenation of the segments

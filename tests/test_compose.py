@@ -29,6 +29,12 @@ def test_idft_weights_match_reference_fixture():
             np.testing.assert_array_equal(ct.idft(float(t), d)[0].numpy(), ref)
 
 
+def _to(m, dev, grad=False):
+    """ModelParams on a device (the optional flip mask may be None); grad: fresh leaves."""
+    f = lambda t: t.to(dev).clone().requires_grad_(True) if grad else t.to(dev)   # noqa: E731
+    return type(m)(*(f(t) for t in m[:6]), None if m.flip is None else m.flip.to(dev))
+
+
 def _logit(p):
     return torch.log(p / (1 - p))
 
@@ -51,7 +57,9 @@ def _scene_graph(sh_degree=1, nb=60_000, actors=((4000, 5), (2500, 3), (6000, 1)
         opacity = 1.0 + 2.0 * torch.randn(n, 1, generator=g)
         fdc = 0.5 * torch.randn(n, F, 3, generator=g)
         frest = 0.15 * torch.randn(n, M - 1, 3, generator=g)
-        models.append(ModelParams(xyz, scaling, rotation, opacity, fdc, frest))
+        # the first actor carries this iteration's flip mask (training symmetry prior, flip_prob 0.5)
+        flip = (torch.rand(n, generator=g) < 0.5) if k == 0 else None
+        models.append(ModelParams(xyz, scaling, rotation, opacity, fdc, frest, flip))
         q = torch.randn(4, generator=g)
         q = q / q.norm() * (1.0 + 0.01 * k)        # obj_rot is not exactly unit in practice
         trans = torch.tensor([-6.0 + 5.0 * k, 0.8, 12.0 + 9.0 * k])
@@ -66,7 +74,7 @@ def test_compose_matches_torch_restatement(sh_degree):
     from oracle import compose_torch as ct
     dev = torch.device("cuda:0")
     models, poses = _scene_graph(sh_degree)
-    got = compose([type(m)(*(t.to(dev) for t in m)) for m in models], poses)
+    got = compose([_to(m, dev) for m in models], poses)
     ref = ct.compose(models, [None if p is None else (p.obj_rot, p.obj_trans, p.fourier_time) for p in poses])
     names = ("means3D", "scales", "rotations", "opacity", "shs")
     P = sum(m.xyz.shape[0] for m in models)
@@ -87,7 +95,7 @@ def test_fused_forward_equals_classic_on_composed_tensors(sh_degree):
     from gaussianrpg_amd.composed import ComposedRasterizer, compose
     dev = torch.device("cuda:0")
     models, poses = _scene_graph(sh_degree)
-    models = [type(m)(*(t.to(dev) for t in m)) for m in models]
+    models = [_to(m, dev) for m in models]
     cam = hz.trajectory_camera(2, W=960, H=640, device=dev)
     bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
     rs = GaussianRasterizationSettings(**hz.settings_kwargs(cam, sh_degree, bg=bg))
@@ -119,7 +127,7 @@ def test_composed_argument_errors():
     from diff_gaussian_rasterization import GaussianRasterizationSettings
     dev = torch.device("cuda:0")
     models, poses = _scene_graph(1, nb=2000, actors=((300, 2),))
-    models = [type(m)(*(t.to(dev) for t in m)) for m in models]
+    models = [_to(m, dev) for m in models]
     cam = hz.trajectory_camera(0, W=128, H=96, device=dev)
     fused = ComposedRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
     with pytest.raises(ValueError):
@@ -149,7 +157,7 @@ def test_compose_matches_reference_quaternion_fixture():
                         torch.zeros(n, 3, 3))
         trans = [0.5 * k, -1.0, 3.0]
         for rot, check in ((obj_rot, "matrix"), (a, "product")):
-            got = compose([ModelParams(*(t.to(dev) for t in m))],
+            got = compose([_to(m, dev)],
                           [ActorPose([float(v) for v in rot], trans, 0.0)])
             if check == "matrix":
                 ref = xyz.double().numpy() @ Rref.T + np.array(trans)
@@ -174,6 +182,10 @@ def test_fused_training_gradients_match_autograd_through_the_restatement(sh_degr
     from oracle import compose_torch as ct
     dev = torch.device("cuda:0")
     models, poses = _scene_graph(sh_degree, nb=30_000, actors=((3000, 5), (2000, 1)), seed=9)
+    # the symmetry prior of the shipped training configs (flip_prob: 0.5): half of the first actor's
+    # Gaussians are flipped this iteration, the second actor has no mask
+    gf = torch.Generator().manual_seed(17)
+    models[1] = models[1]._replace(flip=torch.rand(models[1].xyz.shape[0], generator=gf) < 0.5)
     cam = hz.trajectory_camera(2, W=480, H=320, device=dev)
     bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
     rs = GaussianRasterizationSettings(**hz.settings_kwargs(cam, sh_degree, bg=bg))
@@ -184,7 +196,7 @@ def test_fused_training_gradients_match_autograd_through_the_restatement(sh_degr
     ga = torch.randn(1, 320, 480, generator=g).to(dev)
 
     def leaves():
-        ms = [type(m)(*(t.to(dev).clone().requires_grad_(True) for t in m)) for m in models]
+        ms = [_to(m, dev, grad=True) for m in models]
         ps = [None if p is None else ActorPose(torch.tensor(p.obj_rot, device=dev, requires_grad=True),
                                                torch.tensor(p.obj_trans, device=dev, requires_grad=True),
                                                p.fourier_time) for p in poses]
@@ -219,7 +231,7 @@ def test_fused_training_gradients_match_autograd_through_the_restatement(sh_degr
 
     close("means2D", m2d.grad, m2r.grad)
     for i, (a, b) in enumerate(zip(ms, mr)):
-        for f in a._fields:
+        for f in a._fields[:6]:
             ga_, gb_ = getattr(a, f).grad, getattr(b, f).grad
             if gb_ is None or float(gb_.abs().max()) == 0.0:    # e.g. SH bands above the active degree
                 assert ga_ is None or float(ga_.abs().max()) == 0.0, (i, f)

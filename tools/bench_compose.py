@@ -22,7 +22,7 @@ for k in range(NA):
                               math.log(0.05) + 0.5 * torch.randn(PA, 3, generator=g),
                               torch.randn(PA, 4, generator=g), 1.0 + 2.0 * torch.randn(PA, 1, generator=g),
                               0.5 * torch.randn(PA, F, 3, generator=g), 0.15 * torch.randn(PA, 3, 3, generator=g)))
-models = [ModelParams(*(t.to(dev) for t in m)) for m in models]
+models = [ModelParams(*(t.to(dev) for t in m[:6])) for m in models]
 
 
 def poses_at(f):
@@ -83,7 +83,7 @@ b = hz.time_frames(run_fused, 60)
 
 # training step (forward + backward to the RAW parameters): PyTorch composition with autograd + the
 # classic op, against the fused op's own backward (grpg_backward_composed)
-train_models = [ModelParams(*(t.clone().requires_grad_(True) for t in m)) for m in models]
+train_models = [ModelParams(*(t.clone().requires_grad_(True) for t in m[:6])) for m in models]
 
 
 def train_ref(f):
@@ -107,7 +107,7 @@ def train_fused(f):
 
 def zero_grads():
     for m in train_models:
-        for t in m:
+        for t in m[:6]:
             t.grad = None
 
 
