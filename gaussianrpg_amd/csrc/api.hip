@@ -447,6 +447,12 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     auto layout_for = [&](uint32_t cap, uint32_t ccap) {
       return hier ? bin_layout((size_t)cap, T, NS, ccap) : bin_layout((size_t)cap);
     };
+    // a training forward leaves blend checkpoints of its long tile lists behind the binning blob
+    // (common.h CK_*; the backward starts its segments from them)
+    const bool with_ckpt = (flags & GRPG_FORWARD_NO_BACKWARD) == 0u && S == 0;
+    auto blob_bytes = [&](const BinLayout& L, uint32_t cap) {
+      return L.total + (with_ckpt ? ckpt_bytes(ckpt_slots(cap)) : 0);
+    };
     const CapKey ck = {dev, P, width, height};
     uint32_t Ccap = 0u;
     uint32_t Rcap = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? capacity_from_hint(ck, &Ccap) : 0u;
@@ -455,7 +461,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     BinLayout BL{};
     if (speculative) {
       BL = layout_for(Rcap, Ccap);
-      bin = binning_alloc(BL.total, binning_user);
+      bin = binning_alloc(blob_bytes(BL, Rcap), binning_user);
       if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
     }
     tm.mark(0);
@@ -526,11 +532,15 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       STAGE_CHECK("offsets scan");
       return GRPG_OK;
     };
-    auto render_tail = [&](const uint32_t* point_list, uint32_t cap, bool classified) -> int {
+    auto render_tail = [&](char* binp, const BinLayout& L, const uint32_t* point_list, uint32_t cap,
+                           bool classified) -> int {
       tm.mark(6);
+      const CkptArgs ck = {(float*)(binp + L.total), (uint32_t*)(img + IL.ck_count), (BlobHeader*)binp,
+                           (uint32_t)(L.total / 256), ckpt_slots(cap)};
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
-                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified);
+                            (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified,
+                            with_ckpt ? &ck : nullptr);
       STAGE_CHECK("render");
       tm.mark(7);
       if (S > 0) {
@@ -575,7 +585,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       tm.mark(5);
       launch_tile_ranges(stream, &gh->R, cap, bkey_a, ranges, T);
       STAGE_CHECK("tile ranges");
-      return render_tail(bval_a, cap, false);
+      return render_tail(binp, L, bval_a, cap, false);
     };
     // hierarchical path (hier_binning.hip): everything behind the depth sort.  Stage slots: 2 = scan
     // over the super-tile counts, 3 = coarse emit, 4 = coarse partition + super-tile runs,
@@ -626,13 +636,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                        cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),
                        (const uint32_t*)(binp + L.tile_start), cap, plist);
       STAGE_CHECK("point list fill");
-      return render_tail(plist, cap, true);
+      return render_tail(binp, L, plist, cap, true);
     };
     auto carve = [&](uint32_t cap, uint32_t ccap, bool rezero) -> int {
       Rcap = cap;
       Ccap = ccap;
       BL = layout_for(Rcap, Ccap);
-      bin = binning_alloc(BL.total, binning_user);
+      bin = binning_alloc(blob_bytes(BL, Rcap), binning_user);
       if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
       launch_bin_header(stream, bin, (uint32_t)P, Rcap, (uint32_t)width, (uint32_t)height, (uint32_t)S,
                         rezero ? ranges : nullptr, T, rezero ? work : nullptr);
@@ -919,7 +929,6 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
   const uint32_t* point_list = (const uint32_t*)(binning_buffer + bin_layout(0).val_a);
   const uint2* ranges = (const uint2*)(image_buffer + IL.ranges);
   const uint32_t* n_contrib = (const uint32_t*)(image_buffer + IL.n_contrib);
-  (void)R;
   // tables: the segments (as in the forward; re-uploaded: the caller may hand over other arrays of
   // the same values) and the six output pointers per segment, through pinned staging
   BwdStagingSlot* stg = bwd_staging_acquire();
@@ -950,7 +959,9 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
   HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
   launch_render_backward(stream, ranges, point_list, rec, nullptr, 0, width, height, cam.gx, cam.gy,
                          background, alphas, n_contrib, (const uint32_t*)(image_buffer + IL.work), dL_dpix,
-                         dL_dpix_depth, dL_dalphas, nullptr, grad_rec, nullptr);
+                         dL_dpix_depth, dL_dalphas, nullptr, grad_rec, nullptr,
+                         (const BlobHeader*)binning_buffer, (const uint32_t*)(image_buffer + IL.ck_count),
+                         (uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
   STAGE_CHECK("render backward");
   launch_preprocess_backward_composed(stream, P, D, M, seg_dev, seg_grad_dev, num_segments, radii, rec,
                                       scale_modifier, cam, grad_rec, dL_dmean2D,
@@ -1058,7 +1069,9 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   launch_render_backward(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
                          cam.gy, background, alphas, n_contrib,
                          (const uint32_t*)(image_buffer + IL.work), dL_dpix, dL_dpix_depth, dL_dalphas,
-                         dL_dpix_semantic, grad_rec, dL_dsemantic);
+                         dL_dpix_semantic, grad_rec, dL_dsemantic, (const BlobHeader*)binning_buffer,
+                         (const uint32_t*)(image_buffer + IL.ck_count),
+                         (uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
   STAGE_CHECK("render backward");
   launch_preprocess_backward(stream, P, D, M, means3D, radii_int, colors_precomp ? nullptr : shs,
                              rec, cov3D_precomp ? nullptr : scales, rotations, scale_modifier,

@@ -350,7 +350,7 @@ frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint
     if (h) {
       h->magic = t == 0 ? GEOM_MAGIC : (t == 1 ? BIN_MAGIC : IMG_MAGIC);
       h->P = P; h->R = 0u; h->W = W; h->H = H; h->S = S; h->V = V_init; h->Rcap = Rcap;
-      h->Rc = 0u; h->hier = 0u;
+      h->Rc = 0u; h->hier = 0u; h->ckpt_off256 = 0u; h->ckpt_slots = 0u;
     }
   }
 }
@@ -381,6 +381,7 @@ bin_header_kernel(BlobHeader* bin, const uint32_t P, const uint32_t Rcap, const 
   if (t == 0 && bin) {
     bin->magic = BIN_MAGIC; bin->P = P; bin->R = 0u; bin->W = W; bin->H = H; bin->S = S;
     bin->V = 0u; bin->Rcap = Rcap; bin->Rc = 0u; bin->hier = 0u;
+    bin->ckpt_off256 = 0u; bin->ckpt_slots = 0u;
   }
 }
 

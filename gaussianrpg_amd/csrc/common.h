@@ -73,9 +73,37 @@ struct BlobHeader {      // first 256 bytes of every blob
   uint32_t hier;         // binning blob: 1 = the point list came from the hierarchical path (no
                          // sorted tile keys; tile_start[] instead)
   uint32_t R_pre, Rc_pre;   // geometry blob: the counts as summed right behind preprocess
-  uint32_t reserved[52];
+  uint32_t ckpt_off256;     // binning blob: offset / 256 of the forward's blend checkpoints (CK_* below),
+  uint32_t ckpt_slots;      //   0 = none were written (evaluation forward); slots carved
+  uint32_t reserved[50];
 };
 static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
+
+// Blend checkpoints of long tile lists (written by a TRAINING forward, read by the backward):
+// every quarter wave of a tile with >= CK_LONG_MIN entries stores its per-pixel blend state
+// (T, r, g, b, depth) at batch ends at least CK_SEG list positions apart, and once more at the end of
+// its walk.  The backward then walks (tile, segment) items that START from a checkpoint, so a long
+// list is no longer one serial chain.  Record = CK_PLANES planes of 64 floats (plane 5, lane 0: the
+// 1-based list position the state belongs to); records of tile t, quarter q, index k live at
+// slot ckpt_tile_base(range.x) + k, quarter q.  Slots never overlap: consecutive long tiles are
+// >= 2 CK_SEG entries apart and floor(1.5 (x + len) / SEG) - floor(1.5 x / SEG) >= len / SEG + 1.
+constexpr uint32_t CK_SEG = 1024;
+constexpr uint32_t CK_LONG_MIN = 2048;
+constexpr int CK_PLANES = 6;
+constexpr size_t CK_REC_FLOATS = (size_t)CK_PLANES * 64;
+static_assert(CK_LONG_MIN >= 2 * CK_SEG, "slot numbering needs len >= 2 CK_SEG");
+__host__ __device__ inline uint32_t ckpt_tile_base(const uint32_t range_x) {
+  return (uint32_t)((3ull * range_x) / (2ull * CK_SEG));
+}
+__host__ __device__ inline uint32_t ckpt_tile_cap(const uint32_t len) { return len / CK_SEG + 1u; }
+inline uint32_t ckpt_slots(const uint32_t Rcap) { return (uint32_t)((3ull * Rcap) / (2ull * CK_SEG)) + 2u; }
+// bytes behind the binning blob: the records, then the backward's (tile, segment) item list
+__host__ __device__ inline size_t ckpt_items_offset(const uint32_t slots) {
+  return ((size_t)slots * 4 * CK_REC_FLOATS * 4 + 255) / 256 * 256;
+}
+inline size_t ckpt_bytes(const uint32_t slots) {
+  return ckpt_items_offset(slots) + align_up((size_t)slots * 8, 256);
+}
 
 // radix sort geometry
 constexpr int RS_THREADS = 256;
@@ -150,6 +178,8 @@ struct BinLayout {
 struct ImgLayout {
   size_t total;
   size_t ranges, n_contrib, work;
+  size_t ck_count;   // u32 [T][4]: checkpoint records per (tile, quarter), long tiles only
+  size_t bwd_ctl;    // u32 [4]: [0] number of (tile, segment) items of the backward
 };
 
 // with_grad: room for the backward's 64-byte gradient record per Gaussian (GRAD_* below) behind
@@ -241,6 +271,8 @@ inline ImgLayout img_layout(size_t T, size_t N) {
   L.ranges = take(T * 8);
   L.n_contrib = take(N * 4);
   L.work = take((4 + 4 * T) * 4);   // render work lists: counts[4], lists[4][T]
+  L.ck_count = take(T * 16);
+  L.bwd_ctl = take(16);
   L.total = o;
   return L;
 }
@@ -340,13 +372,20 @@ void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_
                       const uint32_t* seg_table, const uint32_t* tile_start, uint32_t R_cap,
                       uint32_t* point_list);
 
+struct CkptArgs {
+  float* recs;          // checkpoint records (behind the binning blob)
+  uint32_t* counts;     // [T][4] in the image blob
+  BlobHeader* bin_hdr;  // receives ckpt_off256 / ckpt_slots
+  uint32_t off256, slots;
+};
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
                            uint32_t heavy_min, uint32_t R /* num_rendered */,
                            bool aux /* track + write n_contrib (needed by the backward only) */,
-                           bool classified = false /* work lists already built (hier_binning.hip) */);
+                           bool classified = false /* work lists already built (hier_binning.hip) */,
+                           const CkptArgs* ck = nullptr /* aux only: blend checkpoints for the backward */);
 void render_class_multipliers(uint32_t* c0_mul, uint32_t* c1_mul);   // render_fwd.hip
 uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min);   // render_fwd.hip
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
@@ -359,7 +398,9 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
                             const float* dL_dpix_semantic, float* grad_rec /* [P][GRAD_STRIDE], zeroed */,
-                            float* dL_dsemantic);
+                            float* dL_dsemantic, const BlobHeader* bin_hdr = nullptr /* checkpoints */,
+                            const uint32_t* ck_count = nullptr, uint32_t* bwd_ctl = nullptr,
+                            uint32_t R = 0 /* num_rendered: bounds the item count */);
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,
                                 const int* radii, const float* shs, const RecView rec,
                                 const float* scales, const float* rotations, float scale_modifier,

@@ -139,7 +139,9 @@ constexpr int BREC = 4;   // float4 per compacted survivor in LDS: record (3) + 
 
 // One wave, PX pixels per lane: rows y0 + (lane>>4)*PX + k.  bits_mask selects the sub-tile bits
 // of a point-list entry that concern this wave (one bit for a quarter, all four for a whole tile).
-template <int PX, int SMAX>
+// SEG (quarter waves of a long tile only): the wave walks list positions [seg_lo, seg_hi) and starts
+// from the forward's checkpoint at seg_hi (ck_end; NULL for the list's last segment) -- see below.
+template <int PX, int SMAX, bool SEG = false>
 __device__ __forceinline__ void backward_rect(
     float4* __restrict__ my, uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
     const int lane, const uint32_t r_begin, const uint32_t r_end,
@@ -150,7 +152,8 @@ __device__ __forceinline__ void backward_rect(
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
     const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpix_semantic,
     float* __restrict__ grad_rec, float* __restrict__ dL_dsemantic, const int ablate,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, const uint32_t seg_lo = 0u, const uint32_t seg_hi = 0u,
+    const float* __restrict__ ck_end = nullptr, const float* __restrict__ ck_final = nullptr) {
   constexpr int SM = SMAX > 0 ? SMAX : 1;
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
@@ -202,6 +205,20 @@ __device__ __forceinline__ void backward_rect(
     }
     maxlast = max(maxlast, lastc[k]);
   }
+  if (SEG && ck_end != nullptr) {
+    // Start in the MIDDLE of the list, from the forward's state right behind position seg_hi:
+    // T there, and what the back-to-front walk would have accumulated by then -- the composite of
+    // everything behind, as seen from this depth: (C_final - C_k) / T_k per channel, 1 - T_final / T_k
+    // for the accumulated alpha.  A pixel that terminated in front of seg_hi has T_k == T_final and
+    // C_k == C_final (its state stopped changing): zeros, and pos < lastc rejects every entry anyway.
+    const float Tk = ck_end[lane];
+    const float inv = 1.0f / fmaxf(Tk, 1e-30f);
+    const float Tf = T[0];
+    T[0] = Tk;
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[0][c] = (ck_final[64 * (c + 1) + lane] - ck_end[64 * (c + 1) + lane]) * inv;
+    acc_a[0] = 1.0f - Tf * inv;
+  }
   maxlast = wave_max_u32(maxlast);   // nothing behind the tile's deepest contributor matters
   const float nddelx = -(float)(0.5 * W), nddely = -(float)(0.5 * H);   // -ddelx_dx, -ddely_dy (backward.cu:501-502)
 
@@ -228,14 +245,15 @@ __device__ __forceinline__ void backward_rect(
   // processed while that gather is in flight.  A dead entry costs 1/256 of a FILL step and no
   // record is loaded for it; in a horizon tile only one entry in six concerns a given quarter.
   const uint64_t lt = lanemask_lt();
-  const uint32_t count = min(r_end - r_begin, maxlast);
-  uint32_t in_hi = count;           // list positions [0, in_hi) are still unread (wave-uniform)
+  const uint32_t lo = SEG ? seg_lo : 0u;   // list positions [lo, count) are walked
+  const uint32_t count = max(min(SEG ? seg_hi : r_end - r_begin, maxlast), lo);
+  uint32_t in_hi = count;           // list positions [lo, in_hi) are still unread (wave-uniform)
   uint32_t head = 0, rcount = 0;    // ring state                                (wave-uniform)
   uint32_t win[BFILL_Q];
 #pragma unroll
   for (int q = 0; q < BFILL_Q; q++) {
     const uint32_t off = (uint32_t)(q * WAVE + lane);
-    win[q] = off < in_hi ? point_list[r_begin + in_hi - 1 - off] : 0u;
+    win[q] = off < in_hi - lo ? point_list[r_begin + in_hi - 1 - off] : 0u;
   }
   uint32_t st_fill = 0, st_batches = 0, st_iters = 0, st_used = 0, st_rows = 0;   // GRPG_BWD_STATS
   const unsigned long long st_t0 = stats ? __builtin_readcyclecounter() : 0ull;
@@ -243,20 +261,20 @@ __device__ __forceinline__ void backward_rect(
   uint32_t lpos = 0, lid = 0, ncur = 0;
   for (;;) {
     // ---- FILL ----
-    while (rcount < (uint32_t)WAVE && in_hi > 0) {
+    while (rcount < (uint32_t)WAVE && in_hi > lo) {
       uint32_t v[BFILL_Q];
 #pragma unroll
       for (int q = 0; q < BFILL_Q; q++) v[q] = win[q];
-      const uint32_t nxt = in_hi > (uint32_t)(BFILL_Q * WAVE) ? in_hi - BFILL_Q * WAVE : 0u;
+      const uint32_t nxt = in_hi - lo > (uint32_t)(BFILL_Q * WAVE) ? in_hi - BFILL_Q * WAVE : lo;
 #pragma unroll
       for (int q = 0; q < BFILL_Q; q++) {
         const uint32_t off = (uint32_t)(q * WAVE + lane);
-        win[q] = off < nxt ? point_list[r_begin + nxt - 1 - off] : 0u;
+        win[q] = off < nxt - lo ? point_list[r_begin + nxt - 1 - off] : 0u;
       }
 #pragma unroll
       for (int q = 0; q < BFILL_Q; q++) {
         const uint32_t off = (uint32_t)(q * WAVE + lane);
-        const bool keep = (off < in_hi) && (v[q] & bits_mask);
+        const bool keep = (off < in_hi - lo) && (v[q] & bits_mask);
         const uint64_t m = __ballot(keep);
         if (keep) {
           const uint32_t slot = (head + rcount + (uint32_t)__popcll(m & lt)) & (BQCAP - 1);
@@ -431,13 +449,13 @@ __device__ __forceinline__ void backward_rect(
     }
     __builtin_amdgcn_wave_barrier();
     la = na; lb = nb; lc = nc; lpos = npos; lid = nid; ncur = nn;
-    if (ncur == 0 && in_hi == 0) break;   // ring empty (rcount == 0 here) and list exhausted
+    if (ncur == 0 && in_hi == lo) break;   // ring empty (rcount == 0 here) and list exhausted
   }
   if (stats != nullptr && lane == 0) {   // experiment counters (GRPG_BWD_STATS=1), off in production
     // one record of 8 words per wave, no atomics (same-address atomics would dominate the launch)
     unsigned long long* r = stats + 8ull * ((unsigned long long)blockIdx.x * RB_WAVES + (threadIdx.x >> 6));
     r[0] = 1ull + (PX == 1 ? 0ull : 2ull);   // wave kind: 1 quarter wave, 3 light wave
-    r[1] = count;                             // list entries in reach of the wave
+    r[1] = count - lo;                        // list entries in reach of the wave
     r[2] = ((unsigned long long)st_fill << 32) | st_batches;
     r[3] = st_iters;                          // survivors of the rectangle cull = loop trips
     r[4] = st_used;                           // ... of which some pixel used (reduction + atomic)
@@ -450,6 +468,48 @@ __device__ __forceinline__ void backward_rect(
 // Work lists: written by the forward's classify_tiles_kernel (render_fwd.hip) into the image blob:
 // counts[4] (three heavy classes, light), then four lists of T tile ids.
 constexpr int NUM_CLASSES_B = 4;
+
+// (tile, segment) items of the long tiles (forward checkpoints, common.h CK_*): one workgroup walks
+// the tile ranges and appends ckpt_tile_cap(len) items per tile with >= CK_LONG_MIN entries.  A single
+// workgroup on purpose: no counter to clear, no global atomics, T / 1024 rounds of a block scan.
+__global__ void __launch_bounds__(1024)
+backward_items_kernel(const uint2* __restrict__ ranges, const uint32_t T,
+                      const BlobHeader* __restrict__ bin_hdr, uint32_t* __restrict__ bwd_ctl) {
+  __shared__ uint32_t s_wave[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t off256 = bin_hdr->ckpt_off256, slots = bin_hdr->ckpt_slots;
+  if (off256 == 0u) { if (tid == 0) bwd_ctl[0] = 0u; return; }
+  uint2* items = (uint2*)((char*)bin_hdr + (size_t)off256 * 256 + ckpt_items_offset(slots));
+  uint32_t running = 0;
+  for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
+    const uint32_t t = t0 + tid;
+    uint32_t cap = 0;
+    if (t < T) {
+      const uint2 r = ranges[t];
+      cap = r.y - r.x >= CK_LONG_MIN ? ckpt_tile_cap(r.y - r.x) : 0u;
+    }
+    uint32_t incl = cap;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+      const uint32_t v = s_wave[w];
+      before += (uint32_t)w < wave ? v : 0u;
+      total += v;
+    }
+    uint32_t o = running + before + incl - cap;
+    for (uint32_t k = 0; k < cap && o < slots; k++, o++) items[o] = make_uint2(t, k);
+    running += total;
+    __syncthreads();
+  }
+  if (tid == 0) bwd_ctl[0] = min(running, slots);
+}
 
 // MINW: waves per SIMD the register allocator must fit (4 -> 128 VGPRs, 24 B of scratch per lane in
 // the S = 0 / two-pixel-light variant; 1 -> whatever it takes: 138 VGPRs, 3 waves per SIMD)
@@ -464,11 +524,39 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                        const float* __restrict__ dL_dalphas,
                        const float* __restrict__ dL_dpix_semantic, float* __restrict__ grad_rec,
                        float* __restrict__ dL_dsemantic, const int ablate, const int wide_classes,
-                       unsigned long long* __restrict__ stats) {
+                       unsigned long long* __restrict__ stats,
+                       const BlobHeader* __restrict__ bin_hdr, const uint32_t* __restrict__ ck_count,
+                       const uint32_t* __restrict__ bwd_ctl, const uint32_t items_cap) {
   __shared__ float4 s_rec[RB_WAVES][WAVE * BREC];
   __shared__ uint32_t s_qid[RB_WAVES][BQCAP];
   __shared__ uint32_t s_qpos[RB_WAVES][BQCAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // Long tiles (forward checkpoints present): the first items_cap workgroups take (tile, segment)
+  // items, four quarter waves each; the tiles themselves are skipped further down.
+  const bool ck_on = SMAX == 0 && items_cap != 0u && bin_hdr->ckpt_off256 != 0u;
+  if (SMAX == 0 && items_cap != 0u && blockIdx.x < items_cap) {
+    if (!ck_on || blockIdx.x >= bwd_ctl[0]) return;
+    const float* recs = (const float*)((const char*)bin_hdr + (size_t)bin_hdr->ckpt_off256 * 256);
+    const uint2 item = ((const uint2*)((const char*)recs + ckpt_items_offset(bin_hdr->ckpt_slots)))[blockIdx.x];
+    const uint32_t tile = item.x, k = item.y;
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck_count[(size_t)tile * 4 + wave]);
+    if (k >= n) return;   // this quarter cut its list into fewer pieces
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+    const uint2 range = ranges[tile];
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    const float* r0 = recs + ((size_t)ckpt_tile_base(rb) * 4 + (size_t)wave) * CK_REC_FLOATS;
+    const float* rk = r0 + (size_t)k * 4 * CK_REC_FLOATS;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(rk[320]));
+    const uint32_t lo = k ? (uint32_t)__builtin_amdgcn_readfirstlane(
+                                (int)__float_as_uint((rk - 4 * CK_REC_FLOATS)[320])) : 0u;
+    backward_rect<1, SMAX, true>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, rb, re, tx * TILE,
+                                 ty * TILE + wave * 4, 1u << (SUBTILE_SHIFT + wave), W, H, S, point_list,
+                                 rec, semantics, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth,
+                                 dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic, ablate, stats, lo,
+                                 hi, k + 1u == n ? nullptr : rk, r0 + (size_t)(n - 1u) * 4 * CK_REC_FLOATS);
+    return;
+  }
   // wide_classes = k: the k shortest heavy classes of the forward's classification are walked like
   // light tiles here (one wave per tile, 4 pixels per lane) -- one reduction + atomic per
   // (tile, splat) instead of four
@@ -477,7 +565,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   const uint32_t nmid = wide_classes >= 1 ? work[2] : 0u;
   const uint32_t nlight = work[3] + nmid;
   const uint32_t nheavy = n0 + n1 + n2;
-  const uint32_t b = blockIdx.x;
+  const uint32_t b = blockIdx.x - (SMAX == 0 ? items_cap : 0u);
   const uint32_t* lists = work + NUM_CLASSES_B;
   uint32_t tile;
   uint32_t half = 0;   // light tiles: which 16x8 half of the tile this wave owns
@@ -494,7 +582,8 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
   const uint2 range = ranges[tile];
   const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
-  const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+ const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+  if (ck_on && re - rb >= CK_LONG_MIN) return;   // walked as (tile, segment) items above
 #define RB_CALL(PXV, YOFF, BITS)                                                                  \
   backward_rect<PXV, SMAX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, rb, re, tx * TILE, ty * TILE + (YOFF), (BITS), W, H, \
                            S, point_list, rec, semantics, bg, alphas, n_contrib, dL_dpix,          \
@@ -514,26 +603,42 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             int gy, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
-                            const float* dL_dpix_semantic, float* grad_rec, float* dL_dsemantic) {
+                            const float* dL_dpix_semantic, float* grad_rec, float* dL_dsemantic,
+                            const BlobHeader* bin_hdr, const uint32_t* ck_count, uint32_t* bwd_ctl,
+                            uint32_t R) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
+  // GRPG_BWD_SEG=0: ignore the forward's checkpoints (every list is one chain again)
+  static const int seg_on = [] { const char* e = getenv("GRPG_BWD_SEG"); return e ? atoi(e) : 1; }();
+  uint32_t items_cap = 0;
+  if (seg_on && S <= 0 && bin_hdr && ck_count && bwd_ctl) {
+    items_cap = ckpt_slots(R);   // >= sum of ckpt_tile_cap over the long tiles (each >= CK_LONG_MIN)
+    backward_items_kernel<<<1, 1024, 0, s>>>(ranges, (uint32_t)ntiles, bin_hdr, bwd_ctl);
+  }
   // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
   static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 0; }();
   // GRPG_BWD_STATS=1: per-launch loop counters printed to stderr (synchronises: experiments only)
   static const int want_stats = [] { const char* e = getenv("GRPG_BWD_STATS"); return e ? atoi(e) : 0; }();
   static unsigned long long* stats_dev = nullptr;
+  static size_t stats_cap = 0;
   unsigned long long* stats = nullptr;
-  const int grid_max = ntiles + ntiles / 2 + 1;
+  const int grid_max = ntiles + ntiles / 2 + 1 + (int)ckpt_slots(R);
   const size_t stats_words = 8ull * (size_t)grid_max * RB_WAVES;
   if (want_stats) {
-    if (!stats_dev) (void)hipMalloc((void**)&stats_dev, stats_words * sizeof(unsigned long long));
+    if (stats_words > stats_cap) {
+      if (stats_dev) (void)hipFree(stats_dev);
+      stats_dev = nullptr;
+      if (hipMalloc((void**)&stats_dev, stats_words * sizeof(unsigned long long)) != hipSuccess) return;
+      stats_cap = stats_words;
+    }
     (void)hipMemsetAsync(stats_dev, 0, stats_words * sizeof(unsigned long long), s);
     stats = stats_dev;
   }
 #define RB_ARGS                                                                                  \
   ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
-      dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic, ablate, wide, stats
+      dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic, ablate, wide, stats, \
+      bin_hdr, ck_count, bwd_ctl, items_cap
   // nheavy + ceil(LIGHT_SPLIT nlight / 4) <= ntiles for LIGHT_SPLIT <= 2 ... not for nheavy ~ ntiles/2:
   // launch nheavy_max + light workgroups = ntiles + ntiles/2 + 1, surplus workgroups exit at once.
   // Light tiles: two waves per tile at 2 pixels per lane (default): the kernel then fits 128 VGPRs
@@ -541,7 +646,7 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   // SIMD) and GRPG_BWD_WAVES=1 (no register cap) measure within 1 % of it under rocprofv3 at
   // config 5; GRPG_BWD_WAVES=5 (96 VGPRs, 36 spilled) is 8 % slower.
   static const int light4 = [] { const char* e = getenv("GRPG_BWD_LIGHT"); return e && atoi(e) == 4; }();
-  const int grid = light4 ? ntiles : ntiles + ntiles / 2 + 1;
+  const int grid = (light4 ? ntiles : ntiles + ntiles / 2 + 1) + (int)items_cap;
   if (S <= 0) {
     static const int minw = [] { const char* e = getenv("GRPG_BWD_WAVES"); return e ? atoi(e) : 4; }();
     if (light4) render_backward_kernel<0, 1><<<grid, 256, 0, s>>>(RB_ARGS);

@@ -379,6 +379,45 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
 constexpr int QCAP = 512;            // ring capacity in entries (>= 64 + 256), power of two
 constexpr int FILL_Q = 4;            // list entries per lane per FILL step
 
+// Blend checkpoints for the backward (common.h CK_*): per-quarter state of a long tile's walk.
+struct CkptWriter {
+  float* recs;        // record 0 of this (tile, quarter); record k is 4 records further each; NULL = off
+  uint32_t* count;    // receives the number of records written
+  uint32_t k, next, cap;
+};
+__device__ __forceinline__ CkptWriter ckpt_writer(const CkptArgs& ck, const uint32_t tile, const int quarter,
+                                                  const uint32_t rb, const uint32_t re) {
+  CkptWriter w = {nullptr, nullptr, 0u, CK_SEG, 0u};
+  if (ck.recs != nullptr && re - rb >= CK_LONG_MIN) {
+    w.recs = ck.recs + ((size_t)ckpt_tile_base(rb) * 4 + (size_t)quarter) * CK_REC_FLOATS;
+    w.count = ck.counts + (size_t)tile * 4 + quarter;
+    w.cap = ckpt_tile_cap(re - rb);
+  }
+  return w;
+}
+__device__ __forceinline__ void ckpt_store(CkptWriter& w, const int lane, const WavePix<1>& st,
+                                           const uint32_t pos /* 1-based position the state follows */) {
+  float* r = w.recs + (size_t)w.k * 4 * CK_REC_FLOATS + lane;
+  r[0] = st.T[0];
+  r[64] = st.CrCg[0].x; r[128] = st.CrCg[0].y;
+  r[192] = st.CbD[0].x; r[256] = st.CbD[0].y;
+  if (lane == 0) r[320] = __uint_as_float(pos);
+  w.k++;
+  w.next = pos + CK_SEG;
+}
+// a batch whose last entry sits at list position last_pos has been blended
+__device__ __forceinline__ void ckpt_batch_end(CkptWriter& w, const int lane, const WavePix<1>& st,
+                                               const uint32_t last_pos) {
+  if (w.recs != nullptr && last_pos >= w.next && w.k + 1u < w.cap) ckpt_store(w, lane, st, last_pos);
+}
+// end of the walk: the final state, tagged with the list length
+__device__ __forceinline__ void ckpt_finish(CkptWriter& w, const int lane, const WavePix<1>& st,
+                                            const uint32_t len) {
+  if (w.recs == nullptr) return;
+  ckpt_store(w, lane, st, len);
+  if (lane == 0) *w.count = w.k;
+}
+
 template <bool TRACE, bool AUX = true>
 __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
                                             uint32_t* __restrict__ qpos, const int lane,
@@ -391,7 +430,8 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                                             float* __restrict__ out_color,
                                             float* __restrict__ out_depth,
                                             float* __restrict__ out_alpha,
-                                            uint32_t* __restrict__ n_contrib, WaveTrace* tr) {
+                                            uint32_t* __restrict__ n_contrib, WaveTrace* tr,
+                                            CkptWriter ckw) {
   const int px = x0 + (lane & 15);
   const int py = y0 + (lane >> 4);
   const float pxf = (float)px;
@@ -507,11 +547,14 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
         const int bk = na <= 2 ? 0 : (na <= 8 ? 1 : (na <= 24 ? 2 : 3));
         tr->it[bk]++; tr->cyc[bk] += (uint32_t)(tc2 - tc0);
       }
+      // every entry up to the batch's last ring entry is now blended, masked out or culled
+      if (AUX) ckpt_batch_end(ckw, lane, st, (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)ncur - 1));
       __builtin_amdgcn_wave_barrier();
     }
     a = a_n; b = b_n; c = c_n; pos = pos_n; ncur = nn;
     if (ncur == 0 && in_pos >= r_end) break;   // ring empty (count == 0 here) and list exhausted
   }
+  if (AUX) ckpt_finish(ckw, lane, st, r_end - r_begin);
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t HW = (size_t)H * W;
@@ -676,7 +719,8 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             float* __restrict__ out_color,
                                             float* __restrict__ out_depth,
                                             float* __restrict__ out_alpha,
-                                            uint32_t* __restrict__ n_contrib) {
+                                            uint32_t* __restrict__ n_contrib, CkptWriter ckw,
+                                            const uint32_t len) {
   const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
   const float pxf = (float)px;
   WavePix<1> st;
@@ -696,6 +740,11 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     const int cnt = (int)(f - 1u);
     const float4* my = cur ? buf1 : buf0;
     for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad<AUX>(st, my, j0, pxf, (float)py);
+    if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
+      const float* blk = reinterpret_cast<const float*>(my + ((cnt - 1) >> 1) * PAIR_F4);
+      ckpt_batch_end(ckw, lane, st,
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(blk[20 + ((cnt - 1) & 1)])));
+    }
     pc_store(&ctl->flag[cur], 0u);   // hand the buffer back
     cur ^= 1;
     const uint64_t alive = ~st.done[0];
@@ -715,6 +764,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
       if (lane == 0) { ctl->box[0] = bx0; ctl->box[1] = bx1; ctl->box[2] = by0; ctl->box[3] = by1; }
     }
   }
+  if (AUX) ckpt_finish(ckw, lane, st, len);
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t HW = (size_t)H * W;
   if (px < W && py < H) {
@@ -753,7 +803,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                      const uint32_t pc_slots, const int xcd_on,
+                      const uint32_t pc_slots, const int xcd_on, const CkptArgs ck,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
@@ -765,6 +815,10 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   uint32_t tr_tile = 0xFFFFFFFFu, tr_len = 0;
   const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nlight = work[3];
   const uint32_t* lists = work + NUM_CLASSES;
+  if (WRITE_AUX && ck.bin_hdr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    ck.bin_hdr->ckpt_off256 = ck.off256;   // tells the backward where this frame's checkpoints are
+    ck.bin_hdr->ckpt_slots = ck.slots;
+  }
   // pc_slots > 0: class 0 holds the few longest tiles; each is rendered by two workgroups (half
   // tiles) with a producer and a consumer wave per quarter.  The first pc_slots workgroups are
   // reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
@@ -786,7 +840,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
     if (wave < 2)
       pc_consumer<WRITE_AUX>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
-                  out_depth, out_alpha, n_contrib);
+                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb);
     else
       pc_producer(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
                   rb, re, point_list, rec);
@@ -814,7 +868,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     tr_tile = tile; tr_len = re - rb;
     blend_heavy<TRACE, WRITE_AUX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
                        ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
-                       out_alpha, n_contrib, &tr);
+                       out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re));
   } else {
     if (b >= nlwg) return;
     const uint32_t li = xcd_contiguous(b, nlwg, xcd_on) * RW_WAVES + (uint32_t)wave;
@@ -955,9 +1009,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
-                           uint32_t heavy_min, uint32_t R, bool aux, bool classified) {
+                           uint32_t heavy_min, uint32_t R, bool aux, bool classified,
+                           const CkptArgs* ckp) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
+  const CkptArgs ck = (aux && ckp) ? *ckp : CkptArgs{nullptr, nullptr, nullptr, 0u, 0u};
   // work[0..3] were zeroed by write_headers_kernel (same stream, earlier in the frame)
   const bool pc = render_pc_enabled();
   const uint32_t pc_mul = render_pc_mul();
@@ -978,11 +1034,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
     if (aux)                                                                                   \
       render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                        \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots, xcd);                                                 \
+          out_alpha, n_contrib, pc_slots, xcd, ck);                                             \
     else                                                                                       \
       render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                       \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots, xcd);                                                 \
+          out_alpha, n_contrib, pc_slots, xcd, ck);                                             \
   } while (0)
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
   if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
@@ -992,7 +1048,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
       render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, lds_pad, s>>>(
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
-          out_alpha, n_contrib, pc_slots, xcd, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
+          out_alpha, n_contrib, pc_slots, xcd, ck, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
       (void)hipMemcpyAsync(h.data(), d_trace, words * 4, hipMemcpyDeviceToHost, s);
       (void)hipStreamSynchronize(s);
