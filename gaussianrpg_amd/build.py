@@ -42,7 +42,7 @@ HIP_UNITS = {
     "sky.hip": ["-munsafe-fp-atomics"],
     "api.hip": [],
 }
-HEADERS = ["common.h", "gaussian_math.h", "blend_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]
+HEADERS = ["common.h", "gaussian_math.h", "blend_math.h", "compose_math.h", os.path.join(ROOT, "include", "grpg_rasterizer.h")]
 
 
 def _hipcc():
@@ -80,6 +80,7 @@ def build_native(force=False, verbose=False):
         if force or _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
             jobs.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
                          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] + extra +
+                        os.environ.get("GRPG_EXTRA_HIPCC_FLAGS", "").split() +   # experiments (-D...)
                         ["-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:

@@ -535,7 +535,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     auto render_tail = [&](char* binp, const BinLayout& L, const uint32_t* point_list, uint32_t cap,
                            bool classified) -> int {
       tm.mark(6);
-      const CkptArgs ck = {(float*)(binp + L.total), (uint32_t*)(img + IL.ck_count), (BlobHeader*)binp,
+      const CkptArgs ck = {(float*)(binp + L.total), (uint32_t*)(img + IL.ck_count),
+                           (uint32_t*)(img + IL.bwd_ctl), (BlobHeader*)binp,
                            (uint32_t)(L.total / 256), ckpt_slots(cap)};
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
@@ -961,7 +962,7 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
                          background, alphas, n_contrib, (const uint32_t*)(image_buffer + IL.work), dL_dpix,
                          dL_dpix_depth, dL_dalphas, nullptr, grad_rec, nullptr,
                          (const BlobHeader*)binning_buffer, (const uint32_t*)(image_buffer + IL.ck_count),
-                         (uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
+                         (const uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
   STAGE_CHECK("render backward");
   launch_preprocess_backward_composed(stream, P, D, M, seg_dev, seg_grad_dev, num_segments, radii, rec,
                                       scale_modifier, cam, grad_rec, dL_dmean2D,
@@ -1071,7 +1072,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
                          (const uint32_t*)(image_buffer + IL.work), dL_dpix, dL_dpix_depth, dL_dalphas,
                          dL_dpix_semantic, grad_rec, dL_dsemantic, (const BlobHeader*)binning_buffer,
                          (const uint32_t*)(image_buffer + IL.ck_count),
-                         (uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
+                         (const uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
   STAGE_CHECK("render backward");
   launch_preprocess_backward(stream, P, D, M, means3D, radii_int, colors_precomp ? nullptr : shs,
                              rec, cov3D_precomp ? nullptr : scales, rotations, scale_modifier,

@@ -344,7 +344,7 @@ frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint
   for (size_t i = t; i < nzero16; i += stride) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
   if (ranges)
     for (size_t i = t; i < T; i += stride) ranges[i] = make_uint2(0u, 0u);
-  if (work && t < 4) work[t] = 0u;
+  if (work && t < 4) { work[t] = 0u; work[4 + 4 * (size_t)T + t] = 0u; }   // list counters, bwd_ctl
   if (t < 3) {
     BlobHeader* h = t == 0 ? geom : (t == 1 ? bin : img);
     if (h) {
@@ -377,7 +377,7 @@ bin_header_kernel(BlobHeader* bin, const uint32_t P, const uint32_t Rcap, const 
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (ranges)
     for (uint32_t i = t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
-  if (work && t < 4) work[t] = 0u;
+  if (work && t < 4) { work[t] = 0u; work[4 + 4 * (size_t)T + t] = 0u; }   // list counters, bwd_ctl
   if (t == 0 && bin) {
     bin->magic = BIN_MAGIC; bin->P = P; bin->R = 0u; bin->W = W; bin->H = H; bin->S = S;
     bin->V = 0u; bin->Rcap = Rcap; bin->Rc = 0u; bin->hier = 0u;

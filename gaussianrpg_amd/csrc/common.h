@@ -87,8 +87,14 @@ static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 // 1-based list position the state belongs to); records of tile t, quarter q, index k live at
 // slot ckpt_tile_base(range.x) + k, quarter q.  Slots never overlap: consecutive long tiles are
 // >= 2 CK_SEG entries apart and floor(1.5 (x + len) / SEG) - floor(1.5 x / SEG) >= len / SEG + 1.
-constexpr uint32_t CK_SEG = 1024;
-constexpr uint32_t CK_LONG_MIN = 2048;
+#ifndef GRPG_CK_SEG
+#define GRPG_CK_SEG 1024
+#endif
+#ifndef GRPG_CK_LONG_MIN
+#define GRPG_CK_LONG_MIN (2 * GRPG_CK_SEG)
+#endif
+constexpr uint32_t CK_SEG = GRPG_CK_SEG;
+constexpr uint32_t CK_LONG_MIN = GRPG_CK_LONG_MIN;
 constexpr int CK_PLANES = 6;
 constexpr size_t CK_REC_FLOATS = (size_t)CK_PLANES * 64;
 static_assert(CK_LONG_MIN >= 2 * CK_SEG, "slot numbering needs len >= 2 CK_SEG");
@@ -179,7 +185,7 @@ struct ImgLayout {
   size_t total;
   size_t ranges, n_contrib, work;
   size_t ck_count;   // u32 [T][4]: checkpoint records per (tile, quarter), long tiles only
-  size_t bwd_ctl;    // u32 [4]: [0] number of (tile, segment) items of the backward
+  size_t bwd_ctl;    // u32 [4]: [0] number of (tile, segment) items the forward left for the backward
 };
 
 // with_grad: room for the backward's 64-byte gradient record per Gaussian (GRAD_* below) behind
@@ -270,9 +276,9 @@ inline ImgLayout img_layout(size_t T, size_t N) {
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   L.ranges = take(T * 8);
   L.n_contrib = take(N * 4);
-  L.work = take((4 + 4 * T) * 4);   // render work lists: counts[4], lists[4][T]
+  L.work = take((4 + 4 * T + 4) * 4);   // render work lists: counts[4], lists[4][T]; then bwd_ctl[4]
+  L.bwd_ctl = L.work + (4 + 4 * T) * 4;  // cleared together with the list counters (frame_init)
   L.ck_count = take(T * 16);
-  L.bwd_ctl = take(16);
   L.total = o;
   return L;
 }
@@ -373,8 +379,9 @@ void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_
                       uint32_t* point_list);
 
 struct CkptArgs {
-  float* recs;          // checkpoint records (behind the binning blob)
+  float* recs;          // checkpoint records (behind the binning blob), then the item list
   uint32_t* counts;     // [T][4] in the image blob
+  uint32_t* n_items;    // item counter (image blob, bwd_ctl[0]; cleared by frame_init)
   BlobHeader* bin_hdr;  // receives ckpt_off256 / ckpt_slots
   uint32_t off256, slots;
 };
@@ -399,7 +406,7 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             const float* dL_dpix_depth, const float* dL_dalphas,
                             const float* dL_dpix_semantic, float* grad_rec /* [P][GRAD_STRIDE], zeroed */,
                             float* dL_dsemantic, const BlobHeader* bin_hdr = nullptr /* checkpoints */,
-                            const uint32_t* ck_count = nullptr, uint32_t* bwd_ctl = nullptr,
+                            const uint32_t* ck_count = nullptr, const uint32_t* bwd_ctl = nullptr,
                             uint32_t R = 0 /* num_rendered: bounds the item count */);
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means3D,
                                 const int* radii, const float* shs, const RecView rec,

@@ -9,8 +9,13 @@
 // image blob are reused):
 //   * LIGHT tiles: one wave per tile, 4 pixels per lane.  HEAVY tiles: four 16x4 quarter-tile
 //     waves at 1 pixel per lane (a heavy tile no longer serialises behind one wave).
+//   * LONG tiles (>= CK_LONG_MIN entries) are not one serial chain: the training forward left blend
+//     checkpoints behind (common.h CK_*: per quarter the state (T, C, D) at batch ends >= 1024
+//     positions apart), and the first workgroups of the launch walk (tile, segment) items that start
+//     from them: T at the segment's end from the checkpoint, the accumulators from
+//     (C_final - C_k) / T_k.  render_backward_kernel 744 -> 512 us at config 5.
 //   * The list is walked back to front, only up to the deepest contributor of the wave's pixels,
-//     through the forward's FILL / POP / process pipeline: FILL scans 256 entries per step and
+//     through the forward's FILL / POP / process pipeline: FILL scans 128 entries per step and
 //     keeps those whose sub-tile mask (set by emit) concerns the wave in an LDS ring; POP starts
 //     the record gather of up to 64 of them; the previous batch is meanwhile culled against the
 //     bounding box of the pixels that are ACTIVE at that depth (last contributor behind the
@@ -35,8 +40,8 @@
 namespace grpg {
 
 constexpr int RB_WAVES = 4;
-constexpr int BQCAP = 512;     // ring capacity in entries (>= 64 + 256), power of two
-constexpr int BFILL_Q = 4;     // list entries per lane per FILL step
+constexpr int BQCAP = 256;     // ring capacity in entries (>= 64 + 128), power of two
+constexpr int BFILL_Q = 2;     // list entries per lane per FILL step
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_step(float v) {
@@ -227,8 +232,8 @@ __device__ __forceinline__ void backward_rect(
   //   row 0: dL_dmean2D x, y, |.|   row 1: dL_dconic xx, xy, yy   row 2: dL_dcolor r, g, b
   //   row 3: dL_dopacity, dL_ddepth, -
   // i.e. float 3 r + k of the Gaussian's 64-byte gradient record (common.h GRAD_*): ONE
-  // global_atomic_add_f32 with 11 active lanes and ONE memory line per (wave, Gaussian) -- the
-  // reference issues 11 atomics per PIXEL and Gaussian; five separate arrays cost five lines per
+  // global_atomic_add_f32 with 11 active lanes and ONE memory line per (wave, Gaussian) --
+  // the reference issues 11 atomics per PIXEL and Gaussian; five separate arrays cost five lines per
   // atomic, and on this part every line is a transaction of its own at the memory side (the XCDs'
   // L2s are not coherent): 0.28 of 0.96 ms before the record.  The conic moments are accumulated
   // without their -1/2 (backward.cu:634-636); the issuing lanes apply it to the wave total.
@@ -239,10 +244,10 @@ __device__ __forceinline__ void backward_rect(
   const float sc_scale = row == 1 ? -0.5f : 1.0f;
 
   // Back-to-front traversal of list positions [0, count), decoupled like the forward's heavy path
-  // (render_fwd.hip): FILL scans 256 entries per step (prefetched one window ahead) and appends
+  // (render_fwd.hip): FILL scans 128 entries per step (prefetched one window ahead) and appends
   // the ones whose sub-tile mask concerns this wave to an LDS ring, deepest first; POP takes up to
   // 64 of them and starts the gather of their records; the PREVIOUS batch is culled, compacted and
-  // processed while that gather is in flight.  A dead entry costs 1/256 of a FILL step and no
+  // processed while that gather is in flight.  A dead entry costs 1/128 of a FILL step and no
   // record is loaded for it; in a horizon tile only one entry in six concerns a given quarter.
   const uint64_t lt = lanemask_lt();
   const uint32_t lo = SEG ? seg_lo : 0u;   // list positions [lo, count) are walked
@@ -255,6 +260,7 @@ __device__ __forceinline__ void backward_rect(
     const uint32_t off = (uint32_t)(q * WAVE + lane);
     win[q] = off < in_hi - lo ? point_list[r_begin + in_hi - 1 - off] : 0u;
   }
+  const uint64_t ablate_m = (ablate & 4) ? 0ull : ~0ull;
   uint32_t st_fill = 0, st_batches = 0, st_iters = 0, st_used = 0, st_rows = 0;   // GRPG_BWD_STATS
   const unsigned long long st_t0 = stats ? __builtin_readcyclecounter() : 0ull;
   float4 la = make_float4(0, 0, 0, 0), lb = la, lc = la;   // current batch (records arrived)
@@ -351,7 +357,8 @@ __device__ __forceinline__ void backward_rect(
     __builtin_amdgcn_wave_barrier();
     st_batches += ncur > 0 ? 1u : 0u;
     st_iters += (uint32_t)cnt;
-    for (int j = 0; j < cnt; j++) {
+    const int cnt_u = __builtin_amdgcn_readfirstlane(cnt);   // loop control on the scalar unit
+    for (int j = 0; j < cnt_u; j++) {
       const float4 a = my[j * BREC + 0];   // px, py, depth, opacity
       const float4 b = my[j * BREC + 1];   // conic.x, conic.y, conic.z, R
       const float4 c = my[j * BREC + 2];   // G, B, list position, Gaussian id
@@ -375,9 +382,15 @@ __device__ __forceinline__ void backward_rect(
       for (int k = 0; k < PX; k++) {
         const float dy = a.y - pyf[k];
         float G, alpha;   // identical arithmetic to the forward (blend_math.h)
-        const bool valid = pair_alpha(pair_power(st, dy), a.w, G, alpha) && (pos < lastc[k]) &&
-                           !(ablate & 4);
-        if (__ballot(valid) == 0ull) continue;   // wave-uniform: no pixel of this row takes the splat
+        const float power2 = pair_power(st, dy);
+        G = __builtin_amdgcn_exp2f(power2);
+        alpha = fminf(ALPHA_MAX, a.w * G);
+        // lane masks in SGPRs: the compares ARE ballots, the boolean algebra runs on the scalar unit
+        const uint64_t valid_m = __builtin_amdgcn_ballot_w64(!(power2 > 0.0f)) &
+                                 __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_MIN)) &
+                                 __builtin_amdgcn_ballot_w64(pos < lastc[k]) & ablate_m;
+        if (valid_m == 0ull) continue;   // wave-uniform: no pixel of this row takes the splat
+        const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
         any = true;
         st_rows++;
         // Branch-free below: a lane that rejects the splat runs the same arithmetic with
@@ -469,48 +482,6 @@ __device__ __forceinline__ void backward_rect(
 // counts[4] (three heavy classes, light), then four lists of T tile ids.
 constexpr int NUM_CLASSES_B = 4;
 
-// (tile, segment) items of the long tiles (forward checkpoints, common.h CK_*): one workgroup walks
-// the tile ranges and appends ckpt_tile_cap(len) items per tile with >= CK_LONG_MIN entries.  A single
-// workgroup on purpose: no counter to clear, no global atomics, T / 1024 rounds of a block scan.
-__global__ void __launch_bounds__(1024)
-backward_items_kernel(const uint2* __restrict__ ranges, const uint32_t T,
-                      const BlobHeader* __restrict__ bin_hdr, uint32_t* __restrict__ bwd_ctl) {
-  __shared__ uint32_t s_wave[16];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t off256 = bin_hdr->ckpt_off256, slots = bin_hdr->ckpt_slots;
-  if (off256 == 0u) { if (tid == 0) bwd_ctl[0] = 0u; return; }
-  uint2* items = (uint2*)((char*)bin_hdr + (size_t)off256 * 256 + ckpt_items_offset(slots));
-  uint32_t running = 0;
-  for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
-    const uint32_t t = t0 + tid;
-    uint32_t cap = 0;
-    if (t < T) {
-      const uint2 r = ranges[t];
-      cap = r.y - r.x >= CK_LONG_MIN ? ckpt_tile_cap(r.y - r.x) : 0u;
-    }
-    uint32_t incl = cap;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-      if (lane >= (uint32_t)d) incl += o;
-    }
-    if (lane == 63u) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-      const uint32_t v = s_wave[w];
-      before += (uint32_t)w < wave ? v : 0u;
-      total += v;
-    }
-    uint32_t o = running + before + incl - cap;
-    for (uint32_t k = 0; k < cap && o < slots; k++, o++) items[o] = make_uint2(t, k);
-    running += total;
-    __syncthreads();
-  }
-  if (tid == 0) bwd_ctl[0] = min(running, slots);
-}
-
 // MINW: waves per SIMD the register allocator must fit (4 -> 128 VGPRs, 24 B of scratch per lane in
 // the S = 0 / two-pixel-light variant; 1 -> whatever it takes: 138 VGPRs, 3 waves per SIMD)
 template <int SMAX, int LIGHT_SPLIT, int MINW = 1>
@@ -535,7 +506,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   // items, four quarter waves each; the tiles themselves are skipped further down.
   const bool ck_on = SMAX == 0 && items_cap != 0u && bin_hdr->ckpt_off256 != 0u;
   if (SMAX == 0 && items_cap != 0u && blockIdx.x < items_cap) {
-    if (!ck_on || blockIdx.x >= bwd_ctl[0]) return;
+    if (!ck_on || blockIdx.x >= min(bwd_ctl[0], bin_hdr->ckpt_slots)) return;
     const float* recs = (const float*)((const char*)bin_hdr + (size_t)bin_hdr->ckpt_off256 * 256);
     const uint2 item = ((const uint2*)((const char*)recs + ckpt_items_offset(bin_hdr->ckpt_slots)))[blockIdx.x];
     const uint32_t tile = item.x, k = item.y;
@@ -604,17 +575,16 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             const uint32_t* n_contrib, const uint32_t* work, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
                             const float* dL_dpix_semantic, float* grad_rec, float* dL_dsemantic,
-                            const BlobHeader* bin_hdr, const uint32_t* ck_count, uint32_t* bwd_ctl,
+                            const BlobHeader* bin_hdr, const uint32_t* ck_count, const uint32_t* bwd_ctl,
                             uint32_t R) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   // GRPG_BWD_SEG=0: ignore the forward's checkpoints (every list is one chain again)
   static const int seg_on = [] { const char* e = getenv("GRPG_BWD_SEG"); return e ? atoi(e) : 1; }();
   uint32_t items_cap = 0;
-  if (seg_on && S <= 0 && bin_hdr && ck_count && bwd_ctl) {
-    items_cap = ckpt_slots(R);   // >= sum of ckpt_tile_cap over the long tiles (each >= CK_LONG_MIN)
-    backward_items_kernel<<<1, 1024, 0, s>>>(ranges, (uint32_t)ntiles, bin_hdr, bwd_ctl);
-  }
+  // the forward left (tile, segment) items behind; their number is on the device, bounded here by
+  // the sum of ckpt_tile_cap over lists of >= CK_LONG_MIN entries
+  if (seg_on && S <= 0 && bin_hdr && ck_count && bwd_ctl) items_cap = ckpt_slots(R);
   // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
   static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 0; }();

@@ -418,6 +418,21 @@ __device__ __forceinline__ void ckpt_finish(CkptWriter& w, const int lane, const
   if (lane == 0) *w.count = w.k;
 }
 
+// Quarter 0 of a long tile leaves the backward's work items behind: (tile, k) for every record index
+// a quarter of this tile can have written (a quarter that cut its list into fewer pieces skips the
+// surplus items).  One atomic per long tile, at the very end of the wave: nobody waits for it.
+__device__ __forceinline__ void ckpt_publish_items(const CkptArgs& ck, const int lane, const uint32_t tile,
+                                                   const uint32_t len) {
+  if (ck.recs == nullptr || len < CK_LONG_MIN) return;
+  const uint32_t cap = ckpt_tile_cap(len);
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(ck.n_items, cap);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  uint2* items = (uint2*)((char*)ck.recs + ckpt_items_offset(ck.slots));
+  for (uint32_t k = (uint32_t)lane; k < cap; k += WAVE)
+    if (base + k < ck.slots) items[base + k] = make_uint2(tile, k);
+}
+
 template <bool TRACE, bool AUX = true>
 __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
                                             uint32_t* __restrict__ qpos, const int lane,
@@ -838,10 +853,11 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
       s_ctl[slot].box[2] = (float)y0; s_ctl[slot].box[3] = (float)(y0 + 3);
     }
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
-    if (wave < 2)
+    if (wave < 2) {
       pc_consumer<WRITE_AUX>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
                   out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb);
-    else
+      if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
+    } else
       pc_producer(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
                   rb, re, point_list, rec);
     return;
@@ -869,6 +885,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     blend_heavy<TRACE, WRITE_AUX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
                        ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
                        out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re));
+    if (WRITE_AUX && wave == 0) ckpt_publish_items(ck, lane, tile, re - rb);
   } else {
     if (b >= nlwg) return;
     const uint32_t li = xcd_contiguous(b, nlwg, xcd_on) * RW_WAVES + (uint32_t)wave;
@@ -1013,7 +1030,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const CkptArgs* ckp) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
-  const CkptArgs ck = (aux && ckp) ? *ckp : CkptArgs{nullptr, nullptr, nullptr, 0u, 0u};
+  const CkptArgs ck = (aux && ckp) ? *ckp : CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
   // work[0..3] were zeroed by write_headers_kernel (same stream, earlier in the frame)
   const bool pc = render_pc_enabled();
   const uint32_t pc_mul = render_pc_mul();

@@ -66,6 +66,96 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, unsigned long lon
 #define I(r) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(r) : "v"(pb));
       REP4(I(p0) I(p1) I(p2) I(p3) I(p4) I(p5) I(p6) I(p7) I(p8) I(p9) I(p10) I(p11) I(p12) I(p13) I(p14) I(p15))
 #undef I
+    } else if (MODE == 7) {   // cross-lane exchanges of the backward's reduction tree
+#define I(r, q) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r), "+v"(q));
+      REP4(I(a0, a1) I(a2, a3) I(a4, a5) I(a6, a7) I(a8, a9) I(a10, a11) I(a12, a13) I(a14, a15)
+           I(a0, a2) I(a1, a3) I(a4, a6) I(a5, a7) I(a8, a10) I(a9, a11) I(a12, a14) I(a13, a15))
+#undef I
+    } else if (MODE == 8) {
+#define I(r, q) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r), "+v"(q));
+      REP4(I(a0, a1) I(a2, a3) I(a4, a5) I(a6, a7) I(a8, a9) I(a10, a11) I(a12, a13) I(a14, a15)
+           I(a0, a2) I(a1, a3) I(a4, a6) I(a5, a7) I(a8, a10) I(a9, a11) I(a12, a14) I(a13, a15))
+#undef I
+    } else if (MODE == 9) {   // DPP add, quad_perm (source = another accumulator: no RAW hazard nops)
+#define I(r, q) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(q));
+      REP4(I(a0, a8) I(a1, a9) I(a2, a10) I(a3, a11) I(a4, a12) I(a5, a13) I(a6, a14) I(a7, a15)
+           I(a8, a0) I(a9, a1) I(a10, a2) I(a11, a3) I(a12, a4) I(a13, a5) I(a14, a6) I(a15, a7))
+#undef I
+    } else if (MODE == 10) {  // DPP add, row_ror:8
+#define I(r, q) asm volatile("v_add_f32_dpp %0, %1, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(q));
+      REP4(I(a0, a8) I(a1, a9) I(a2, a10) I(a3, a11) I(a4, a12) I(a5, a13) I(a6, a14) I(a7, a15)
+           I(a8, a0) I(a9, a1) I(a10, a2) I(a11, a3) I(a12, a4) I(a13, a5) I(a14, a6) I(a15, a7))
+#undef I
+    } else if (MODE == 11) {  // VOP2 multiply
+#define I(r) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 12) {  // VOP2 subtract
+#define I(r) asm volatile("v_sub_f32_e32 %0, %1, %0" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 13) {
+#define I(r) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(r));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 14) {  // compare into an SGPR pair (no consumer)
+#define I(r) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m2) : "v"(r), "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 15) {  // VOP2 fused multiply-accumulate
+#define I(r) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 16) {
+#define I(r) asm volatile("v_min_f32_e32 %0, %1, %0" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 17) {  // integer add (loop / address arithmetic)
+#define I(r) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 18) {  // VOP3 multiply with a negated source (what the gradient code emits)
+#define I(r) asm volatile("v_mul_f32_e64 %0, %0, -%1" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 19) {  // v_mov_b32
+#define I(r, q) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(r) : "v"(q));
+      REP4(I(a0, a8) I(a1, a9) I(a2, a10) I(a3, a11) I(a4, a12) I(a5, a13) I(a6, a14) I(a7, a15)
+           I(a8, a0) I(a9, a1) I(a10, a2) I(a11, a3) I(a12, a4) I(a13, a5) I(a14, a6) I(a15, a7))
+#undef I
+    } else if (MODE == 20) {  // signed integer minimum (orders non-negative floats like v_min_f32)
+#define I(r) asm volatile("v_min_i32_e32 %0, %1, %0" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 21) {
+#define I(r) asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(r) : "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 22) {
+#define I(r) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 23) {  // compare into VCC (VOPC encoding), no consumer
+#define I(r) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(r), "v"(b) : "vcc");
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 24) {  // integer compare into an SGPR pair
+#define I(r) asm volatile("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m2) : "v"(r), "v"(b));
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 25) {  // v_cndmask_b32 on VCC (VOP2 encoding)
+#define I(r) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(r) : "v"(b) : "vcc");
+      REP4(I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7) I(a8) I(a9) I(a10) I(a11) I(a12) I(a13) I(a14) I(a15))
+#undef I
+    } else if (MODE == 26) {  // v_pk_add_f32
+#define I(r) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(r) : "v"(pb));
+      REP4(I(p0) I(p1) I(p2) I(p3) I(p4) I(p5) I(p6) I(p7) I(p8) I(p9) I(p10) I(p11) I(p12) I(p13) I(p14) I(p15))
+#undef I
+    } else if (MODE == 27) {  // v_fma_f32 with three DIFFERENT rotating sources (register-bank pressure)
+#define I(r, x, y) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r) : "v"(x), "v"(y));
+      REP4(I(a0, a5, a10) I(a1, a6, a11) I(a2, a7, a12) I(a3, a8, a13) I(a4, a9, a14) I(a5, a10, a15) I(a6, a11, a0) I(a7, a12, a1)
+           I(a8, a13, a2) I(a9, a14, a3) I(a10, a15, a4) I(a11, a0, a5) I(a12, a1, a6) I(a13, a2, a7) I(a14, a3, a8) I(a15, a4, a9))
+#undef I
     } else if (MODE == 5) {   // alternating v_fma_f32 / v_exp_f32 (3 : 1, the quad loop's mix)
 #define I4(r, s, t, u)                                                      \
   asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));      \
@@ -154,6 +244,27 @@ int main(int argc, char** argv) {
   run<3>("v_cndmask_b32 (sgpr mask)", 0, num_cu, clock_ghz, js, false);
   run<6>("v_cmp + v_cndmask", 0, num_cu, clock_ghz, js, false);
   run<5>("3 v_fma + 1 v_exp", 2, num_cu, clock_ghz, js, false);
+  run<15>("v_fmac_f32 (VOP2)", 2, num_cu, clock_ghz, js, false);
+  run<11>("v_mul_f32 (VOP2)", 1, num_cu, clock_ghz, js, false);
+  run<18>("v_mul_f32 (VOP3, neg)", 1, num_cu, clock_ghz, js, false);
+  run<12>("v_sub_f32 (VOP2)", 1, num_cu, clock_ghz, js, false);
+  run<16>("v_min_f32", 0, num_cu, clock_ghz, js, false);
+  run<17>("v_add_u32", 0, num_cu, clock_ghz, js, false);
+  run<19>("v_mov_b32", 0, num_cu, clock_ghz, js, false);
+  run<13>("v_rcp_f32", 1, num_cu, clock_ghz, js, false);
+  run<14>("v_cmp_gt_f32 -> sgpr", 0, num_cu, clock_ghz, js, false);
+  run<20>("v_min_i32", 0, num_cu, clock_ghz, js, false);
+  run<21>("v_max_f32", 0, num_cu, clock_ghz, js, false);
+  run<22>("v_med3_f32", 0, num_cu, clock_ghz, js, false);
+  run<23>("v_cmp_gt_f32 -> vcc (e32)", 0, num_cu, clock_ghz, js, false);
+  run<24>("v_cmp_lt_u32 -> sgpr", 0, num_cu, clock_ghz, js, false);
+  run<25>("v_cndmask_b32 (vcc, e32)", 0, num_cu, clock_ghz, js, false);
+  run<26>("v_pk_add_f32", 2, num_cu, clock_ghz, js, false);
+  run<27>("v_fma_f32 (3 rotating sources)", 2, num_cu, clock_ghz, js, false);
+  run<7>("v_permlane32_swap", 0, num_cu, clock_ghz, js, false);
+  run<8>("v_permlane16_swap", 0, num_cu, clock_ghz, js, false);
+  run<9>("v_add_f32_dpp quad_perm", 1, num_cu, clock_ghz, js, false);
+  run<10>("v_add_f32_dpp row_ror", 1, num_cu, clock_ghz, js, false);
   if (js) { fprintf(js, "\n]}\n"); fclose(js); }
   return 0;
 }
