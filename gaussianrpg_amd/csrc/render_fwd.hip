@@ -162,8 +162,42 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
     }
   }
   if (any == 0ull) return false;   // nobody in the wave blends any of these splats
+  // Transmittance chains first (alpha = 0 where a lane rejects a splat): if no live pixel's T falls
+  // below 1e-4 by the END of the group, none terminates inside it (T only decreases) and the
+  // per-splat termination tests are not needed -- see blend_quad.  Same products, same order.
+  float w[G][PX], Tn[PX];
+  uint64_t bad = 0ull;
 #pragma unroll
-  for (int g = 0; g < G; g++) {
+  for (int k = 0; k < PX; k++) {
+    const uint64_t live = ~s.done[k];
+    float T = s.T[k];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const float am = in_mask(ok[g][k] & live) ? alpha[g][k] : 0.0f;
+      w[g][k] = am * T;
+      T = (1.0f - am) * T;
+    }
+    Tn[k] = T;
+    bad |= lanes(T < 0.0001f) & live;
+  }
+  if (bad == 0ull) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+#pragma unroll
+      for (int k = 0; k < PX; k++) {
+        s.CrCg[k].x = fmaf(rc[g].x, w[g][k], s.CrCg[k].x);
+        s.CrCg[k].y = fmaf(rc[g].y, w[g][k], s.CrCg[k].y);
+        s.CbD[k].x = fmaf(rc[g].z, w[g][k], s.CbD[k].x);
+        s.CbD[k].y = fmaf(rc[g].w, w[g][k], s.CbD[k].y);
+        if (AUX) s.last[k] = in_mask(ok[g][k] & ~s.done[k]) ? __float_as_uint(ra[g].w) : s.last[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PX; k++) s.T[k] = Tn[k];
+    return true;
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++) {   // some pixel terminates inside this group: exact per-splat blend
 #pragma unroll
     for (int k = 0; k < PX; k++)
       blend_one<PX, AUX>(s, k, ok[g][k], alpha[g][k], rc[g], __float_as_uint(ra[g].w));
@@ -208,11 +242,44 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
     ok[2 * h + 0] = lanes(!(p.x > 0.0f)) & lanes(!(alpha[2 * h + 0] < ALPHA_MIN));
     ok[2 * h + 1] = lanes(!(p.y > 0.0f)) & lanes(!(alpha[2 * h + 1] < ALPHA_MIN));
   }
-  if (((ok[0] | ok[1] | ok[2] | ok[3]) & ~s.done[0]) == 0ull) return false;
+  const uint64_t live = ~s.done[0];
+  if (((ok[0] | ok[1] | ok[2] | ok[3]) & live) == 0ull) return false;
+  // The transmittance chain of the four splats first, with alpha = 0 in the lanes that reject a
+  // splat.  T only ever decreases, so if the LAST T is still >= 1e-4 in every live lane, no pixel
+  // terminates inside this quad and the per-splat termination tests (a v_cmp and two v_cndmask
+  // each: half-rate instructions, tools/ubench/valu_rate.hip) are not needed: the colours are
+  // accumulated with the weights just computed -- the same products in the same order, hence the
+  // same bits (a rejecting lane adds c * 0 and keeps T * 1).  A pixel terminates at most once, so the
+  // exact per-splat path below runs for at most 64 quads of a wave.
+  float w[4];
+  float T = s.T[0];
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-    // (skipping the blend of a splat no live lane accepts -- 1 in 6 survivors -- with a scalar
-    // branch per splat was measured: 0.253 -> 0.272 ms; the branches cost more than the 9 VALU)
+  for (int i = 0; i < 4; i++) {
+    const float am = in_mask(ok[i] & live) ? alpha[i] : 0.0f;
+    const v2f tw = (v2f){1.0f - am, am} * (v2f){T, T};
+    w[i] = tw.y;
+    T = tw.x;
+  }
+  if ((lanes(T < 0.0001f) & live) == 0ull) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4];
+      const v2f w0 = {w[2 * h], w[2 * h]}, w1 = {w[2 * h + 1], w[2 * h + 1]};
+      s.CrCg[0] = __builtin_elementwise_fma((v2f){c0.x, c0.y}, w0, s.CrCg[0]);
+      s.CbD[0] = __builtin_elementwise_fma((v2f){c0.z, c0.w}, w0, s.CbD[0]);
+      s.CrCg[0] = __builtin_elementwise_fma((v2f){c1.x, c1.y}, w1, s.CrCg[0]);
+      s.CbD[0] = __builtin_elementwise_fma((v2f){c1.z, c1.w}, w1, s.CbD[0]);
+      if (AUX) {   // n_contrib: position of the last splat the pixel took
+        const float4 pp = blk[h * PAIR_F4 + 5];
+        s.last[0] = in_mask(ok[2 * h] & live) ? __float_as_uint(pp.x) : s.last[0];
+        s.last[0] = in_mask(ok[2 * h + 1] & live) ? __float_as_uint(pp.y) : s.last[0];
+      }
+    }
+    s.T[0] = T;
+    return true;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {   // some pixel terminates in this quad: the exact per-splat blend
     const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4], pp = blk[h * PAIR_F4 + 5];
     blend_one<1, AUX>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x));
     blend_one<1, AUX>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y));
