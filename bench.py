@@ -258,6 +258,35 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
             else:
                 bw.append(t4 - t2)
             Vs.append(int(pkg["visibility_filter"].sum()))
+    # The op alone, arguments resident on the device (means2D = zeros on the DEVICE: the reference
+    # caller's `torch.zeros(P, 3, requires_grad=True).float().cuda() + 0` makes autograd copy the
+    # [P, 3] gradient back to the HOST inside loss.backward() -- 12 MB over PCIe, inside the event
+    # pair above).  Same scene, cameras and loss; event pairs around the op's forward and backward.
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    of, obd = [], []
+    for it in range(warmup + steps):
+        cam = hz.trajectory_camera(it % NUM_FRAMES, device=dev)
+        rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        for t in leaves[:5]:
+            t.grad = None
+        ef0, ef1, eb0, eb1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        torch.cuda.synchronize()
+        ef0.record()
+        color, radii, depth, alpha, _ = rast(means3D=leaves.means3D, means2D=m2d, opacities=leaves.opacity,
+                                             shs=leaves.shs, scales=leaves.scales, rotations=leaves.rotations)
+        ef1.record()
+        loss = (color - gt).abs().mean() + 0.1 * (depth / (alpha + 1e-10)).mean() + 0.05 * alpha.mean()
+        outs = (color, depth, alpha)
+        gouts = torch.autograd.grad(loss, outs, retain_graph=True)
+        torch.cuda.synchronize()
+        eb0.record()
+        torch.autograd.backward(outs, gouts)
+        eb1.record()
+        torch.cuda.synchronize()
+        if it >= warmup:
+            of.append(ef0.elapsed_time(ef1)); obd.append(eb0.elapsed_time(eb1))
+    of.sort(), obd.sort()
     # num_rendered of the last frames (untimed)
     e = torch.Tensor([])
     with torch.no_grad():
@@ -273,12 +302,19 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
     b_bwd = (28 + 4 * S) * N + (44 + 4 * S) * R + 92 * V + (163 + 24 * M + 4 * S) * P
     bwd_ms = 1e3 * bw[len(bw) // 2]
     op_bwd_ms = ob[len(ob) // 2]
+    op_only_bwd_ms = obd[len(obd) // 2]
     return {"config": "configs[4]: train fwd+bwd, scene-149-like P=%d @%dx%d, train-mode arguments, "
                       "loss = L1 + sky(acc) + lidar(depth/acc) (train.py:110-176)" % (P, W, H),
             "steps": steps, "P": P, "V_avg": V, "R_avg": R,
             "forward_ms_median": 1e3 * fw[len(fw) // 2], "backward_ms_median": bwd_ms,
             "loss_backward_ms_median": 1e3 * lb[len(lb) // 2],
             "op_backward_device_ms_median": op_bwd_ms,
+            "op_only": {"forward_device_ms_median": of[len(of) // 2], "backward_device_ms_median": op_only_bwd_ms,
+                        "what": "the op's forward / backward alone between two events, means2D allocated on the "
+                                "device (tools/bench_train.py's pattern); op_backward_device_ms_median above goes "
+                                "through the reference caller's pattern, whose `.cuda()` of a host zeros tensor "
+                                "makes autograd copy the [P,3] means2D gradient back to the host (12 MB over PCIe) "
+                                "inside the event pair"},
             "timing": "forward / backward / loss_backward: synchronize-bracketed wall time (backward = "
                       "loss.backward(): the loss' own PyTorch backward + _C.rasterize_gaussians_backward incl. "
                       "gradient allocation, on every other iteration; loss_backward = the loss' own backward "
@@ -286,10 +322,12 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
                       "backward alone (gradient zero-fill + render_backward_kernel + "
                       "preprocess_backward_kernel); per-kernel times: profiles/round3_train_summary.txt",
             "backward_algorithmic_bytes": b_bwd,
-            "backward_roofline": {"bound": "hbm", "achieved": b_bwd / (op_bwd_ms * 1e-3) / 1e9,
+            "backward_roofline": {"bound": "hbm", "achieved": b_bwd / (op_only_bwd_ms * 1e-3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": b_bwd / (op_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "measured": "algorithmic bytes / op_backward_device_ms_median"}}
+                                  "frac": b_bwd / (op_only_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "measured": "algorithmic bytes / op_only.backward_device_ms_median",
+                                  "note": "the backward is VALU-bound (the vector ALUs are busy for the whole "
+                                          "render_backward_kernel launch, DESIGN.md §7), not HBM-bound"}}
 
 
 def main():

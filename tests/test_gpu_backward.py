@@ -155,6 +155,65 @@ def test_backward_long_lists(dev):
     _run(dev, sc, hz.trajectory_camera(0, W=64, H=64), torch.tensor([0.1, 0.4, 0.2]), seed=11)
 
 
+def _long_list_gradients(dev, backward_twice=False):
+    """Gradients of the 10-18 k-entry scene for a fixed loss; no oracle (used to compare schedules)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.toy_scene(40000, seed=21, sh_degree=1, depth=6.0, spread=0.8, scale=0.015)
+    cam = hz.trajectory_camera(0, W=64, H=64, device=dev)
+    g = torch.Generator().manual_seed(5)
+    gc, gd, ga = (torch.randn(c, 64, 64, generator=g).to(dev) for c in (3, 1, 1))
+    rast = GaussianRasterizer(GaussianRasterizationSettings(
+        **hz.settings_kwargs(cam, 1, bg=torch.tensor([0.1, 0.4, 0.2], device=dev))))
+    leaves = [t.to(dev).clone().requires_grad_(True)
+              for t in (sc.means3D, sc.opacity, sc.shs, sc.scales, sc.rotations)]
+    means2D = torch.zeros(sc.means3D.shape[0], 3, device=dev, requires_grad=True)
+    color, radii, depth, alpha, _ = rast(means3D=leaves[0], means2D=means2D, opacities=leaves[1],
+                                         shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+    loss = (color * gc).sum() + 0.1 * (depth * gd).sum() + (alpha * ga).sum()
+    out = []
+    for _ in range(2 if backward_twice else 1):
+        for t in leaves + [means2D]:
+            t.grad = None
+        loss.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        out.append([t.grad.detach().cpu().numpy().copy() for t in leaves + [means2D]])
+    return out
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def test_backward_twice_on_one_forward(dev):
+    """retain_graph: the blend checkpoints and the (tile, segment) items the training forward left
+    behind are state of the FRAME; a second backward on it finds them unchanged (only the float
+    atomics' order differs between two runs)."""
+    g1, g2 = _long_list_gradients(dev, backward_twice=True)
+    for a, b in zip(g1, g2):
+        assert np.isfinite(a).all() and _rel_l2(a, b) < 1e-5
+
+
+def test_backward_segments_match_single_chain(dev, tmp_path):
+    """The segmented walk of long lists (forward checkpoints, default) against the same library
+    walking every list as one chain (GRPG_BWD_SEG=0, read once per process: a child process)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "chain.npz")
+    code = ("import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
+            "import test_gpu_backward as t\n"
+            "g = t._long_list_gradients(torch.device('cuda:0'))[0]\n"
+            "np.savez(%r, *g)\n" % (here, os.path.dirname(here), out))
+    env = dict(os.environ, GRPG_BWD_SEG="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+    chain = np.load(out)
+    seg = _long_list_gradients(dev)[0]
+    for i, a in enumerate(seg):
+        b = chain["arr_%d" % i]
+        assert _rel_l2(a, b) < 2e-4, (i, _rel_l2(a, b))
+
+
 def test_backward_colors_and_cov_precomp(dev):
     sc = hz.toy_scene(1200, seed=33, sh_degree=1, scale=0.1)
     _run(dev, sc, hz.trajectory_camera(0, W=96, H=64), torch.ones(3), use_colors=True, use_cov=True,
