@@ -510,8 +510,17 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key.
     uint32_t* tiles_sorted = (uint32_t*)(geom + GL.tiles_sorted);
     const uint32_t* sorted_gid;
+    // hierarchical binning on a grid of <= 255 x 255 tiles: the tile rectangles ride through the
+    // depth sort as a packed payload and arrive in depth order together with the super-tile counts
+    // (sort.hip RectPayload); GRPG_SORT_RECT=0: the coarse scan gathers them by sorted id instead
+    static const int sort_rect_on = [] { const char* e = getenv("GRPG_SORT_RECT"); return e ? atoi(e) : 1; }();
+    const bool rect_sorted_by_sort = hier && sort_rect_on && cam.gx <= 255 && cam.gy <= 255;
     if (fat_sort) {   // drops the culled Gaussians: V pairs remain
-      depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V);
+      if (rect_sorted_by_sort)   // scratch: rect_sorted's own first half and the not yet written offsets
+        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
+                       rects, (uint32_t*)rect_sorted, offsets, rect_sorted, tiles_sorted);
+      else
+        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V);
       sorted_gid = val_a;
     } else {          // culled keys sort last (tile count 0); V stays P
       const bool in_b = radix_sort_pairs(stream, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true,
@@ -605,9 +614,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       uint32_t* btotals = (uint32_t*)(binp + L.totals);
       uint2* cranges = (uint2*)(binp + L.cranges);
       tm.mark(2);
-      launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, sorted_gid, nullptr, offsets,
-                          block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap, rects,
-                          rect_sorted);
+      if (rect_sorted_by_sort)   // counts and rectangles are already in depth order
+        launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, nullptr, nullptr, offsets,
+                            block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap);
+      else
+        launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, sorted_gid, nullptr, offsets,
+                            block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap, rects,
+                            rect_sorted);
       STAGE_CHECK("coarse offsets scan");
       tm.mark(3);
       launch_emit_coarse(stream, &gh->V, &gh->Rc, ccap, sorted_gid, rect_sorted, offsets, emit_win,

@@ -332,7 +332,10 @@ int radix_sort_first_pass_bits(int begin_bit, int end_bit);
 
 // Fat depth sort (sort.hip): result in (key_a, val_a), V visible pairs; see depth_sort_fat.
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out);
+                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
+                    const uint2* rects_by_id = nullptr /* hierarchical binning: the rectangles ride along */,
+                    uint32_t* aux_a = nullptr, uint32_t* aux_b = nullptr, uint2* rect_sorted = nullptr,
+                    uint32_t* counts_sorted = nullptr);
 
 // offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total_out (device) = sum, also stored
 // to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.  gather_gid != NULL:

@@ -286,14 +286,35 @@ depth_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict_
   if (threadIdx.x < DS_RADIX) table[(size_t)blockIdx.x * DS_RADIX + threadIdx.x] = h[threadIdx.x];
 }
 
-template <int PASS>
+// Payload of the hierarchical binning (RECT): a Gaussian's tile rectangle travels with its (key, id)
+// pair, packed into one word (8 bits per bound: grids of <= 255 x 255 tiles).  Pass 0 reads the
+// rectangles in id order -- fully coalesced, its ids ARE its positions -- and the last pass leaves
+// them behind in DEPTH order (rect_sorted) together with the super-tile counts the coarse scan
+// sums: the scan's random gather by sorted id (26 us: 8 useful bytes per line) disappears for
+// 4 bytes per pair and pass.
+struct RectPayload {
+  const uint2* rects_by_id;   // pass 0 input
+  const uint32_t* aux_in;     // passes 1..3 input (packed)
+  uint32_t* aux_out;          // passes 0..2 output (packed)
+  uint2* rect_sorted;         // pass 3 output
+  uint32_t* counts_sorted;    // pass 3 output: super-tiles per Gaussian, depth order
+};
+__device__ __forceinline__ uint32_t rect_pack(const uint2 r) {
+  return (r.x & 0xFFu) | ((r.x >> 16) << 8) | ((r.y & 0xFFu) << 16) | ((r.y >> 16) << 24);
+}
+__device__ __forceinline__ uint2 rect_unpack(const uint32_t p) {
+  return make_uint2((p & 0xFFu) | (((p >> 8) & 0xFFu) << 16), ((p >> 16) & 0xFFu) | ((p >> 24) << 16));
+}
+
+template <int PASS, bool RECT>
 __global__ void __launch_bounds__(DS_THREADS)
 depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                      const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][256] */,
-                     const uint32_t nchunks, uint32_t* __restrict__ V_out) {
+                     const uint32_t nchunks, uint32_t* __restrict__ V_out, const RectPayload rp) {
   __shared__ uint32_t s_keys[DS_CHUNK];
   __shared__ uint32_t s_vals[DS_CHUNK];
+  __shared__ uint32_t s_aux[RECT ? DS_CHUNK : 1];
   __shared__ uint32_t s_cnt[DS_WAVES * DS_RADIX];   // [wave][digit]: bank-conflict-free ranking
   __shared__ uint32_t s_gbase[DS_RADIX];
   __shared__ uint32_t s_w[8];
@@ -311,7 +332,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   const uint32_t n_in = PASS == 0 ? P : *V_out;
   const uint32_t chunk_base = chunk * DS_CHUNK;
   const uint32_t chunk_n = chunk_base < n_in ? min((uint32_t)DS_CHUNK, n_in - chunk_base) : 0u;
-  uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS];
+  uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS], aux[RECT ? DS_ITEMS : 1];
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
     const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
@@ -319,6 +340,8 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const bool inb = local < chunk_n;
     key[i] = inb ? keys_in[idx] : CULLED_KEY;
     val[i] = PASS == 0 ? idx : (inb ? vals_in[idx] : 0u);
+    if (RECT)   // a culled Gaussian's rectangle was never written: loaded, never used
+      aux[i] = !inb ? 0u : (PASS == 0 ? rect_pack(rp.rects_by_id[idx]) : rp.aux_in[idx]);
   }
 
   // ---- sweep the count table: per digit, sum over earlier chunks and over all chunks ----
@@ -417,6 +440,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       const uint32_t slot = s_cnt[wave * DS_RADIX + d] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
+      if (RECT) s_aux[slot] = aux[i];
     }
   }
   __syncthreads();
@@ -430,28 +454,52 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       const uint32_t g = s_gbase[(k >> shift) & (DS_RADIX - 1)] + j;
       keys_out[g] = k;
       vals_out[g] = s_vals[j];
+      if (RECT) {
+        if (PASS < 3) {
+          rp.aux_out[g] = s_aux[j];
+        } else {
+          const uint2 r = rect_unpack(s_aux[j]);
+          rp.rect_sorted[g] = r;
+          rp.counts_sorted[g] = rect_super_tiles(r.x, r.y);
+        }
+      }
     }
   }
 }
 
 // Depth sort of the P (key, id) pairs; ids are implicit in pass 0.  Result: (key_a, val_a) hold
 // the V visible pairs in (depth_bits, id) order, *V_out = V (the per-Gaussian tile counts are
-// brought into sorted order by the offsets scan's reduce launch).  ds_table must be zero except
+// brought into sorted order by the offsets scan's reduce launch -- or, with the rectangle payload
+// below, arrive in sorted order with the last pass).  ds_table must be zero except
 // for the rows of pass 0 (preprocess).  7 launches.
+// rects_by_id != NULL (hierarchical binning, grid <= 255 x 255 tiles): the tile rectangles ride along
+// (RectPayload above); aux_a / aux_b are two scratch arrays of P words, rect_sorted [P] and
+// counts_sorted [P] receive the rectangles and super-tile counts in depth order.  aux_a may alias
+// rect_sorted (it is dead before pass 3 writes that array).
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out) {
+                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
+                    const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint2* rect_sorted,
+                    uint32_t* counts_sorted) {
   if (P == 0) return;
   const size_t tsz = (size_t)nchunks * DS_RADIX;
-#define DS_SCATTER(PASS, KI, VI, KO, VO)                                                        \
-  depth_scatter_kernel<PASS><<<nchunks, DS_THREADS, 0, s>>>(KI, VI, KO, VO, P, ds_table + PASS * tsz, \
-                                                            nchunks, V_out)
-  DS_SCATTER(0, key_a, nullptr, key_b, val_b);
+  const bool rect = rects_by_id != nullptr;
+#define DS_SCATTER(PASS, KI, VI, KO, VO, AI, AO)                                                 \
+  do {                                                                                           \
+    const RectPayload rp = {rects_by_id, AI, AO, rect_sorted, counts_sorted};                    \
+    if (rect)                                                                                    \
+      depth_scatter_kernel<PASS, true><<<nchunks, DS_THREADS, 0, s>>>(                           \
+          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp);                         \
+    else                                                                                         \
+      depth_scatter_kernel<PASS, false><<<nchunks, DS_THREADS, 0, s>>>(                          \
+          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp);                         \
+  } while (0)
+  DS_SCATTER(0, key_a, nullptr, key_b, val_b, nullptr, aux_b);
   depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 8, ds_table + 1 * tsz);
-  DS_SCATTER(1, key_b, val_b, key_a, val_a);
+  DS_SCATTER(1, key_b, val_b, key_a, val_a, aux_b, aux_a);
   depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_a, V_out, 16, ds_table + 2 * tsz);
-  DS_SCATTER(2, key_a, val_a, key_b, val_b);
+  DS_SCATTER(2, key_a, val_a, key_b, val_b, aux_a, aux_b);
   depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 24, ds_table + 3 * tsz);
-  DS_SCATTER(3, key_b, val_b, key_a, val_a);
+  DS_SCATTER(3, key_b, val_b, key_a, val_a, aux_b, nullptr);
 #undef DS_SCATTER
 }
 
