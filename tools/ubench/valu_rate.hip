@@ -258,7 +258,6 @@ int main(int argc, char** argv) {
   run<22>("v_med3_f32", 0, num_cu, clock_ghz, js, false);
   run<23>("v_cmp_gt_f32 -> vcc (e32)", 0, num_cu, clock_ghz, js, false);
   run<24>("v_cmp_lt_u32 -> sgpr", 0, num_cu, clock_ghz, js, false);
-  run<25>("v_cndmask_b32 (vcc, e32)", 0, num_cu, clock_ghz, js, false);
   run<26>("v_pk_add_f32", 2, num_cu, clock_ghz, js, false);
   run<27>("v_fma_f32 (3 rotating sources)", 2, num_cu, clock_ghz, js, false);
   run<7>("v_permlane32_swap", 0, num_cu, clock_ghz, js, false);
