@@ -88,7 +88,7 @@ static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 // slot ckpt_tile_base(range.x) + k, quarter q.  Slots never overlap: consecutive long tiles are
 // >= 2 CK_SEG entries apart and floor(1.5 (x + len) / SEG) - floor(1.5 x / SEG) >= len / SEG + 1.
 #ifndef GRPG_CK_SEG
-#define GRPG_CK_SEG 1024
+#define GRPG_CK_SEG 2048
 #endif
 #ifndef GRPG_CK_LONG_MIN
 #define GRPG_CK_LONG_MIN (2 * GRPG_CK_SEG)

@@ -10,10 +10,10 @@
 //   * LIGHT tiles: one wave per tile, 4 pixels per lane.  HEAVY tiles: four 16x4 quarter-tile
 //     waves at 1 pixel per lane (a heavy tile no longer serialises behind one wave).
 //   * LONG tiles (>= CK_LONG_MIN entries) are not one serial chain: the training forward left blend
-//     checkpoints behind (common.h CK_*: per quarter the state (T, C, D) at batch ends >= 1024
+//     checkpoints behind (common.h CK_*: per quarter the state (T, C, D) at batch ends >= CK_SEG
 //     positions apart), and the first workgroups of the launch walk (tile, segment) items that start
 //     from them: T at the segment's end from the checkpoint, the accumulators from
-//     (C_final - C_k) / T_k.  render_backward_kernel 744 -> 512 us at config 5.
+//     (C_final - C_k) / T_k.  render_backward_kernel 744 -> 505 us at config 5.
 //   * The list is walked back to front, only up to the deepest contributor of the wave's pixels,
 //     through the forward's FILL / POP / process pipeline: FILL scans 128 entries per step and
 //     keeps those whose sub-tile mask (set by emit) concerns the wave in an LDS ring; POP starts

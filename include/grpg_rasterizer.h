@@ -340,7 +340,7 @@ GRPG_API int grpg_set_binning_algorithm(int alg);
  * geometry blob has no room for the gradient records the backward accumulates in its tail; the
  * geometry blob is therefore written by this call, the other two are only read).
  * A forward a backward may follow (S == 0) also asks its binning callback for room behind the
- * point list for blend checkpoints of the tile lists with >= 2048 entries (6 KB per 683 instances of
+ * point list for blend checkpoints of the tile lists with >= 4096 entries (6 KB per 1365 instances of
  * capacity): the backward starts independent walks from them instead of walking
  * such a list as one serial chain.  R must be the forward's return value (it bounds the number of
  * those walks); the call may be repeated on the same three blobs.
