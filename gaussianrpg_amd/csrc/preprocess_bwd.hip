@@ -334,6 +334,113 @@ struct SegmentGradDev {
 
 constexpr int POSE_ACC = 16;   // per segment: dL/dt (3), dL/dR row-major (9), dL/da product path (4)
 
+// One Gaussian of the composed training backward.  sg / go refer either to the workgroup's copies in
+// LDS (all 256 Gaussians in one segment: the common case) or to the tables in global memory; the
+// function is inlined into both call sites, so each knows its address space and the stores to the
+// gradient arrays cannot force the table fields to be reloaded.
+template <bool M4>
+__device__ __forceinline__ void composed_backward_one(
+    const SegmentDev& sg, const SegmentGradDev& go, const int idx, const int D, const int M,
+    const int* __restrict__ radii, const RecView rec, const float scale_modifier,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    const float h_x, const float h_y, const float tan_fovx, const float tan_fovy,
+    const float4* __restrict__ grad_rec, float* __restrict__ dL_dmean2D, float (&pv)[POSE_ACC]) {
+  const int Mc = M4 ? 4 : M;   // compile-time trip counts in the common (SH degree 1) instance
+  const uint32_t j = (uint32_t)idx - sg.start;
+  const int F = sg.fourier_dim;
+  const bool vis = radii[idx] > 0;
+  if (!vis) {
+    dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
+    go.xyz[3 * j] = 0.f; go.xyz[3 * j + 1] = 0.f; go.xyz[3 * j + 2] = 0.f;
+    go.scaling[3 * j] = 0.f; go.scaling[3 * j + 1] = 0.f; go.scaling[3 * j + 2] = 0.f;
+    reinterpret_cast<float4*>(go.rotation)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    go.opacity[j] = 0.f;
+    for (int e = 0; e < 3 * F; e++) go.fdc[(size_t)j * F * 3 + e] = 0.f;
+    for (int e = 0; e < 3 * (Mc - 1); e++) go.frest[(size_t)j * (Mc - 1) * 3 + e] = 0.f;
+  } else {
+    const Activated a = compose_one(sg, j);
+    const BlendGrad bgr = load_blend_grad(grad_rec, idx);
+    dL_dmean2D[3 * idx] = bgr.g2x; dL_dmean2D[3 * idx + 1] = bgr.g2y; dL_dmean2D[3 * idx + 2] = bgr.gabs;
+    float c3[6];
+    cov3d_from_scale_rot(a.s0, a.s1, a.s2, scale_modifier, a.q, c3);
+    float sh[M4 ? 12 : 48], dsh[M4 ? 12 : 48];
+    compose_features(sg, j, a, Mc, sh);
+#pragma unroll
+    for (int e = 0; e < (M4 ? 12 : 48); e++) dsh[e] = 0.f;
+    const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
+    Vec3 gm;
+    float dcov[6], ds[3], dr[4];
+    preprocess_backward_core(Vec3{a.mx, a.my, a.mz}, c3, true, a.s0, a.s1, a.s2, scale_modifier, a.q, view,
+                             proj, campos, h_x, h_y, tan_fovx, tan_fovy, bgr, clamped, D, sh, dsh, gm, dcov,
+                             ds, dr);
+    // ---- activations ----
+    go.scaling[3 * j] = ds[0] * a.s0; go.scaling[3 * j + 1] = ds[1] * a.s1; go.scaling[3 * j + 2] = ds[2] * a.s2;
+    go.opacity[j] = bgr.gop * (a.opacity * (1.0f - a.opacity));
+    for (int c = 0; c < F; c++) {
+      go.fdc[((size_t)j * F + c) * 3 + 0] = dsh[0] * sg.idft[c];
+      go.fdc[((size_t)j * F + c) * 3 + 1] = dsh[1] * sg.idft[c];
+      go.fdc[((size_t)j * F + c) * 3 + 2] = dsh[2] * sg.idft[c];
+    }
+    for (int e = 0; e < 3 * (Mc - 1); e++) go.frest[(size_t)j * (Mc - 1) * 3 + e] = dsh[3 + e];
+    // ---- rotation: raw r -> ql = r / |r| [-> p = a (x) ql -> q = p / |p|] ----
+    const bool flip = sg.flip != nullptr && sg.flip[j] != 0;
+    const float4 rq = load_quat(sg.rotation, (int)j);
+    const float rn = fmaxf(sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w), 1e-12f);
+    const float4 qn_ = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
+    const float4 ql = flip ? make_float4(-qn_.z, qn_.w, qn_.x, -qn_.y) : qn_;   // as in compose_one
+    float4 gql = make_float4(dr[0], dr[1], dr[2], dr[3]);   // dL/dq of the quaternion the op used
+    if (sg.rigid) {
+      const float aw = sg.rot[0], ax = sg.rot[1], ay = sg.rot[2], az = sg.rot[3];
+      const float ow = aw * ql.x - ax * ql.y - ay * ql.z - az * ql.w;
+      const float ox = aw * ql.y + ax * ql.x + ay * ql.w - az * ql.z;
+      const float oy = aw * ql.z - ax * ql.w + ay * ql.x + az * ql.y;
+      const float oz = aw * ql.w + ax * ql.z - ay * ql.y + az * ql.x;
+      const float pn = fmaxf(sqrtf(ow * ow + ox * ox + oy * oy + oz * oz), 1e-12f);
+      // through q = p / |p| (a.q is that q)
+      const float along = a.q.x * gql.x + a.q.y * gql.y + a.q.z * gql.z + a.q.w * gql.w;
+      const float ipn = 1.0f / pn;
+      const float gw = (gql.x - a.q.x * along) * ipn, gx = (gql.y - a.q.y * along) * ipn,
+                  gy = (gql.z - a.q.z * along) * ipn, gz = (gql.w - a.q.w * along) * ipn;
+      // through the Hamilton product (general_utils.py:220-238): p = a (x) b, b = ql
+      gql = make_float4(aw * gw + ax * gx + ay * gy + az * gz, -ax * gw + aw * gx + az * gy - ay * gz,
+                        -ay * gw - az * gx + aw * gy + ax * gz, -az * gw + ay * gx - ax * gy + aw * gz);
+      pv[12] = ql.x * gw + ql.y * gx + ql.z * gy + ql.w * gz;
+      pv[13] = -ql.y * gw + ql.x * gx - ql.w * gy + ql.z * gz;
+      pv[14] = -ql.z * gw + ql.w * gx + ql.x * gy - ql.y * gz;
+      pv[15] = -ql.w * gw - ql.z * gx + ql.y * gy + ql.x * gz;
+    }
+    {
+      // back through the flip's signed permutation ql = (-n.y', n.z', n.w', -n.x') of the normalised
+      // local quaternion n = (w, x, y, z): dL/dn = (g_y, -g_z, -g_w, g_x) in (w, x, y, z) order
+      const float4 gn = flip ? make_float4(gql.z, -gql.w, -gql.x, gql.y) : gql;
+      const float along = qn_.x * gn.x + qn_.y * gn.y + qn_.z * gn.z + qn_.w * gn.w;
+      const float irn = 1.0f / rn;
+      reinterpret_cast<float4*>(go.rotation)[j] =
+          make_float4((gn.x - qn_.x * along) * irn, (gn.y - qn_.y * along) * irn, (gn.z - qn_.z * along) * irn,
+                      (gn.w - qn_.w * along) * irn);
+    }
+    // ---- mean: world == local, or m = R(a / |a|) x + t ----
+    if (sg.rigid) {
+      const float x = sg.xyz[3 * j], y = flip ? -sg.xyz[3 * j + 1] : sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
+      const float on = sqrtf(sg.rot[0] * sg.rot[0] + sg.rot[1] * sg.rot[1] + sg.rot[2] * sg.rot[2] +
+                             sg.rot[3] * sg.rot[3]);
+      const float r = sg.rot[0] / on, qx = sg.rot[1] / on, qy = sg.rot[2] / on, qz = sg.rot[3] / on;
+      const float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - r * qz), R02 = 2.f * (qx * qz + r * qy);
+      const float R10 = 2.f * (qx * qy + r * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - r * qx);
+      const float R20 = 2.f * (qx * qz - r * qy), R21 = 2.f * (qy * qz + r * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
+      go.xyz[3 * j] = R00 * gm.x + R10 * gm.y + R20 * gm.z;
+      go.xyz[3 * j + 1] = (flip ? -1.f : 1.f) * (R01 * gm.x + R11 * gm.y + R21 * gm.z);
+      go.xyz[3 * j + 2] = R02 * gm.x + R12 * gm.y + R22 * gm.z;
+      pv[0] = gm.x; pv[1] = gm.y; pv[2] = gm.z;
+      pv[3] = gm.x * x; pv[4] = gm.x * y; pv[5] = gm.x * z;
+      pv[6] = gm.y * x; pv[7] = gm.y * y; pv[8] = gm.y * z;
+      pv[9] = gm.z * x; pv[10] = gm.z * y; pv[11] = gm.z * z;
+    } else {
+      go.xyz[3 * j] = gm.x; go.xyz[3 * j + 1] = flip ? -gm.y : gm.y; go.xyz[3 * j + 2] = gm.z;
+    }
+  }
+}
+
 template <bool M4>
 __global__ void __launch_bounds__(256)
 preprocess_backward_composed_kernel(const int P, const int D, const int M,
@@ -348,117 +455,44 @@ preprocess_backward_composed_kernel(const int P, const int D, const int M,
   // one actor's sums, aggregated over the workgroup when all of its Gaussians belong to one segment
   __shared__ float s_pose[POSE_ACC];
   __shared__ int s_seg0;
+  __shared__ SegmentDev s_sg;          // the workgroup's segment (uniform case): one copy in LDS instead
+  __shared__ SegmentGradDev s_go;      // of a binary search and dependent global loads per thread
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (threadIdx.x < POSE_ACC) s_pose[threadIdx.x] = 0.f;
   const int last = min(P, (int)(blockIdx.x + 1) * 256) - 1;
   const SegmentDev* sg_first = find_segment(segs, nseg, (uint32_t)(blockIdx.x * 256));
   const bool uniform = sg_first == find_segment(segs, nseg, (uint32_t)last);
   if (threadIdx.x == 0) s_seg0 = (int)(sg_first - segs);
+  if (uniform) {
+    constexpr int SW = sizeof(SegmentDev) / 4, GW = sizeof(SegmentGradDev) / 4;
+    if (threadIdx.x < SW)
+      reinterpret_cast<uint32_t*>(&s_sg)[threadIdx.x] = reinterpret_cast<const uint32_t*>(sg_first)[threadIdx.x];
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + GW)
+      reinterpret_cast<uint32_t*>(&s_go)[threadIdx.x - 64] =
+          reinterpret_cast<const uint32_t*>(gsegs + (sg_first - segs))[threadIdx.x - 64];
+  }
   __syncthreads();
   float pv[POSE_ACC];
 #pragma unroll
   for (int i = 0; i < POSE_ACC; i++) pv[i] = 0.f;
-  const SegmentDev* sgp = nullptr;
+  bool rigid_lane = false;
+  int seg_index = 0;
   if (idx < P) {
-    const SegmentDev& sg = *find_segment(segs, nseg, (uint32_t)idx);
-    sgp = &sg;
-    const SegmentGradDev& go = gsegs[&sg - segs];
-    const uint32_t j = (uint32_t)idx - sg.start;
-    const int F = sg.fourier_dim;
-    const bool vis = radii[idx] > 0;
-    if (!vis) {
-      dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
-      go.xyz[3 * j] = 0.f; go.xyz[3 * j + 1] = 0.f; go.xyz[3 * j + 2] = 0.f;
-      go.scaling[3 * j] = 0.f; go.scaling[3 * j + 1] = 0.f; go.scaling[3 * j + 2] = 0.f;
-      reinterpret_cast<float4*>(go.rotation)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      go.opacity[j] = 0.f;
-      for (int e = 0; e < 3 * F; e++) go.fdc[(size_t)j * F * 3 + e] = 0.f;
-      for (int e = 0; e < 3 * (M - 1); e++) go.frest[(size_t)j * (M - 1) * 3 + e] = 0.f;
+    const SegmentDev* sgp = uniform ? sg_first : find_segment(segs, nseg, (uint32_t)idx);
+    seg_index = (int)(sgp - segs);
+    if (uniform) {
+      rigid_lane = s_sg.rigid != 0;
+      composed_backward_one<M4>(s_sg, s_go, idx, D, M, radii, rec, scale_modifier, view, proj, campos, h_x, h_y,
+                                tan_fovx, tan_fovy, grad_rec, dL_dmean2D, pv);
     } else {
-      const Activated a = compose_one(sg, j);
-      const BlendGrad bgr = load_blend_grad(grad_rec, idx);
-      dL_dmean2D[3 * idx] = bgr.g2x; dL_dmean2D[3 * idx + 1] = bgr.g2y; dL_dmean2D[3 * idx + 2] = bgr.gabs;
-      float c3[6];
-      cov3d_from_scale_rot(a.s0, a.s1, a.s2, scale_modifier, a.q, c3);
-      float sh[M4 ? 12 : 48], dsh[M4 ? 12 : 48];
-      compose_features(sg, j, a, M, sh);
-#pragma unroll
-      for (int e = 0; e < (M4 ? 12 : 48); e++) dsh[e] = 0.f;
-      const uint32_t clamped = __float_as_uint(rec.colour(idx).w);
-      Vec3 gm;
-      float dcov[6], ds[3], dr[4];
-      preprocess_backward_core(Vec3{a.mx, a.my, a.mz}, c3, true, a.s0, a.s1, a.s2, scale_modifier, a.q, view,
-                               proj, campos, h_x, h_y, tan_fovx, tan_fovy, bgr, clamped, D, sh, dsh, gm, dcov,
-                               ds, dr);
-      // ---- activations ----
-      go.scaling[3 * j] = ds[0] * a.s0; go.scaling[3 * j + 1] = ds[1] * a.s1; go.scaling[3 * j + 2] = ds[2] * a.s2;
-      go.opacity[j] = bgr.gop * (a.opacity * (1.0f - a.opacity));
-      for (int c = 0; c < F; c++) {
-        go.fdc[((size_t)j * F + c) * 3 + 0] = dsh[0] * sg.idft[c];
-        go.fdc[((size_t)j * F + c) * 3 + 1] = dsh[1] * sg.idft[c];
-        go.fdc[((size_t)j * F + c) * 3 + 2] = dsh[2] * sg.idft[c];
-      }
-      for (int e = 0; e < 3 * (M - 1); e++) go.frest[(size_t)j * (M - 1) * 3 + e] = dsh[3 + e];
-      // ---- rotation: raw r -> ql = r / |r| [-> p = a (x) ql -> q = p / |p|] ----
-      const bool flip = sg.flip != nullptr && sg.flip[j] != 0;
-      const float4 rq = load_quat(sg.rotation, (int)j);
-      const float rn = fmaxf(sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w), 1e-12f);
-      const float4 qn_ = make_float4(rq.x / rn, rq.y / rn, rq.z / rn, rq.w / rn);
-      const float4 ql = flip ? make_float4(-qn_.z, qn_.w, qn_.x, -qn_.y) : qn_;   // as in compose_one
-      float4 gql = make_float4(dr[0], dr[1], dr[2], dr[3]);   // dL/dq of the quaternion the op used
-      if (sg.rigid) {
-        const float aw = sg.rot[0], ax = sg.rot[1], ay = sg.rot[2], az = sg.rot[3];
-        const float ow = aw * ql.x - ax * ql.y - ay * ql.z - az * ql.w;
-        const float ox = aw * ql.y + ax * ql.x + ay * ql.w - az * ql.z;
-        const float oy = aw * ql.z - ax * ql.w + ay * ql.x + az * ql.y;
-        const float oz = aw * ql.w + ax * ql.z - ay * ql.y + az * ql.x;
-        const float pn = fmaxf(sqrtf(ow * ow + ox * ox + oy * oy + oz * oz), 1e-12f);
-        // through q = p / |p| (a.q is that q)
-        const float along = a.q.x * gql.x + a.q.y * gql.y + a.q.z * gql.z + a.q.w * gql.w;
-        const float gw = (gql.x - a.q.x * along) / pn, gx = (gql.y - a.q.y * along) / pn,
-                    gy = (gql.z - a.q.z * along) / pn, gz = (gql.w - a.q.w * along) / pn;
-        // through the Hamilton product (general_utils.py:220-238): p = a (x) b, b = ql
-        gql = make_float4(aw * gw + ax * gx + ay * gy + az * gz, -ax * gw + aw * gx + az * gy - ay * gz,
-                          -ay * gw - az * gx + aw * gy + ax * gz, -az * gw + ay * gx - ax * gy + aw * gz);
-        pv[12] = ql.x * gw + ql.y * gx + ql.z * gy + ql.w * gz;
-        pv[13] = -ql.y * gw + ql.x * gx - ql.w * gy + ql.z * gz;
-        pv[14] = -ql.z * gw + ql.w * gx + ql.x * gy - ql.y * gz;
-        pv[15] = -ql.w * gw - ql.z * gx + ql.y * gy + ql.x * gz;
-      }
-      {
-        // back through the flip's signed permutation ql = (-n.y', n.z', n.w', -n.x') of the normalised
-        // local quaternion n = (w, x, y, z): dL/dn = (g_y, -g_z, -g_w, g_x) in (w, x, y, z) order
-        const float4 gn = flip ? make_float4(gql.z, -gql.w, -gql.x, gql.y) : gql;
-        const float along = qn_.x * gn.x + qn_.y * gn.y + qn_.z * gn.z + qn_.w * gn.w;
-        reinterpret_cast<float4*>(go.rotation)[j] =
-            make_float4((gn.x - qn_.x * along) / rn, (gn.y - qn_.y * along) / rn, (gn.z - qn_.z * along) / rn,
-                        (gn.w - qn_.w * along) / rn);
-      }
-      // ---- mean: world == local, or m = R(a / |a|) x + t ----
-      if (sg.rigid) {
-        const float x = sg.xyz[3 * j], y = flip ? -sg.xyz[3 * j + 1] : sg.xyz[3 * j + 1], z = sg.xyz[3 * j + 2];
-        const float on = sqrtf(sg.rot[0] * sg.rot[0] + sg.rot[1] * sg.rot[1] + sg.rot[2] * sg.rot[2] +
-                               sg.rot[3] * sg.rot[3]);
-        const float r = sg.rot[0] / on, qx = sg.rot[1] / on, qy = sg.rot[2] / on, qz = sg.rot[3] / on;
-        const float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - r * qz), R02 = 2.f * (qx * qz + r * qy);
-        const float R10 = 2.f * (qx * qy + r * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - r * qx);
-        const float R20 = 2.f * (qx * qz - r * qy), R21 = 2.f * (qy * qz + r * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
-        go.xyz[3 * j] = R00 * gm.x + R10 * gm.y + R20 * gm.z;
-        go.xyz[3 * j + 1] = (flip ? -1.f : 1.f) * (R01 * gm.x + R11 * gm.y + R21 * gm.z);
-        go.xyz[3 * j + 2] = R02 * gm.x + R12 * gm.y + R22 * gm.z;
-        pv[0] = gm.x; pv[1] = gm.y; pv[2] = gm.z;
-        pv[3] = gm.x * x; pv[4] = gm.x * y; pv[5] = gm.x * z;
-        pv[6] = gm.y * x; pv[7] = gm.y * y; pv[8] = gm.y * z;
-        pv[9] = gm.z * x; pv[10] = gm.z * y; pv[11] = gm.z * z;
-      } else {
-        go.xyz[3 * j] = gm.x; go.xyz[3 * j + 1] = flip ? -gm.y : gm.y; go.xyz[3 * j + 2] = gm.z;
-      }
+      rigid_lane = sgp->rigid != 0;
+      composed_backward_one<M4>(*sgp, gsegs[seg_index], idx, D, M, radii, rec, scale_modifier, view, proj,
+                                campos, h_x, h_y, tan_fovx, tan_fovy, grad_rec, dL_dmean2D, pv);
     }
   }
   // ---- the actor's sums ----
-  const bool rigid_lane = sgp != nullptr && sgp->rigid != 0;
   if (uniform) {
-    if (segs[s_seg0].rigid) {
+    if (s_sg.rigid) {
 #pragma unroll
       for (int i = 0; i < POSE_ACC; i++) {
         float v = pv[i];
@@ -471,7 +505,7 @@ preprocess_backward_composed_kernel(const int P, const int D, const int M,
         atomicAdd(&pose_acc[(size_t)s_seg0 * POSE_ACC + threadIdx.x], s_pose[threadIdx.x]);
     }
   } else if (rigid_lane) {   // a workgroup across a model boundary (at most nseg - 1 of them)
-    const size_t sidx = (size_t)(sgp - segs);
+    const size_t sidx = (size_t)seg_index;
 #pragma unroll
     for (int i = 0; i < POSE_ACC; i++)
       if (pv[i] != 0.f) atomicAdd(&pose_acc[sidx * POSE_ACC + i], pv[i]);
