@@ -372,7 +372,8 @@ def test_streams_and_threads_give_identical_frames(dev):
                                  {"GRPG_DEPTH_SORT": "classic"}, {"GRPG_SYNC_R": "1"},
                                  {"GRPG_RCAP_TEST": "3000"}, {"GRPG_RCAP_TEST": "3000:3000000"},
                                  {"GRPG_BINNING": "sort"},
-                                 {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"}])
+                                 {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"},
+                                 {"GRPG_SORT_RECT": "0"}])
 def test_alternative_code_paths(env):
     """The experiment switches are read once per process, so the parity cases are re-run in a
     subprocess: no producer/consumer pairs; pairs for EVERY heavy tile; light path with one splat
@@ -380,7 +381,9 @@ def test_alternative_code_paths(env):
     reference-like mid-frame wait for num_rendered (exact binning-blob size); a binning capacity
     guess of 3000 instances, so that every frame overflows it and re-runs its tail (hierarchical
     binning: first with the coarse list overflowing too, then with only the point list); the sort-based
-    binning (emit + stable partition) instead of the hierarchical one, also with overflows."""
+    binning (emit + stable partition) instead of the hierarchical one, also with overflows; the
+    coarse scan gathering the tile rectangles by sorted id instead of receiving them from the depth
+    sort (the path of grids beyond 255 x 255 tiles)."""
     import os
     import subprocess
     import sys
