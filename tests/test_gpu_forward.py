@@ -204,6 +204,18 @@ def test_giant_splat_and_single_tile(dev):
     _check(_rasterize(dev, sc, cam1), o1, max_fragile_frac=0.5)
 
 
+def test_grid_wider_than_255_tiles(dev):
+    """A panorama strip 4144 pixels wide = 259 tile columns: the packed tile rectangle that rides
+    through the depth sort holds 8 bits per bound, so such grids take the coarse scan's gather path;
+    the same scene on a 4064-pixel (254-column) strip takes the payload path."""
+    sc = hz.toy_scene(3000, seed=18, sh_degree=1, spread=6.0)
+    for W in (4144, 4064):
+        cam = hz.trajectory_camera(0, W=W, H=48)
+        o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                           **oracle_kwargs(cam, 1))
+        _check(_rasterize(dev, sc, cam), o)
+
+
 def test_equal_depth_ties_keep_id_order(dev):
     """Duplicated Gaussians have identical depth keys: order must be ascending id (stable sort)."""
     sc = hz.toy_scene(500, seed=16, sh_degree=1)
