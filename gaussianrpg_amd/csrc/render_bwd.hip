@@ -7,8 +7,8 @@
 //
 // CDNA4 mapping (same decomposition as the forward, render_fwd.hip, whose tile work lists in the
 // image blob are reused):
-//   * LIGHT tiles: one wave per tile, 4 pixels per lane.  HEAVY tiles: four 16x4 quarter-tile
-//     waves at 1 pixel per lane (a heavy tile no longer serialises behind one wave).
+//   * Tiles with fewer than 2048 entries: two half-tile waves at 2 pixels per lane.  Longer ones:
+//     four 16x4 quarter-tile waves at 1 pixel per lane (their chains are the critical path).
 //   * LONG tiles (>= CK_LONG_MIN entries) are not one serial chain: the training forward left blend
 //     checkpoints behind (common.h CK_*: per quarter the state (T, C, D) at batch ends >= CK_SEG
 //     positions apart), and the first workgroups of the launch walk (tile, segment) items that start
@@ -528,9 +528,9 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                                  hi, k + 1u == n ? nullptr : rk, r0 + (size_t)(n - 1u) * 4 * CK_REC_FLOATS);
     return;
   }
-  // wide_classes = k: the k shortest heavy classes of the forward's classification are walked like
-  // light tiles here (one wave per tile, 4 pixels per lane) -- one reduction + atomic per
-  // (tile, splat) instead of four
+  // wide_classes = 1: the shortest heavy class of the forward's classification is walked like the
+  // light tiles here (two half-tile waves, 2 pixels per lane) -- one reduction + atomic per
+  // (half tile, splat) instead of one per quarter (see launch_render_backward)
   const uint32_t n0 = work[0], n1 = work[1];
   const uint32_t n2 = wide_classes >= 1 ? 0u : work[2];
   const uint32_t nmid = wide_classes >= 1 ? work[2] : 0u;
@@ -587,7 +587,13 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   if (seg_on && S <= 0 && bin_hdr && ck_count && bwd_ctl) items_cap = ckpt_slots(R);
   // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
   static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
-  static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 0; }();
+  // GRPG_BWD_WIDE (default 1): the forward's shortest heavy class (lists of 256 .. 2047 entries) is
+  // walked by two half-tile waves at 2 pixels per lane like the light tiles -- one reduction + atomic
+  // per (half tile, splat) instead of one per quarter.  The kernel is VALU-bound and a third of its
+  // cycles are that reduction: 515 -> 489 us at config 5, 645 -> 573 us on the 2 M-Gaussian scene
+  // (0 = quarter waves for every heavy tile; lists of 2048 .. 4095 entries as half tiles: slower,
+  // their chains become the tail).
+  static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 1; }();
   // GRPG_BWD_STATS=1: per-launch loop counters printed to stderr (synchronises: experiments only)
   static const int want_stats = [] { const char* e = getenv("GRPG_BWD_STATS"); return e ? atoi(e) : 0; }();
   static unsigned long long* stats_dev = nullptr;
