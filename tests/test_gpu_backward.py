@@ -214,6 +214,23 @@ def test_backward_segments_match_single_chain(dev, tmp_path):
         assert _rel_l2(a, b) < 2e-4, (i, _rel_l2(a, b))
 
 
+@pytest.mark.parametrize("env", [{"GRPG_BINNING": "sort"}, {"GRPG_RENDER_PC": "0"}, {"GRPG_PC_MUL": "1"},
+                                 {"GRPG_RCAP_TEST": "3000"}, {"GRPG_BWD_WIDE": "0"}, {"GRPG_BWD_LIGHT": "4"}])
+def test_backward_alternative_code_paths(env):
+    """Switches read once per process, hence a child process each: the sort-based binning blob (other
+    layout in front of the checkpoints); long tiles without / only with producer-consumer pairs in
+    the forward (the consumer writes the checkpoints there); a capacity guess every frame overflows,
+    so the checkpoints come from the re-run tail; quarter waves for every heavy tile; one wave per
+    light tile."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "test_backward_long_lists or test_backward_street or test_backward_twice"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_backward_colors_and_cov_precomp(dev):
     sc = hz.toy_scene(1200, seed=33, sh_degree=1, scale=0.1)
     _run(dev, sc, hz.trajectory_camera(0, W=96, H=64), torch.ones(3), use_colors=True, use_cov=True,
