@@ -1,9 +1,7 @@
 #!/bin/bash
-# build a variant (extra hipcc flags) and profile the train step on the GPU:
-#   bash tools/variant_run.sh <tag> "<flags>" [test] [ENV=val ...]
+# build a variant and profile BOTH training workloads (config 5 op, composed 2 M scene):
+#   bash tools/variant_run2.sh <tag> "<flags>"
 tag=$1; flags=$2; shift 2
-pre=""
-if [ "${1:-}" = "test" ]; then pre="timeout 600 python -m pytest tests/test_gpu_backward.py -m gpu -x -q 2>&1 | tail -2;"; shift; fi
 cd /root/repo
 GRPG_EXTRA_HIPCC_FLAGS="$flags" python -m gaussianrpg_amd.build --force > /dev/null 2>&1 || { echo "build failed"; exit 1; }
-/usr/local/graft/bin/gpurun --timeout 900 -- "$pre bash tools/gpu_prof_train.sh $tag $*; cat gpurun_out/proft_$tag.json" 2>&1 | grep -E "^$tag|op_backward|GPU-minutes|passed|failed"
+/usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/gpu_prof_train.sh $tag $*; bash tools/gpu_prof_compose.sh $tag $*" 2>&1 | grep -E "^$tag.*(render_backward|render_forward_kernel<true|eval fused)|GPU-minutes"
