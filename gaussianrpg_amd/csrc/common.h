@@ -130,8 +130,11 @@ static_assert(EMIT_PER_BLOCK == RS_CHUNK, "emit block must equal one radix chunk
 // "fat" depth sort (sort.hip): 1024-thread workgroups own 8192 keys; every workgroup derives its
 // digit bases straight from the [chunk][digit] count table, so a pass is ONE launch (+ one small
 // histogram launch for the next pass) instead of histogram / digit scan / scatter.
-constexpr int DS_THREADS = 1024;
-constexpr int DS_ITEMS = 8;
+#ifndef GRPG_DS_THREADS
+#define GRPG_DS_THREADS 1024
+#endif
+constexpr int DS_THREADS = GRPG_DS_THREADS;
+constexpr int DS_ITEMS = 8192 / DS_THREADS;
 constexpr int DS_CHUNK = DS_THREADS * DS_ITEMS;   // 8192 keys per workgroup
 constexpr int DS_WAVES = DS_THREADS / WAVE;       // 16
 constexpr int DS_RADIX = 256;
