@@ -260,6 +260,31 @@ struct StageTimer {
   }
 };
 
+// Backward: two device times per call (blend backward, preprocess backward), same mechanism -- but
+// process-wide: PyTorch runs an op's backward on its autograd thread, not on the thread that
+// switched the timing on.
+struct BwdTimingRecord { hipEvent_t ev[3]; };
+std::atomic<int> g_bwd_timing{0};
+std::mutex g_bwd_mu;
+std::vector<BwdTimingRecord*> g_bwd_pending;
+std::vector<BwdTimingRecord*> g_bwd_free;
+BwdTimingRecord* bwd_timing_begin(hipStream_t s) {
+  if (!g_bwd_timing.load()) return nullptr;
+  BwdTimingRecord* r = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_bwd_mu);
+    if (!g_bwd_free.empty()) { r = g_bwd_free.back(); g_bwd_free.pop_back(); }
+  }
+  if (!r) { r = new BwdTimingRecord(); for (auto& e : r->ev) (void)hipEventCreate(&e); }
+  (void)hipEventRecord(r->ev[0], s);
+  return r;
+}
+void bwd_timing_mark(BwdTimingRecord* r, int i, hipStream_t s) {
+  if (!r) return;
+  (void)hipEventRecord(r->ev[i], s);
+  if (i == 2) { std::lock_guard<std::mutex> lk(g_bwd_mu); g_bwd_pending.push_back(r); }
+}
+
 CameraArgs make_camera(const float* view, const float* proj, const float* campos, int W, int H,
                        float tan_fovx, float tan_fovy) {
   CameraArgs c;
@@ -284,6 +309,12 @@ int grpg_set_stage_timing(int enabled) {
   g_timing_enabled = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
   for (auto* r : g_pending) g_free.push_back(r);
   g_pending.clear();
+  g_bwd_timing.store(enabled != 0 ? 1 : 0);
+  {
+    std::lock_guard<std::mutex> lk(g_bwd_mu);
+    for (auto* r : g_bwd_pending) g_bwd_free.push_back(r);
+    g_bwd_pending.clear();
+  }
   return GRPG_OK;
 }
 int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls) {
@@ -303,6 +334,23 @@ int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls) {
     g_free.push_back(r);
   }
   g_pending.clear();
+  return GRPG_OK;
+}
+
+int grpg_get_backward_timing(float* blend_ms_sum, float* preprocess_ms_sum, int* num_calls) {
+  if (!blend_ms_sum || !preprocess_ms_sum || !num_calls) return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL output");
+  *blend_ms_sum = 0.f; *preprocess_ms_sum = 0.f; *num_calls = 0;
+  std::lock_guard<std::mutex> lk(g_bwd_mu);
+  for (auto* r : g_bwd_pending) {
+    hipError_t e = hipEventSynchronize(r->ev[2]);
+    if (e != hipSuccess) return fail(GRPG_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, r->ev[0], r->ev[1]);
+    (void)hipEventElapsedTime(&b, r->ev[1], r->ev[2]);
+    *blend_ms_sum += a; *preprocess_ms_sum += b; (*num_calls)++;
+    g_bwd_free.push_back(r);
+  }
+  g_bwd_pending.clear();
   return GRPG_OK;
 }
 
@@ -971,15 +1019,18 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
   HIP_TRY(hipEventRecord(stg->ev, stream));
   float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
   HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
+  BwdTimingRecord* const btr = bwd_timing_begin(stream);
   launch_render_backward(stream, ranges, point_list, rec, nullptr, 0, width, height, cam.gx, cam.gy,
                          background, alphas, n_contrib, (const uint32_t*)(image_buffer + IL.work), dL_dpix,
                          dL_dpix_depth, dL_dalphas, nullptr, grad_rec, nullptr,
                          (const BlobHeader*)binning_buffer, (const uint32_t*)(image_buffer + IL.ck_count),
                          (const uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
   STAGE_CHECK("render backward");
+  bwd_timing_mark(btr, 1, stream);
   launch_preprocess_backward_composed(stream, P, D, M, seg_dev, seg_grad_dev, num_segments, radii, rec,
                                       scale_modifier, cam, grad_rec, dL_dmean2D,
                                       (float*)(geom_buffer + GL.pose_acc), dL_dposes);
+  bwd_timing_mark(btr, 2, stream);
   STAGE_CHECK("preprocess backward (composed)");
   return GRPG_OK;
 }
@@ -1080,6 +1131,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   // accumulated by the blend backward, fanned out into the caller's arrays by the preprocess backward
   float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
   HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
+  BwdTimingRecord* const btr = bwd_timing_begin(stream);
   launch_render_backward(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
                          cam.gy, background, alphas, n_contrib,
                          (const uint32_t*)(image_buffer + IL.work), dL_dpix, dL_dpix_depth, dL_dalphas,
@@ -1087,11 +1139,13 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
                          (const uint32_t*)(image_buffer + IL.ck_count),
                          (const uint32_t*)(image_buffer + IL.bwd_ctl), (uint32_t)R);
   STAGE_CHECK("render backward");
+  bwd_timing_mark(btr, 1, stream);
   launch_preprocess_backward(stream, P, D, M, means3D, radii_int, colors_precomp ? nullptr : shs,
                              rec, cov3D_precomp ? nullptr : scales, rotations, scale_modifier,
                              cov3D_precomp, cam, grad_rec, dL_dmean2D, dL_dconic, dL_dopacity,
                              dL_dmean3D, dL_dcolor, dL_ddepth, dL_dcov3D,
                              colors_precomp ? nullptr : dL_dsh, dL_dscale, dL_drot);
+  bwd_timing_mark(btr, 2, stream);
   STAGE_CHECK("preprocess backward");
   return GRPG_OK;
 }

@@ -721,6 +721,14 @@ std::tuple<std::vector<float>, int> StageTiming() {
   return std::make_tuple(ms, calls);
 }
 
+std::tuple<float, float, int> BackwardTiming() {
+  float blend = 0.f, pre = 0.f;
+  int calls = 0;
+  const int rc = grpg_get_backward_timing(&blend, &pre, &calls);
+  if (rc != GRPG_OK) raise_abi_error("grpg_get_backward_timing", rc);
+  return std::make_tuple(blend, pre, calls);
+}
+
 // simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:14-25): [P,3] points -> [P] mean
 // squared distance to the 3 nearest other points.
 torch::Tensor distCUDA2(const torch::Tensor& points) {
@@ -768,6 +776,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("mask") = pybind11::none(), pybind11::arg("jitter") = pybind11::none());
   m.def("pack_u8", &PackU8, pybind11::arg("color"), pybind11::arg("out") = pybind11::none());
   m.def("pack_hwc", &PackHWC);
+  m.def("get_backward_timing", &BackwardTiming);   // (blend ms sum, preprocess ms sum, calls)
   m.def("set_stage_timing", [](int mode) { grpg_set_stage_timing(mode); });   // 0 off, 1 all, 2 render only
   m.def("stage_timing", &StageTiming);
   m.def("abi_version", []() { return grpg_abi_version(); });

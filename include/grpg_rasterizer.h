@@ -444,6 +444,10 @@ GRPG_API int grpg_pack_rgb_u8_hwc(const float* src_chw, unsigned char* dst_hwc, 
 #define GRPG_NUM_STAGES 8
 GRPG_API int grpg_set_stage_timing(int enabled);
 GRPG_API int grpg_get_stage_timing(float* stage_ms_sum, int* num_calls);
+/* While stage timing is enabled every grpg_backward / grpg_backward_composed on this thread records
+ * three events as well: this call waits for them and returns the summed device time of the blend
+ * backward (render_backward_kernel) and of the preprocess backward over *num_calls calls. */
+GRPG_API int grpg_get_backward_timing(float* blend_ms_sum, float* preprocess_ms_sum, int* num_calls);
 
 /*
  * distCUDA2: mean squared distance of every point to its 3 nearest OTHER points (used by the

@@ -184,6 +184,20 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
+def test_backward_timing_records_both_kernels(dev):
+    """grpg_get_backward_timing: events around the two backward launches, recorded on whatever thread
+    autograd runs the op's backward on."""
+    from gaussianrpg_amd.rasterizer import _C
+    _C.set_stage_timing(1)
+    try:
+        _long_list_gradients(dev, backward_twice=True)
+        blend, pre, calls = _C.get_backward_timing()
+    finally:
+        _C.set_stage_timing(0)
+    assert calls == 2 and 0.0 < pre < blend < 50.0
+    assert _C.get_backward_timing()[2] == 0
+
+
 def test_backward_twice_on_one_forward(dev):
     """retain_graph: the blend checkpoints and the (tile, segment) items the training forward left
     behind are state of the FRAME; a second backward on it finds them unchanged (only the float

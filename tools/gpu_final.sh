@@ -21,7 +21,7 @@ for n in ("bench_final_1","bench_final_2","bench_200"):
         print(n,"value %.1f ms %.4f"%(d["value"],d["ms_per_step"]),"entry",{k:(round(v,1) if isinstance(v,float) else v) for k,v in d["entry_points"].items() if k in("forward","forward_deferred")},
               "roof %.3f (%.4f ms)"%(d["roofline"]["frac"],d["roofline"]["avg_launch_ms"]),"valu",(d["roofline_valu"] or {}).get("frac"),"lat",d["frame_latency"]["median_ms"] if d["frame_latency"] else None,
               "opdev",d["op_device_time"]["median_ms"] if d["op_device_time"] else None,"sum",d["serial_stage_sum_ms"])
-        if d.get("train"): t=d["train"]; print("   train fwd %.3f bwd %.3f lossbwd %.3f opbwd_dev %.3f roof %.3f | op only: fwd %.3f bwd %.3f"%(t["forward_ms_median"],t["backward_ms_median"],t["loss_backward_ms_median"],t["op_backward_device_ms_median"],t["backward_roofline"]["frac"],t["op_only"]["forward_device_ms_median"],t["op_only"]["backward_device_ms_median"]))
+        if d.get("train"): t=d["train"]; print("   train fwd %.3f bwd %.3f lossbwd %.3f opbwd_dev %.3f roof %.3f | op only: fwd %.3f bwd %.3f"%(t["forward_ms_median"],t["backward_ms_median"],t["loss_backward_ms_median"],t["op_backward_device_ms_median"],t["backward_roofline"]["frac"],t["op_only"]["forward_device_ms_median"],t["op_only"]["backward_device_ms_median"]), "kernels", {k:(round(v,4) if isinstance(v,float) else v) for k,v in t["backward_kernels_ms"].items() if k!="measured"})
         if d.get("cpu_baseline"): print("   cpu",d["cpu_baseline"]["value"],d["cpu_baseline"]["c_restatement"]["openmp"]["value"])
         print("   stages",{k:round(v,4) for k,v in d["stages_ms_serial"].items() if v})
     except Exception as e: print(n,"parse error",e)
