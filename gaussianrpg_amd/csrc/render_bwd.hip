@@ -262,6 +262,7 @@ __device__ __forceinline__ void backward_rect(
   }
   const uint64_t ablate_m = (ablate & 4) ? 0ull : ~0ull;
   uint32_t st_fill = 0, st_batches = 0, st_iters = 0, st_used = 0, st_rows = 0;   // GRPG_BWD_STATS
+  unsigned long long st_small = 0ull;
   const unsigned long long st_t0 = stats ? __builtin_readcyclecounter() : 0ull;
   float4 la = make_float4(0, 0, 0, 0), lb = la, lc = la;   // current batch (records arrived)
   uint32_t lpos = 0, lid = 0, ncur = 0;
@@ -378,6 +379,7 @@ __device__ __forceinline__ void backward_rect(
 #pragma unroll
       for (int cc = 0; cc < SM; cc++) g_s[cc] = 0.f;
       bool any = false;
+      uint64_t st_lanes = 0ull;   // GRPG_BWD_STATS: lanes that take the splat for some pixel
 #pragma unroll
       for (int k = 0; k < PX; k++) {
         const float dy = a.y - pyf[k];
@@ -393,6 +395,7 @@ __device__ __forceinline__ void backward_rect(
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
         any = true;
         st_rows++;
+        st_lanes |= valid_m;
         // Branch-free below: a lane that rejects the splat runs the same arithmetic with
         // alpha = G = 0, which leaves its T and accumulators unchanged (T / (1 - 0), acc + 0 * d)
         // and contributes exact zeros to every sum.
@@ -443,6 +446,10 @@ __device__ __forceinline__ void backward_rect(
       }
       if (!any) continue;         // wave-uniform: nobody in the tile used this splat
       st_used++;
+      if (stats != nullptr) {
+        const int nl = (int)__popcll(st_lanes);
+        st_small += nl <= 1 ? 1ull : (nl <= 4 ? (1ull << 20) : (nl <= 8 ? (1ull << 40) : 0ull));
+      }
       if (ablate & 2) continue;   // experiment switch (GRPG_BWD_ABLATE): no reduction, no atomics
       {
         const float qv[12] = {g_mx, g_my, g_mabs, g_cxx, g_cxy, g_cyy, g_c[0], g_c[1], g_c[2], g_op,
@@ -474,7 +481,7 @@ __device__ __forceinline__ void backward_rect(
     r[4] = st_used;                           // ... of which some pixel used (reduction + atomic)
     r[5] = st_rows;                           // gradient blocks executed
     r[6] = __builtin_readcyclecounter() - st_t0;
-    r[7] = st_t0;
+    r[7] = st_small;                          // used trips with 1 / 2-4 / 5-8 accepting lanes (20 bits each)
   }
 }
 
@@ -642,20 +649,22 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
     (void)hipMemcpy(h.data(), stats_dev, stats_words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     unsigned long long waves[2] = {0, 0}, entries = 0, fills = 0, batches = 0, trips[2] = {0, 0}, used = 0, rows = 0;
     unsigned long long cyc_sum = 0, cyc_max = 0, trips_of_longest = 0, reach_of_longest = 0;
+    unsigned long long small1 = 0, small4 = 0, small8 = 0;
     for (size_t w = 0; w < stats_words / 8; w++) {
       const unsigned long long* r = &h[8 * w];
       if (!r[0]) continue;
       const int kind = r[0] == 1ull ? 0 : 1;
       waves[kind]++; entries += r[1]; fills += r[2] >> 32; batches += r[2] & 0xFFFFFFFFull;
       trips[kind] += r[3]; used += r[4]; rows += r[5]; cyc_sum += r[6];
+      small1 += r[7] & 0xFFFFFull; small4 += (r[7] >> 20) & 0xFFFFFull; small8 += (r[7] >> 40) & 0xFFFFFull;
       if (r[6] > cyc_max) { cyc_max = r[6]; trips_of_longest = r[3]; reach_of_longest = r[1]; }
     }
     fprintf(stderr, "[bwd stats] waves q %llu l %llu; entries_in_reach %llu fill_steps %llu batches %llu; trips q %llu l %llu "
                     "used %llu grad_blocks %llu | wave cycles: sum %llu mean %.0f max %llu (that wave: %llu trips, %llu entries "
-                    "in reach)\n",
+                    "in reach); used trips by accepting lanes: 1: %llu, 2-4: %llu, 5-8: %llu\n",
             waves[0], waves[1], entries, fills, batches, trips[0], trips[1], used, rows, cyc_sum,
             (waves[0] + waves[1]) ? (double)cyc_sum / (double)(waves[0] + waves[1]) : 0.0, cyc_max, trips_of_longest,
-            reach_of_longest);
+            reach_of_longest, small1, small4, small8);
   }
 }
 
