@@ -205,8 +205,10 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   const int S = dL_dout_semantic.size(0);
   TORCH_CHECK(S <= GRPG_MAX_SEMANTIC_BACKWARD, "rasterize_gaussians_backward supports at most ",
               GRPG_MAX_SEMANTIC_BACKWARD, " semantic channels, got ", S);
+  // rasterize_points.cu:159-163 takes M = 0 when sh has no rows; an EMPTY model (P = 0) that still
+  // carries shs of shape [0, M, 3] then gets a [0, 0, 3] gradient autograd rejects -- keep M
   int M = 0;
-  if (sh.size(0) != 0) M = sh.size(1);
+  if (sh.dim() == 3) M = sh.size(1);
 
   auto o = means3D.options();
   // The reference zero-fills eleven gradient arrays per call (rasterize_points.cu:166-176) because

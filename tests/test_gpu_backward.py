@@ -184,6 +184,31 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
+@pytest.mark.parametrize("case", ["all_culled", "one_splat", "empty"])
+def test_backward_degenerate_inputs(dev, case):
+    """Nothing visible (num_rendered = 0), a single Gaussian, an empty model (P = 0, which the
+    reference's renderer never passes to the op, street_gaussian_renderer.py:131-144): the backward
+    runs, gradients are finite and exactly zero where nothing was rendered."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = {"all_culled": hz.toy_scene(500, seed=3, depth=-10.0), "one_splat": hz.toy_scene(1, seed=4),
+          "empty": hz.toy_scene(0, seed=5)}[case]
+    cam = hz.trajectory_camera(0, W=64, H=48, device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
+    leaves = [t.to(dev).clone().requires_grad_(True)
+              for t in (sc.means3D, sc.opacity, sc.shs, sc.scales, sc.rotations)]
+    m2d = torch.zeros(leaves[0].shape[0], 3, device=dev, requires_grad=True)
+    color, radii, depth, alpha, _ = rast(means3D=leaves[0], means2D=m2d, opacities=leaves[1], shs=leaves[2],
+                                         scales=leaves[3], rotations=leaves[4])
+    (color.sum() + depth.sum() + alpha.sum()).backward()
+    torch.cuda.synchronize()
+    for t in leaves + [m2d]:
+        assert t.grad is not None and t.grad.shape == t.shape and bool(torch.isfinite(t.grad).all())
+    if case != "one_splat":
+        assert all(float(t.grad.abs().sum()) == 0.0 for t in leaves + [m2d])
+    else:
+        assert int((radii > 0).sum()) == 1 and float(leaves[0].grad.abs().sum()) > 0.0
+
+
 def test_backward_timing_records_both_kernels(dev):
     """grpg_get_backward_timing: events around the two backward launches, recorded on whatever thread
     autograd runs the op's backward on."""
