@@ -155,6 +155,14 @@ def test_backward_long_lists(dev):
     _run(dev, sc, hz.trajectory_camera(0, W=64, H=64), torch.tensor([0.1, 0.4, 0.2]), seed=11)
 
 
+def test_backward_long_lists_partial_tiles(dev):
+    """Long lists (segmented walk, producer/consumer forward) on an image whose right and bottom
+    tiles are cut by the border: quarters partly or wholly outside the image write and read their
+    checkpoints like the others."""
+    sc = hz.toy_scene(30000, seed=23, sh_degree=1, depth=6.0, spread=0.8, scale=0.015)
+    _run(dev, sc, hz.trajectory_camera(0, W=70, H=53), torch.tensor([0.3, 0.1, 0.2]), seed=12)
+
+
 def _long_list_gradients(dev, backward_twice=False):
     """Gradients of the 10-18 k-entry scene for a fixed loss; no oracle (used to compare schedules)."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
