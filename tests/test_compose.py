@@ -122,6 +122,33 @@ def test_fused_forward_equals_classic_on_composed_tensors(sh_degree):
 
 
 @pytest.mark.gpu
+def test_single_gaussian_actors():
+    """Actors of ONE Gaussian each behind a small one (a workgroup of the preprocess kernels then spans
+    four models; empty models are rejected by the binding, test_composed_argument_errors): fused ==
+    classic bit for bit, and the training backward returns gradients of every tensor's own shape."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianrpg_amd.composed import ComposedRasterizer, compose
+    dev = torch.device("cuda:0")
+    models, poses = _scene_graph(1, nb=5000, actors=((300, 5), (1, 3), (1, 2)))
+    models = [_to(m, dev, grad=True) for m in models]
+    cam = hz.trajectory_camera(2, W=320, H=208, device=dev)
+    rs = GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1))
+    fused = ComposedRasterizer(rs)
+    with torch.no_grad():
+        c1, r1, d1, a1 = fused(models, poses)
+        means, scales, rots, opac, shs = compose(models, poses)
+        c2, r2, d2, a2, _ = GaussianRasterizer(rs)(means3D=means, means2D=None, opacities=opac, shs=shs,
+                                                   scales=scales, rotations=rots)
+    assert torch.equal(r1, r2) and torch.equal(c1, c2) and torch.equal(d1, d2) and torch.equal(a1, a2)
+    c, r, d, a = fused(models, poses)
+    (c.sum() + d.sum() + a.sum()).backward()
+    torch.cuda.synchronize()
+    for m in models:
+        for t in m[:6]:
+            assert t.grad is not None and t.grad.shape == t.shape and bool(torch.isfinite(t.grad).all())
+
+
+@pytest.mark.gpu
 def test_composed_argument_errors():
     from gaussianrpg_amd.composed import ComposedRasterizer
     from diff_gaussian_rasterization import GaussianRasterizationSettings
