@@ -27,7 +27,7 @@ hb = bucket[~light]
 print("  all heavy waves: iters", hb[:, :4].sum(0), " Mcycles", (hb[:, 4:].sum(0) / 1e6).round(1))
 for i in np.argsort(-cyc)[:3]:
     print("  tile %d wave %d: iters %s kcycles %s" % (tile[i], v[i, 7] & 15, bucket[i, :4], (bucket[i, 4:] / 1e3).round(0)))
-for name, m in (("heavy", ~light), ("light", light)):
-    print("%s: stage cycles %.1f M, loop cycles %.1f M, wave cycles %.1f M (s_memtime ticks x?): stage share %.2f loop share %.2f" % (
-        name, tstage[m].sum() / 1e6, tloop[m].sum() / 1e6, 0.0, tstage[m].sum() / max(tstage[m].sum() + tloop[m].sum(), 1),
-        tloop[m].sum() / max(tstage[m].sum() + tloop[m].sum(), 1)))
+for name, m in (("heavy", ~light), ("light", light)):   # cull + compaction vs the blend loop, shader cycles
+    tot = max(tstage[m].sum() + tloop[m].sum(), 1)
+    print("%s: cull + compaction %.1f M cycles (%.2f), blend loop %.1f M cycles (%.2f)" % (
+        name, tstage[m].sum() / 1e6, tstage[m].sum() / tot, tloop[m].sum() / 1e6, tloop[m].sum() / tot))
