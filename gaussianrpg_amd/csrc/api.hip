@@ -551,8 +551,15 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // word ~70 us into the frame, with an event behind it.  The host looks at it only after the
     // whole frame is enqueued (speculative mode) -- by then it has long arrived, so grpg_forward
     // returns the exact count without ever idling the stream or itself.
-    launch_publish_counts(stream, pre_counts, (uint32_t)((P + 255) / 256), pub_ptr, &gh->R_pre);
-    HIP_TRY(hipEventRecord(pub_ev, stream));
+    // With the fat depth sort the sum rides in its first pass (one launch fewer; the count arrives
+    // ~35 us later, still long before the host has enqueued the frame); GRPG_PUBLISH_FOLD=0 or the
+    // classic sort: the separate one-workgroup launch right here.
+    static const int publish_fold = [] { const char* e = getenv("GRPG_PUBLISH_FOLD"); return e ? atoi(e) : 1; }();
+    const bool fold_publish = publish_fold && depth_sort_is_fat(GL.nchunks_ds);
+    if (!fold_publish) {
+      launch_publish_counts(stream, pre_counts, (uint32_t)((P + 255) / 256), pub_ptr, &gh->R_pre);
+      HIP_TRY(hipEventRecord(pub_ev, stream));
+    }
     STAGE_CHECK("preprocess");
     tm.mark(1);
     // (depth_bits, id) order: stable sort of ids by the 32-bit depth key.
@@ -564,11 +571,15 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     static const int sort_rect_on = [] { const char* e = getenv("GRPG_SORT_RECT"); return e ? atoi(e) : 1; }();
     const bool rect_sorted_by_sort = hier && sort_rect_on && cam.gx <= 255 && cam.gy <= 255;
     if (fat_sort) {   // drops the culled Gaussians: V pairs remain
+      const uint2* pc = fold_publish ? pre_counts : nullptr;
+      const uint32_t pnb = (uint32_t)((P + 255) / 256);
       if (rect_sorted_by_sort)   // scratch: rect_sorted's own first half and the not yet written offsets
         depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
-                       rects, (uint32_t*)rect_sorted, offsets, rect_sorted, tiles_sorted);
+                       rects, (uint32_t*)rect_sorted, offsets, rect_sorted, tiles_sorted, pc, pnb, pub_ptr,
+                       &gh->R_pre, pub_ev);
       else
-        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V);
+        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, pc, pnb, pub_ptr, &gh->R_pre, pub_ev);
       sorted_gid = val_a;
     } else {          // culled keys sort last (tile count 0); V stays P
       const bool in_b = radix_sort_pairs(stream, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true,

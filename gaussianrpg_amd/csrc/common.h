@@ -338,7 +338,11 @@ void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a,
                     uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
                     const uint2* rects_by_id = nullptr /* hierarchical binning: the rectangles ride along */,
                     uint32_t* aux_a = nullptr, uint32_t* aux_b = nullptr, uint2* rect_sorted = nullptr,
-                    uint32_t* counts_sorted = nullptr);
+                    uint32_t* counts_sorted = nullptr,
+                    // count publish folded into pass 0 (see sort.hip CountPublish); the event is recorded behind it
+                    const uint2* pre_counts = nullptr, uint32_t pre_nblocks = 0,
+                    uint32_t* count_host_word = nullptr, uint32_t* count_header_words = nullptr,
+                    hipEvent_t count_event = nullptr);
 
 // offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total_out (device) = sum, also stored
 // to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.  gather_gid != NULL:

@@ -306,12 +306,23 @@ __device__ __forceinline__ uint2 rect_unpack(const uint32_t p) {
   return make_uint2((p & 0xFFu) | (((p >> 8) & 0xFFu) << 16), ((p >> 16) & 0xFFu) | ((p >> 24) << 16));
 }
 
+// The frame's count publish rides in pass 0 (its last, usually partial, chunk's workgroup): the sum
+// of preprocess' per-workgroup (instances, coarse pairs) goes to the pinned host words and the
+// geometry header; the host's event is recorded behind this launch.  One launch fewer per frame.
+struct CountPublish {
+  const uint2* pre_counts;   // NULL: nothing to publish
+  uint32_t nblocks;
+  uint32_t* host_word;       // pinned, device-mapped: [0] num_rendered, [1] coarse pairs
+  uint32_t* header_words;    // geometry header R_pre, Rc_pre
+};
+
 template <int PASS, bool RECT>
 __global__ void __launch_bounds__(DS_THREADS)
 depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                      const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][256] */,
-                     const uint32_t nchunks, uint32_t* __restrict__ V_out, const RectPayload rp) {
+                     const uint32_t nchunks, uint32_t* __restrict__ V_out, const RectPayload rp,
+                     const CountPublish pub) {
   __shared__ uint32_t s_keys[DS_CHUNK];
   __shared__ uint32_t s_vals[DS_CHUNK];
   __shared__ uint32_t s_aux[RECT ? DS_CHUNK : 1];
@@ -326,6 +337,29 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t chunk = blockIdx.x;
   constexpr int shift = 8 * PASS;
+  if (PASS == 0 && pub.pre_counts != nullptr && chunk == nchunks - 1u) {
+    __shared__ unsigned long long s_pr[DS_WAVES], s_pc[DS_WAVES];
+    unsigned long long r = 0ull, c = 0ull;
+    for (uint32_t i = tid; i < pub.nblocks; i += DS_THREADS) {
+      const uint2 v = pub.pre_counts[i];
+      r += v.x; c += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      r += __shfl_xor(r, o);
+      c += __shfl_xor(c, o);
+    }
+    if (lane == 0) { s_pr[wave] = r; s_pc[wave] = c; }
+    __syncthreads();
+    if (tid == 0) {
+      r = 0ull; c = 0ull;
+      for (int w = 0; w < DS_WAVES; w++) { r += s_pr[w]; c += s_pc[w]; }
+      const uint32_t r32 = r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;   // saturating, like publish_counts_kernel
+      const uint32_t c32 = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+      if (pub.header_words) { pub.header_words[0] = r32; pub.header_words[1] = c32; }
+      if (pub.host_word) { pub.host_word[0] = r32; pub.host_word[1] = c32; __threadfence_system(); }
+    }
+  }
 
   // ---- the chunk's own loads go out first: they overlap the table sweep below.  Pass 0 moves
   // P keys; later passes move the V visible ones (published by chunk 0 of pass 0). ----
@@ -479,21 +513,25 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
                     uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
                     const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint2* rect_sorted,
-                    uint32_t* counts_sorted) {
+                    uint32_t* counts_sorted, const uint2* pre_counts, uint32_t pre_nblocks,
+                    uint32_t* count_host_word, uint32_t* count_header_words, hipEvent_t count_event) {
   if (P == 0) return;
   const size_t tsz = (size_t)nchunks * DS_RADIX;
   const bool rect = rects_by_id != nullptr;
 #define DS_SCATTER(PASS, KI, VI, KO, VO, AI, AO)                                                 \
   do {                                                                                           \
     const RectPayload rp = {rects_by_id, AI, AO, rect_sorted, counts_sorted};                    \
+    const CountPublish pub = {PASS == 0 ? pre_counts : nullptr, pre_nblocks, count_host_word,    \
+                              count_header_words};                                               \
     if (rect)                                                                                    \
       depth_scatter_kernel<PASS, true><<<nchunks, DS_THREADS, 0, s>>>(                           \
-          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp);                         \
+          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp, pub);                    \
     else                                                                                         \
       depth_scatter_kernel<PASS, false><<<nchunks, DS_THREADS, 0, s>>>(                          \
-          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp);                         \
+          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp, pub);                    \
   } while (0)
   DS_SCATTER(0, key_a, nullptr, key_b, val_b, nullptr, aux_b);
+  if (pre_counts != nullptr && count_event != nullptr) (void)hipEventRecord(count_event, s);
   depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 8, ds_table + 1 * tsz);
   DS_SCATTER(1, key_b, val_b, key_a, val_a, aux_b, aux_a);
   depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_a, V_out, 16, ds_table + 2 * tsz);
