@@ -385,7 +385,7 @@ def test_streams_and_threads_give_identical_frames(dev):
                                  {"GRPG_RCAP_TEST": "3000"}, {"GRPG_RCAP_TEST": "3000:3000000"},
                                  {"GRPG_BINNING": "sort"},
                                  {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"},
-                                 {"GRPG_SORT_RECT": "0"}])
+                                 {"GRPG_SORT_RECT": "0"}, {"GRPG_PUBLISH_FOLD": "0"}])
 def test_alternative_code_paths(env):
     """The experiment switches are read once per process, so the parity cases are re-run in a
     subprocess: no producer/consumer pairs; pairs for EVERY heavy tile; light path with one splat
@@ -395,7 +395,8 @@ def test_alternative_code_paths(env):
     binning: first with the coarse list overflowing too, then with only the point list); the sort-based
     binning (emit + stable partition) instead of the hierarchical one, also with overflows; the
     coarse scan gathering the tile rectangles by sorted id instead of receiving them from the depth
-    sort (the path of grids beyond 255 x 255 tiles)."""
+    sort (the path of grids beyond 255 x 255 tiles); num_rendered published by its own launch behind
+    preprocess instead of by the depth sort's first pass."""
     import os
     import subprocess
     import sys
