@@ -127,73 +127,78 @@ def effective_cores():
 
 def _cpu_baseline_worker(threads):
     """Runs in a child process (hard wall-clock limit enforced by the parent).  Prints one JSON line.
-    (i)  pure-PyTorch CPU splat on every 2nd Gaussian of the bench scene at 960x640;
-    (ii) the C restatement on the same sample, scalar build and OpenMP build."""
+    ONE FULL FRAME of the bench workload -- frame 0, all P Gaussians, 1920x1280 -- through
+    (i) the pure-PyTorch CPU splat (oracle/torch_splat.py) and (ii) the C restatement
+    (oracle/gs_oracle.c), scalar build and OpenMP build.  No sub-sampling, no extrapolation."""
     os.environ["OMP_NUM_THREADS"] = str(threads)
     import oracle
     from oracle import torch_splat as ts
     torch.set_num_threads(threads)
     scene = hz.street_scene(P_GAUSS, seed=SCENE_SEED, sh_degree=1)
-    sub = hz.Scene(*(t[::2].contiguous() if isinstance(t, torch.Tensor) else t for t in scene))
-    cam = hz.trajectory_camera(0, W=960, H=640)
+    cam = hz.trajectory_camera(0, W=W, H=H)
     kw = hz.settings_kwargs(cam, scene.sh_degree)
     kw.pop("prefiltered"), kw.pop("debug")
-    out = {"P_sample": int(sub.means3D.shape[0])}
+    out = {"P": int(scene.means3D.shape[0]), "W": W, "H": H}
     with torch.no_grad():
         t0 = time.time()
-        r = ts.rasterize(sub.means3D, sub.opacity, shs=sub.shs, scales=sub.scales,
-                         rotations=sub.rotations, **kw)
+        r = ts.rasterize(scene.means3D, scene.opacity, shs=scene.shs, scales=scene.scales,
+                         rotations=scene.rotations, **kw)
         out["torch_seconds"] = time.time() - t0
-        out["R_sample"] = int(r["num_rendered"])
+        out["R"] = int(r["num_rendered"])
         out["torch_threads"] = torch.get_num_threads()
-    args = dict(shs=sub.shs, scales=sub.scales, rotations=sub.rotations, **kw)
+    print(json.dumps(out), flush=True)      # the headline value survives a time-out of the C legs
+    args = dict(shs=scene.shs, scales=scene.scales, rotations=scene.rotations, **kw)
     t0 = time.time()
-    o1 = oracle.forward(sub.means3D, sub.opacity, **args)
+    o1 = oracle.forward(scene.means3D, scene.opacity, **args)
     out["c_scalar_seconds"] = time.time() - t0
-    assert int(o1["num_rendered"]) == out["R_sample"]
+    assert int(o1["num_rendered"]) == out["R"]
     oracle.use_openmp(True)
     out["c_omp_threads"] = oracle.num_threads()
     t0 = time.time()
-    oracle.forward(sub.means3D, sub.opacity, **args)
+    oracle.forward(scene.means3D, scene.opacity, **args)
     out["c_omp_seconds"] = time.time() - t0
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(R_full, limit_s=300):
-    """cpu_baseline leg (rank 0, N=1): timed on the host cores on a bounded sample of the same
-    workload (frame 0, every 2nd Gaussian, 960x640), scaled to whole frames of the full workload
-    by the ratio of tile instances (the blend's work is proportional to R)."""
+    """cpu_baseline leg (rank 0, N=1): ONE FULL FRAME of the same workload (frame 0, P = 2 M,
+    1920x1280) timed on the host cores -- value = 1 / seconds, nothing scaled (SURVEY.md §8(d)
+    licenses a sub-sample only beyond 10 minutes per frame; a frame takes well under one)."""
     import subprocess
     cores = effective_cores()
     threads = min(cores, 32)
+    stdout = ""
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
                             str(threads)], capture_output=True, text=True, timeout=limit_s)
-        res = json.loads(p.stdout.strip().splitlines()[-1])
+        stdout = p.stdout
+    except subprocess.TimeoutExpired as exc:
+        stdout = exc.stdout.decode() if isinstance(exc.stdout, bytes) else (exc.stdout or "")
     except Exception as exc:
         return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
-                "sample": "cpu baseline did not finish within %d s: %r" % (limit_s, exc)}
-    R_s = max(res["R_sample"], 1)
-    scale = R_s / max(R_full, 1)
-
-    def fps(sec):
-        return (1.0 / sec) * scale
-
-    return {"value": fps(res["torch_seconds"]), "unit": "frames/s", "cores": res["torch_threads"],
-            "kind": "port", "host_cpu_count": os.cpu_count(), "usable_cores": cores,
-            "sample": "frame 0, every 2nd Gaussian (P=%d) at 960x640, R=%d tile instances; each value = "
-                      "1/t scaled by R_sample/R_full (R_full=%d) to whole 1920x1280 frames.  value = "
-                      "oracle/torch_splat.py (pure-PyTorch CPU splat) on %d threads: %.2f s" % (
-                          res["P_sample"], R_s, R_full, res["torch_threads"], res["torch_seconds"]),
-            "sample_seconds": res["torch_seconds"],
-            "c_restatement": {
-                "what": "oracle/gs_oracle.c (scalar C restatement of the reference kernels), same sample",
-                "scalar": {"value": fps(res["c_scalar_seconds"]), "cores": 1,
-                           "sample_seconds": res["c_scalar_seconds"]},
-                "openmp": {"value": fps(res["c_omp_seconds"]), "cores": res["c_omp_threads"],
-                           "sample_seconds": res["c_omp_seconds"],
-                           "note": "OpenMP over Gaussians (preprocess) and pixel rows (blend); "
-                                   "binning stays serial"}}}
+                "sample": "cpu baseline failed: %r" % (exc,)}
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": "cpu baseline did not finish one frame within %d s" % limit_s}
+    res = json.loads(lines[-1])
+    out = {"value": 1.0 / res["torch_seconds"], "unit": "frames/s", "cores": res["torch_threads"],
+           "kind": "port", "host_cpu_count": os.cpu_count(), "usable_cores": cores,
+           "sample": "full frame: frame 0 of the bench workload, all P=%d Gaussians at %dx%d, R=%d tile "
+                     "instances (the GPU's timed frames: R_avg=%d); value = 1 / wall time of oracle/torch_splat.py "
+                     "(pure-PyTorch CPU splat) on %d threads: %.2f s.  No sub-sampling, no scaling" % (
+                         res["P"], res["W"], res["H"], res["R"], R_full, res["torch_threads"],
+                         res["torch_seconds"]),
+           "sample_seconds": res["torch_seconds"]}
+    if "c_omp_seconds" in res:
+        out["c_restatement"] = {
+            "what": "oracle/gs_oracle.c (scalar C restatement of the reference kernels), the same full frame",
+            "scalar": {"value": 1.0 / res["c_scalar_seconds"], "cores": 1,
+                       "sample_seconds": res["c_scalar_seconds"]},
+            "openmp": {"value": 1.0 / res["c_omp_seconds"], "cores": res["c_omp_threads"],
+                       "sample_seconds": res["c_omp_seconds"],
+                       "note": "OpenMP over Gaussians (preprocess) and pixel rows (blend); binning stays serial"}}
+    return out
 
 
 def train_leg(dev, steps=12, warmup=4, P=1_000_000):

@@ -118,9 +118,53 @@ def build_binding(force=False, verbose=False):
     return EXT_PATH
 
 
+# Test variants of the C-ABI library: the same sources with one translation unit recompiled under an
+# extra -D.  They live under build/variants/ (git-ignored like every built file, shipped to the GPU
+# box by gpurun), are loaded through ctypes by the one test that needs them and are never imported
+# by the package.
+VARIANTS = {
+    # every producer / consumer hand-over of the render gives up at once: the timeout -> error path
+    # (render_fwd.hip pc_fail, tests/test_gpu_pc_timeout.py)
+    "pcspin0": {"render_fwd.hip": ["-DGRPG_PC_SPIN_LIMIT=0"]},
+}
+
+
+def variant_path(name):
+    return os.path.join(ROOT, "build", "variants", "libgrpg_rasterizer_%s.so" % name)
+
+
+def build_variant(name, force=False):
+    """build/variants/libgrpg_rasterizer_<name>.so from the objects of build_native(), except the
+    units VARIANTS[name] lists, which are recompiled with the extra flags."""
+    build_native()
+    hipcc = _hipcc()
+    out = variant_path(name)
+    vobj = os.path.join(ROOT, "build", "obj_" + name)
+    os.makedirs(vobj, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for unit, extra in HIP_UNITS.items():
+        if unit not in VARIANTS[name]:
+            objs.append(os.path.join(OBJ, unit.replace(".hip", ".o")))
+            continue
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(vobj, unit.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
+            _run([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                  "-Wall", "-Wno-unused-function"] + extra + VARIANTS[name][unit] + ["-c", src, "-o", obj])
+    if force or _newer(out, objs):
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs +
+             ["-Wl,--enable-new-dtags", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 def build_all(force=False, verbose=False):
     build_native(force=force, verbose=verbose)
     build_binding(force=force, verbose=verbose)
+    for name in VARIANTS:
+        build_variant(name, force=force)
     return LIB_PATH, EXT_PATH
 
 

@@ -65,10 +65,6 @@ class ActorPose(NamedTuple):
     fourier_time: float = 0.0
 
 
-def _floats(v):
-    return [float(x) for x in (v.detach().cpu().tolist() if isinstance(v, torch.Tensor) else v)]
-
-
 def idft_weights(time: float, dim: int) -> List[float]:
     """IDFT(time, dim) of lib/utils/sh_utils.py:120-130: even k -> cos(pi t k), odd k -> sin(pi t (k+1)),
     evaluated in float32 like the reference (pinned by tests/golden/ref_idft.npz)."""
@@ -101,7 +97,8 @@ def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
     if len(models) != len(poses):
         raise ValueError("one pose entry (None for a static model) per model")
     rows, times, dims = [], [], []
-    for m, p in zip(models, poses):
+    tens, slots = [], []   # tensor-valued pose parts and where they go: ONE host copy for all of them
+    for i, (m, p) in enumerate(zip(models, poses)):
         F = int(m.features_dc.shape[1])
         if F > MAX_FOURIER:
             raise ValueError("fourier_dim %d > %d" % (F, MAX_FOURIER))
@@ -109,9 +106,29 @@ def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
         if p is None:      # a static model has fourier_dim 1: weight cos(0) = 1
             rows.append([0.0] * 8)
             times.append(0.0)
+            continue
+        row = [1.0] + [0.0] * 7
+        for off, v, n in ((1, p.obj_rot, 4), (5, p.obj_trans, 3)):
+            if isinstance(v, torch.Tensor):
+                if v.numel() != n:
+                    raise ValueError("pose component of %d elements, expected %d" % (v.numel(), n))
+                tens.append(v.detach().reshape(-1).float())
+                slots.append((i, off, n))
+            else:
+                row[off:off + n] = [float(x) for x in v]
+        rows.append(row)
+        times.append(float(p.fourier_time))
+    if tens:
+        # tracked poses usually live on the GPU: a .cpu() per actor would be a device sync per actor and
+        # frame; stack them first (one small kernel) and copy once
+        if len({t.device for t in tens}) == 1:
+            flat_vals = torch.cat(tens).cpu().tolist()
         else:
-            rows.append([1.0] + _floats(p.obj_rot) + _floats(p.obj_trans))
-            times.append(float(p.fourier_time))
+            flat_vals = torch.cat([t.cpu() for t in tens]).tolist()
+        k = 0
+        for i, off, n in slots:
+            rows[i][off:off + n] = flat_vals[k:k + n]
+            k += n
     pose_t = torch.tensor(rows, dtype=torch.float32).reshape(len(models), 8)
     idft_t = _idft_rows(times, dims)
     lists = [[getattr(m, f) for m in models] for f in ModelParams._fields[:6]]
@@ -133,12 +150,13 @@ class _ComposedRasterize(torch.autograd.Function):
     _C.rasterize_gaussians_composed_backward (C ABI grpg_backward_composed)."""
 
     @staticmethod
-    def forward(ctx, rs, nm, pose_t, idft_t, flips, pose_rot, pose_trans, means2D, *flat):
+    def forward(ctx, owner, rs, nm, pose_t, idft_t, flips, pose_rot, pose_trans, means2D, *flat):
         lists = [list(flat[f * nm:(f + 1) * nm]) for f in range(6)]
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians_composed(
             rs.bg, *lists, flips, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
             rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug, True)
         ctx.rs, ctx.nm, ctx.num_rendered = rs, nm, num_rendered
+        owner.num_rendered = num_rendered   # like the evaluation branch of ComposedRasterizer.forward
         ctx.pose_t, ctx.idft_t, ctx.flips = pose_t, idft_t, flips
         ctx.pose_dev = (None if pose_rot is None else pose_rot.device,
                         None if pose_trans is None else pose_trans.device)
@@ -160,11 +178,11 @@ class _ComposedRasterize(torch.autograd.Function):
             g_depth if g_depth is not None else zeros(alpha),
             g_alpha if g_alpha is not None else zeros(alpha), rs.debug)
         need = ctx.needs_input_grad
-        g_rot = g_poses[:, 0:4].to(ctx.pose_dev[0]) if need[5] else None
-        g_trans = g_poses[:, 4:7].to(ctx.pose_dev[1]) if need[6] else None
+        g_rot = g_poses[:, 0:4].to(ctx.pose_dev[0]) if need[6] else None
+        g_trans = g_poses[:, 4:7].to(ctx.pose_dev[1]) if need[7] else None
         grads = [g for per_field in (gx, gs, gr, go, gdc, gfr) for g in per_field]
-        flat_grads = tuple(g if n else None for g, n in zip(grads, need[8:]))
-        return (None, None, None, None, None, g_rot, g_trans, g_means2D if need[7] else None) + flat_grads
+        flat_grads = tuple(g if n else None for g, n in zip(grads, need[9:]))
+        return (None, None, None, None, None, None, g_rot, g_trans, g_means2D if need[8] else None) + flat_grads
 
 
 class ComposedRasterizer(nn.Module):
@@ -202,4 +220,5 @@ class ComposedRasterizer(nn.Module):
                 torch.tensor([float(x) for x in v], device=dev)   # noqa: E731
             pose_rot = torch.stack([one.to(dev) if p is None else as_t(p.obj_rot, dev) for p in poses])
             pose_trans = torch.stack([zero3.to(dev) if p is None else as_t(p.obj_trans, dev) for p in poses])
-        return _ComposedRasterize.apply(rs, len(models), pose_t, idft_t, flips, pose_rot, pose_trans, means2D, *flat)
+        return _ComposedRasterize.apply(self, rs, len(models), pose_t, idft_t, flips, pose_rot, pose_trans,
+                                        means2D, *flat)

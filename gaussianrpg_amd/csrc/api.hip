@@ -37,7 +37,7 @@ thread_local int g_timing_enabled = 0;   // 0 off, 1 all stages, 2 render stage 
 // ---- num_rendered hand-over: pinned, device-mapped host words + one event per (thread, device) ----
 struct HostWord {
   int dev = -1;
-  uint32_t* host_ptr = nullptr;   // [0] num_rendered, [1] Gaussians in the sorted arrays
+  uint32_t* host_ptr = nullptr;   // [0] num_rendered, [1] coarse pairs, [3] sticky asynchronous error
   uint32_t* dev_ptr = nullptr;    // the same memory as the device addresses it
   hipEvent_t ev = nullptr;
 };
@@ -53,7 +53,7 @@ HostWord* host_word() {
   if (hipHostMalloc((void**)&h.host_ptr, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
   if (hipHostGetDevicePointer((void**)&h.dev_ptr, h.host_ptr, 0) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-  h.host_ptr[0] = 0u; h.host_ptr[1] = 0u;
+  h.host_ptr[0] = 0u; h.host_ptr[1] = 0u; h.host_ptr[2] = 0u; h.host_ptr[3] = 0u;
   g_host_words.push_back(h);
   return &g_host_words.back();
 }
@@ -162,11 +162,8 @@ void update_hint(const CapKey& k, uint32_t R, uint32_t Rc) {
 }
 
 // The fat depth sort (sort.hip) sweeps the whole count table in every workgroup: fine up to a few
-// hundred chunks, quadratic beyond.  GRPG_DEPTH_SORT=classic forces the three-kernel passes.
-bool depth_sort_is_fat(uint32_t nchunks_ds) {
-  static const bool classic = [] { const char* e = getenv("GRPG_DEPTH_SORT"); return e && e[0] == 'c'; }();
-  return !classic && nchunks_ds <= DS_MAX_CHUNKS;
-}
+// hundred chunks, quadratic beyond (P > 4 M: the classic three-kernel passes).
+bool depth_sort_is_fat(uint32_t nchunks_ds) { return nchunks_ds <= DS_MAX_CHUNKS; }
 
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -188,6 +185,19 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                    \
       return fail(GRPG_ERR_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+// Asynchronous device-side failures (today: a producer / consumer hand-over of the render that timed
+// out, render_fwd.hip pc_fail) raise a sticky word in pinned host memory.  Like an asynchronous HIP
+// error it is reported by the NEXT entry point the thread calls (all forwards, the backwards,
+// grpg_frame_status), once; with debug = true the forward that suffered it fails itself.
+int check_async_error(HostWord* hw) {
+  if (hw && hw->host_ptr[3] != 0u) {
+    hw->host_ptr[3] = 0u;
+    return fail(GRPG_ERR_HIP, "render: a producer/consumer hand-over timed out in an earlier frame "
+                              "of this thread (image blob header pc_timeout): that frame's image is invalid");
+  }
+  return GRPG_OK;
+}
 
 int ensure_device() {
   int n = 0;
@@ -279,10 +289,52 @@ BwdTimingRecord* bwd_timing_begin(hipStream_t s) {
   (void)hipEventRecord(r->ev[0], s);
   return r;
 }
+constexpr size_t BWD_PENDING_CAP = 256;   // a caller that never collects them keeps the newest 256
 void bwd_timing_mark(BwdTimingRecord* r, int i, hipStream_t s) {
   if (!r) return;
   (void)hipEventRecord(r->ev[i], s);
-  if (i == 2) { std::lock_guard<std::mutex> lk(g_bwd_mu); g_bwd_pending.push_back(r); }
+  if (i == 2) {
+    std::lock_guard<std::mutex> lk(g_bwd_mu);
+    if (g_bwd_pending.size() >= BWD_PENDING_CAP) {   // recycle the oldest record (its events are reused)
+      g_bwd_free.push_back(g_bwd_pending.front());
+      g_bwd_pending.erase(g_bwd_pending.begin());
+    }
+    g_bwd_pending.push_back(r);
+  }
+}
+// a backward that fails between begin and the last mark hands its record back
+struct BwdTimingGuard {
+  BwdTimingRecord* r;
+  bool done = false;
+  explicit BwdTimingGuard(BwdTimingRecord* r_) : r(r_) {}
+  ~BwdTimingGuard() {
+    if (r && !done) { std::lock_guard<std::mutex> lk(g_bwd_mu); g_bwd_free.push_back(r); }
+  }
+};
+
+// ---- which geometry blobs were carved WITH the backward's gradient records (a training forward)?
+// grpg_backward writes P x 64 bytes behind the rest of the blob; a blob carved by an evaluation
+// forward (GRPG_FORWARD_NO_BACKWARD) has no such region.  The last forwards' blob addresses are
+// remembered so that the mistake is an error return, not an out-of-bounds device write. ----
+struct GeomSeen { const void* ptr = nullptr; int P = 0; bool has_grad = false; uint64_t stamp = 0; };
+std::mutex g_geom_mu;
+GeomSeen g_geom_seen[64];
+uint64_t g_geom_clock = 0;
+void remember_geom(const void* ptr, int P, bool has_grad) {
+  std::lock_guard<std::mutex> lk(g_geom_mu);
+  GeomSeen* slot = &g_geom_seen[0];
+  for (auto& g : g_geom_seen) {
+    if (g.ptr == ptr) { slot = &g; break; }
+    if (g.stamp < slot->stamp) slot = &g;
+  }
+  slot->ptr = ptr; slot->P = P; slot->has_grad = has_grad; slot->stamp = ++g_geom_clock;
+}
+// false only when the blob is KNOWN to lack the gradient records
+bool geom_may_take_backward(const void* ptr, int P) {
+  std::lock_guard<std::mutex> lk(g_geom_mu);
+  for (auto& g : g_geom_seen)
+    if (g.ptr == ptr && g.P == P) return g.has_grad;
+  return true;
 }
 
 CameraArgs make_camera(const float* view, const float* proj, const float* campos, int W, int H,
@@ -451,6 +503,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   char* geom = geometry_alloc(GL.total, geometry_user);
   char* img = image_alloc(IL.total, image_user);
   if (!geom || !img) return fail(GRPG_ERR_ALLOC, "geometry/image buffer allocation failed");
+  remember_geom(geom, P, (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
 
   float4* rec_w = (float4*)(geom + GL.rec);
   const RecView rec = {rec_w};
@@ -478,6 +531,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipGetDevice(&dev));
     HostWord* hw = host_word();
     if (!hw) return fail(GRPG_ERR_HIP, "pinned host word / event allocation failed");
+    if (int rc = check_async_error(hw)) return rc;
     // where the speculative frame publishes its count: the thread's word, or the deferred frame's own
     uint32_t* const pub_ptr = defer ? defer->dev_ptr : hw->dev_ptr;
     hipEvent_t const pub_ev = defer ? defer->ev : hw->ev;
@@ -515,10 +569,11 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     tm.mark(0);
     launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
                       (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
-                      geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
+                      geom + GL.zero_begin, GL.zero_end - GL.zero_begin,
+                      (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
     uint2* rects = hier ? (uint2*)(geom + GL.rects) : nullptr;
     uint2* rect_sorted = (uint2*)(geom + GL.rect_sorted);
-    uint2* pre_counts = (uint2*)(geom + GL.pre_counts);
+    uint4* pre_counts = (uint4*)(geom + GL.pre_counts);
     if (segs == nullptr) {
       launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                         cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles, rects,
@@ -552,10 +607,9 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // whole frame is enqueued (speculative mode) -- by then it has long arrived, so grpg_forward
     // returns the exact count without ever idling the stream or itself.
     // With the fat depth sort the sum rides in its first pass (one launch fewer; the count arrives
-    // ~35 us later, still long before the host has enqueued the frame); GRPG_PUBLISH_FOLD=0 or the
-    // classic sort: the separate one-workgroup launch right here.
-    static const int publish_fold = [] { const char* e = getenv("GRPG_PUBLISH_FOLD"); return e ? atoi(e) : 1; }();
-    const bool fold_publish = publish_fold && depth_sort_is_fat(GL.nchunks_ds);
+    // ~35 us later, still long before the host has enqueued the frame); the classic sort of very
+    // large P: the separate one-workgroup launch right here.
+    const bool fold_publish = fat_sort;
     if (!fold_publish) {
       launch_publish_counts(stream, pre_counts, (uint32_t)((P + 255) / 256), pub_ptr, &gh->R_pre);
       HIP_TRY(hipEventRecord(pub_ev, stream));
@@ -567,19 +621,21 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     const uint32_t* sorted_gid;
     // hierarchical binning on a grid of <= 255 x 255 tiles: the tile rectangles ride through the
     // depth sort as a packed payload and arrive in depth order together with the super-tile counts
-    // (sort.hip RectPayload); GRPG_SORT_RECT=0: the coarse scan gathers them by sorted id instead
-    static const int sort_rect_on = [] { const char* e = getenv("GRPG_SORT_RECT"); return e ? atoi(e) : 1; }();
-    const bool rect_sorted_by_sort = hier && sort_rect_on && cam.gx <= 255 && cam.gy <= 255;
+    // (sort.hip RectPayload); larger grids: the coarse scan gathers them by sorted id instead
+    const bool rect_sorted_by_sort = hier && cam.gx <= 255 && cam.gy <= 255;
     if (fat_sort) {   // drops the culled Gaussians: V pairs remain
-      const uint2* pc = fold_publish ? pre_counts : nullptr;
       const uint32_t pnb = (uint32_t)((P + 255) / 256);
-      if (rect_sorted_by_sort)   // scratch: rect_sorted's own first half and the not yet written offsets
-        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
-                       rects, (uint32_t*)rect_sorted, offsets, rect_sorted, tiles_sorted, pc, pnb, pub_ptr,
-                       &gh->R_pre, pub_ev);
+      uint32_t* key_c = (uint32_t*)(geom + GL.key_c);
+      uint32_t* val_c = (uint32_t*)(geom + GL.val_c);
+      if (rect_sorted_by_sort)   // scratch: rect_sorted's own first half, the not yet written offsets, aux_c
+        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, key_c, val_c, ds_table,
+                       GL.nchunks_ds, &gh->V, &gh->key_base, rects, (uint32_t*)rect_sorted, offsets,
+                       (uint32_t*)(geom + GL.aux_c), rect_sorted, tiles_sorted, pre_counts, pnb, true,
+                       pub_ptr, &gh->R_pre, pub_ev);
       else
-        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, ds_table, GL.nchunks_ds, &gh->V,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, pc, pnb, pub_ptr, &gh->R_pre, pub_ev);
+        depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, key_c, val_c, ds_table,
+                       GL.nchunks_ds, &gh->V, &gh->key_base, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, pre_counts, pnb, true, pub_ptr, &gh->R_pre, pub_ev);
       sorted_gid = val_a;
     } else {          // culled keys sort last (tile count 0); V stays P
       const bool in_b = radix_sort_pairs(stream, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true,
@@ -609,8 +665,11 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
                             (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified,
-                            with_ckpt ? &ck : nullptr);
+                            with_ckpt ? &ck : nullptr,
+                            PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3});
       STAGE_CHECK("render");
+      if (debug)   // the stage check has synchronised: a hand-over timeout of THIS frame is known
+        if (int rc = check_async_error(hw)) return rc;
       tm.mark(7);
       if (S > 0) {
         launch_render_semantic(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
@@ -780,7 +839,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     char* bin = binning_alloc(bin_layout(0).total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
     launch_frame_init(stream, geom, bin, img, 0u, 0u, 0u, (uint32_t)width, (uint32_t)height,
-                      (uint32_t)S, ranges, T, work, geom + GL.zero_begin, GL.zero_end - GL.zero_begin);
+                      (uint32_t)S, ranges, T, work, geom + GL.zero_begin, GL.zero_end - GL.zero_begin,
+                      (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
   }
   if (defer && defer->state == 0) { defer->state = 2; defer->result = (int)R; }
   return (int)R;
@@ -925,6 +985,8 @@ int grpg_frame_status(int ticket, int wait, int* num_rendered) {
     return fail(GRPG_ERR_INVALID_ARGUMENT,
                 "no such ticket on this thread: tickets are valid only on the thread that enqueued the "
                 "frame, and only until GRPG_MAX_DEFERRED_FRAMES (64) later frames have been enqueued there");
+  for (auto& hw : g_host_words)
+    if (int rc = check_async_error(&hw)) return rc;
   const int r = defer_resolve(slot, wait != 0);
   if (r >= 0) { if (num_rendered) *num_rendered = r; return GRPG_OK; }
   if (r == GRPG_ERR_CAPACITY)
@@ -985,6 +1047,11 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
     return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M <= 16");
   if (!grads || !geom_buffer || !binning_buffer || !image_buffer)
     return fail(GRPG_ERR_BAD_BUFFER, "NULL gradient table / state buffer");
+  if (!geom_may_take_backward(geom_buffer, P))
+    return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer was carved by an evaluation forward "
+                                     "(GRPG_FORWARD_NO_BACKWARD): it has no room for the backward's gradient records");
+  for (auto& hw : g_host_words)
+    if (int rc = check_async_error(&hw)) return rc;
   if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dposes || !radii ||
       !background || !viewmatrix || !projmatrix || !campos)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL pointer");
@@ -1031,6 +1098,7 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
   float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
   HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
   BwdTimingRecord* const btr = bwd_timing_begin(stream);
+  BwdTimingGuard btg(btr);
   launch_render_backward(stream, ranges, point_list, rec, nullptr, 0, width, height, cam.gx, cam.gy,
                          background, alphas, n_contrib, (const uint32_t*)(image_buffer + IL.work), dL_dpix,
                          dL_dpix_depth, dL_dalphas, nullptr, grad_rec, nullptr,
@@ -1042,6 +1110,7 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
                                       scale_modifier, cam, grad_rec, dL_dmean2D,
                                       (float*)(geom_buffer + GL.pose_acc), dL_dposes);
   bwd_timing_mark(btr, 2, stream);
+  btg.done = true;
   STAGE_CHECK("preprocess backward (composed)");
   return GRPG_OK;
 }
@@ -1104,12 +1173,24 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   if (P <= 0) return GRPG_OK;
   if (!geom_buffer || !binning_buffer || !image_buffer)
     return fail(GRPG_ERR_BAD_BUFFER, "NULL state buffer");
+  if (!geom_may_take_backward(geom_buffer, P))
+    return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer was carved by an evaluation forward "
+                                     "(GRPG_FORWARD_NO_BACKWARD): it has no room for the backward's gradient records");
+  for (auto& hw : g_host_words)
+    if (int rc = check_async_error(&hw)) return rc;
   // dL_dconic / dL_ddepth (pure intermediates of the reference's binding) and dL_dcolor / dL_dcov3D
   // (gradients of the OPTIONAL inputs colors_precomp / cov3D_precomp) may be NULL: not written then
   if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dopacity || !dL_dmean3D)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
   if ((colors_precomp && !dL_dcolor) || (cov3D_precomp && !dL_dcov3D))
     return fail(GRPG_ERR_INVALID_ARGUMENT, "colors_precomp / cov3D_precomp given without their gradient array");
+  // every gradient array is WRITTEN, not accumulated: the inputs in use need theirs
+  if (!colors_precomp && (!shs || !dL_dsh))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "shs (no colors_precomp) needs shs and dL_dsh");
+  if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "scales / rotations (no cov3D_precomp) need dL_dscale and dL_drot");
+  if (!means3D || !background || !viewmatrix || !projmatrix || !campos)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL means3D / camera / background pointer");
   if (S > 0 && (!semantics || !dL_dpix_semantic || !dL_dsemantic))
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL semantic pointer with S>0");
   if (S > GRPG_MAX_SEMANTIC_BACKWARD)   // the blend backward carries the channels in registers
@@ -1130,6 +1211,10 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
         h[0].P != (uint32_t)P || h[0].R != (uint32_t)R || h[1].Rcap < (uint32_t)R ||
         h[2].W != (uint32_t)width || h[2].H != (uint32_t)height)
       return fail(GRPG_ERR_BAD_BUFFER, "state buffers do not match this call (P/R/W/H or magic)");
+    if (h[0].has_grad_rec == 0u)
+      return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer was carved by an evaluation forward (no gradient records)");
+    if (h[2].pc_timeout != 0u)
+      return fail(GRPG_ERR_HIP, "the forward of this frame reported a producer/consumer timeout: its image is invalid");
   }
   const RecView rec = {(const float4*)(geom_buffer + GL.rec)};
   const int* radii_int = radii ? radii : (const int*)(geom_buffer + GL.radii);
@@ -1143,6 +1228,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   float* grad_rec = (float*)(geom_buffer + GL.grad_rec);
   HIP_TRY(hipMemsetAsync(grad_rec, 0, (size_t)P * GRAD_STRIDE * sizeof(float), stream));
   BwdTimingRecord* const btr = bwd_timing_begin(stream);
+  BwdTimingGuard btg(btr);
   launch_render_backward(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
                          cam.gy, background, alphas, n_contrib,
                          (const uint32_t*)(image_buffer + IL.work), dL_dpix, dL_dpix_depth, dL_dalphas,
@@ -1157,6 +1243,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
                              dL_dmean3D, dL_dcolor, dL_ddepth, dL_dcov3D,
                              colors_precomp ? nullptr : dL_dsh, dL_dscale, dL_drot);
   bwd_timing_mark(btr, 2, stream);
+  btg.done = true;
   STAGE_CHECK("preprocess backward");
   return GRPG_OK;
 }

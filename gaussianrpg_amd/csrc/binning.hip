@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256)
 frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint32_t P,
                   const uint32_t V_init, const uint32_t Rcap, const uint32_t W, const uint32_t H,
                   const uint32_t S, uint2* __restrict__ ranges, const uint32_t T,
-                  uint32_t* __restrict__ work, uint4* __restrict__ zero16, const size_t nzero16) {
+                  uint32_t* __restrict__ work, uint4* __restrict__ zero16, const size_t nzero16,
+                  const uint32_t geom_has_grad) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = t; i < nzero16; i += stride) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -351,13 +352,15 @@ frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint
       h->magic = t == 0 ? GEOM_MAGIC : (t == 1 ? BIN_MAGIC : IMG_MAGIC);
       h->P = P; h->R = 0u; h->W = W; h->H = H; h->S = S; h->V = V_init; h->Rcap = Rcap;
       h->Rc = 0u; h->hier = 0u; h->ckpt_off256 = 0u; h->ckpt_slots = 0u;
+      h->key_base = 0u; h->key_far = 0u; h->pc_timeout = 0u;
+      h->has_grad_rec = t == 0 ? geom_has_grad : 0u;
     }
   }
 }
 
 void launch_frame_init(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t V_init,
                        uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S, uint2* ranges, uint32_t T,
-                       uint32_t* work, char* zero_begin, size_t zero_bytes) {
+                       uint32_t* work, char* zero_begin, size_t zero_bytes, bool geom_has_grad) {
   const size_t nzero16 = zero_bytes / 16;   // the region is 256-byte aligned at both ends
   size_t items = nzero16 > (size_t)T ? nzero16 : (size_t)T;
   uint32_t blocks = (uint32_t)((items + 255) / 256);
@@ -365,7 +368,7 @@ void launch_frame_init(hipStream_t s, char* geom, char* bin, char* img, uint32_t
   if (blocks > 2048) blocks = 2048;
   frame_init_kernel<<<blocks, 256, 0, s>>>((BlobHeader*)geom, (BlobHeader*)bin, (BlobHeader*)img, P,
                                             V_init, Rcap, W, H, S, ranges, T, work,
-                                            (uint4*)zero_begin, nzero16);
+                                            (uint4*)zero_begin, nzero16, geom_has_grad ? 1u : 0u);
 }
 
 // Binning-blob header alone (the blob was sized after num_rendered became known), or a re-run of

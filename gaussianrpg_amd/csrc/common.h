@@ -73,9 +73,13 @@ struct BlobHeader {      // first 256 bytes of every blob
   uint32_t hier;         // binning blob: 1 = the point list came from the hierarchical path (no
                          // sorted tile keys; tile_start[] instead)
   uint32_t R_pre, Rc_pre;   // geometry blob: the counts as summed right behind preprocess
+  uint32_t key_base;        // geometry blob: smallest visible depth key, rounded down to 2^18 (sort.hip)
+  uint32_t key_far;         //   != 0: some visible key - key_base needs more than 27 bits (fourth sort pass)
   uint32_t ckpt_off256;     // binning blob: offset / 256 of the forward's blend checkpoints (CK_* below),
   uint32_t ckpt_slots;      //   0 = none were written (evaluation forward); slots carved
-  uint32_t reserved[50];
+  uint32_t pc_timeout;      // image blob: a producer / consumer hand-over of the render gave up (render_fwd.hip)
+  uint32_t has_grad_rec;    // geometry blob: carved with the backward's gradient records (training forward)
+  uint32_t reserved[46];
 };
 static_assert(sizeof(BlobHeader) == 256, "header is 256 bytes");
 
@@ -130,14 +134,12 @@ static_assert(EMIT_PER_BLOCK == RS_CHUNK, "emit block must equal one radix chunk
 // "fat" depth sort (sort.hip): 1024-thread workgroups own 8192 keys; every workgroup derives its
 // digit bases straight from the [chunk][digit] count table, so a pass is ONE launch (+ one small
 // histogram launch for the next pass) instead of histogram / digit scan / scatter.
-#ifndef GRPG_DS_THREADS
-#define GRPG_DS_THREADS 1024
-#endif
-constexpr int DS_THREADS = GRPG_DS_THREADS;
+constexpr int DS_THREADS = 1024;
 constexpr int DS_ITEMS = 8192 / DS_THREADS;
 constexpr int DS_CHUNK = DS_THREADS * DS_ITEMS;   // 8192 keys per workgroup
 constexpr int DS_WAVES = DS_THREADS / WAVE;       // 16
-constexpr int DS_RADIX = 256;
+constexpr int DS_BITS = 9;                        // three 9-bit passes over key - key_base (+ a fourth
+constexpr int DS_RADIX = 1 << DS_BITS;            // over the last 5 bits when the depth range needs it)
 constexpr int DS_PASSES = 4;
 constexpr uint32_t DS_MAX_CHUNKS = 512;           // beyond (P > 4 M) the table sweep per workgroup grows
                                                   // quadratically: classic three-kernel passes instead
@@ -166,13 +168,14 @@ static_assert(sizeof(SegmentDev) % 16 == 0, "segment table entries are read as 1
 struct GeomLayout {
   size_t total;
   size_t rec, key_a, key_b, val_a, val_b, tiles, rects, rect_sorted, tiles_sorted, offsets, radii, table, totals, block_sums, emit_win;
+  size_t key_c, val_c, aux_c;   // third (key, id, payload) set of the fat depth sort
   size_t ds_table;       // [DS_PASSES][nchunks_ds][DS_RADIX] u32 (fat depth sort)
   size_t seg_table;      // SegmentDev[MAX_SEGMENTS] (composed forward only)
-  size_t pre_counts;     // uint2[ceil(P/256)]: per-workgroup (instances, coarse pairs) of preprocess
+  size_t pre_counts;     // uint4[ceil(P/256)]: per-workgroup (instances, coarse pairs, min key, max key) of preprocess
   size_t grad_rec;       // float[P][16]: per-Gaussian gradient accumulators of the backward (train forwards only)
   size_t seg_grad_table; // composed training backward: six output pointers per segment
   size_t pose_acc;       // ... and the per-actor sums [MAX_SEGMENTS][16]
-  size_t zero_begin, zero_end;   // region frame_init clears: ds_table
+  size_t zero_begin, zero_end;   // region frame_init clears: pass 0's rows of ds_table
   uint32_t nchunks_sort, nblocks_scan, emit_win_cap, nchunks_ds;
 };
 struct BinLayout {
@@ -214,15 +217,20 @@ inline GeomLayout geom_layout(size_t P, bool with_grad = true) {
   L.totals = take(4 * RS_MAX_RADIX * 4);
   L.nchunks_ds = (uint32_t)((P + DS_CHUNK - 1) / DS_CHUNK);
   L.block_sums = take(((size_t)L.nblocks_scan + 1) * 4);
+  // pass 0's table is accumulated by preprocess with atomics (cleared by frame_init); the later
+  // passes' tables are written row by row for the chunks that hold data, and swept for those only
   L.zero_begin = o;
   L.ds_table = take((size_t)DS_PASSES * (L.nchunks_ds ? L.nchunks_ds : 1) * DS_RADIX * 4);
-  L.zero_end = o;
+  L.zero_end = L.ds_table + align_up((size_t)(L.nchunks_ds ? L.nchunks_ds : 1) * DS_RADIX * 4, 256);
+  L.key_c = take(P * 4);
+  L.val_c = take(P * 4);
+  L.aux_c = take(P * 4);
   // owner (depth-sorted Gaussian index) of the first slot of every 2048-slot emit block, written by
   // the offsets scan; blocks beyond the cap (R > 256 P, pathological) fall back to a binary search
   L.emit_win_cap = (uint32_t)(P / 8 + 1024);
   L.emit_win = take(((size_t)L.emit_win_cap + 2) * 4);
   L.seg_table = take((size_t)MAX_SEGMENTS * sizeof(SegmentDev));
-  L.pre_counts = take(((P + 255) / 256 + 1) * 8);
+  L.pre_counts = take(((P + 255) / 256 + 1) * 16);
   L.grad_rec = o;
   if (with_grad) (void)take(P * GRAD_STRIDE * 4);
   L.seg_grad_table = o;
@@ -302,15 +310,16 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles,
                        uint2* rects /* packed tile rectangles (hierarchical binning), or NULL */,
                        uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */,
-                       uint2* pre_counts /* [ceil(P/256)] per-workgroup (instances, coarse pairs), or NULL */);
-// sums pre_counts -> pinned host words [0] num_rendered, [1] coarse pairs (+ two header words)
-void launch_publish_counts(hipStream_t s, const uint2* pre_counts, uint32_t nblocks,
+                       uint4* pre_counts /* [ceil(P/256)] per-workgroup (instances, coarse pairs, min key, max key), or NULL */);
+// sums pre_counts -> pinned host words [0] num_rendered, [1] coarse pairs; header words R_pre,
+// Rc_pre, key_base, key_far (sort.hip)
+void launch_publish_counts(hipStream_t s, const uint4* pre_counts, uint32_t nblocks,
                            uint32_t* host_word, uint32_t* header_words);
 // Composed variants (preprocess.hip): raw per-model parameters + actor poses instead of flat tensors.
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
                                 uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                                uint32_t* ds_table0, uint2* pre_counts);
+                                uint32_t* ds_table0, uint4* pre_counts);
 void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
                     float* scales, float* rotations, float* opacities, float* shs);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
@@ -335,14 +344,15 @@ int radix_sort_first_pass_bits(int begin_bit, int end_bit);
 
 // Fat depth sort (sort.hip): result in (key_a, val_a), V visible pairs; see depth_sort_fat.
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
-                    const uint2* rects_by_id = nullptr /* hierarchical binning: the rectangles ride along */,
-                    uint32_t* aux_a = nullptr, uint32_t* aux_b = nullptr, uint2* rect_sorted = nullptr,
-                    uint32_t* counts_sorted = nullptr,
-                    // count publish folded into pass 0 (see sort.hip CountPublish); the event is recorded behind it
-                    const uint2* pre_counts = nullptr, uint32_t pre_nblocks = 0,
-                    uint32_t* count_host_word = nullptr, uint32_t* count_header_words = nullptr,
-                    hipEvent_t count_event = nullptr);
+                    uint32_t* val_b, uint32_t* key_c, uint32_t* val_c, uint32_t* ds_table,
+                    uint32_t nchunks, uint32_t* V_out, const uint32_t* range /* header: key_base, key_far */,
+                    // hierarchical binning: the rectangles ride along (all NULL otherwise)
+                    const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint32_t* aux_c,
+                    uint2* rect_sorted, uint32_t* counts_sorted,
+                    // per-workgroup words of preprocess; publish_here: pass 0 sums them (counts ->
+                    // pinned host words + header, key range -> header) and the event is recorded behind it
+                    const uint4* pre_counts, uint32_t pre_nblocks, bool publish_here,
+                    uint32_t* count_host_word, uint32_t* count_header_words, hipEvent_t count_event);
 
 // offsets[i] = exclusive prefix sum over tiles_sorted[i]; *total_out (device) = sum, also stored
 // to total_host[0] (pinned, device-mapped; [1] = element count) when not NULL.  gather_gid != NULL:
@@ -395,14 +405,20 @@ struct CkptArgs {
   BlobHeader* bin_hdr;  // receives ckpt_off256 / ckpt_slots
   uint32_t off256, slots;
 };
+// where a producer / consumer hand-over that gave up reports it (render_fwd.hip pc_fail)
+struct PCErr {
+  uint32_t* header_word;   // image blob header: pc_timeout
+  uint32_t* host_word;     // the calling thread's sticky error word (pinned, device-mapped), may be NULL
+};
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
                            uint32_t heavy_min, uint32_t R /* num_rendered */,
                            bool aux /* track + write n_contrib (needed by the backward only) */,
-                           bool classified = false /* work lists already built (hier_binning.hip) */,
-                           const CkptArgs* ck = nullptr /* aux only: blend checkpoints for the backward */);
+                           bool classified /* work lists already built (hier_binning.hip) */,
+                           const CkptArgs* ck /* aux only: blend checkpoints for the backward, or NULL */,
+                           const PCErr pc_err);
 void render_class_multipliers(uint32_t* c0_mul, uint32_t* c1_mul);   // render_fwd.hip
 uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min);   // render_fwd.hip
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
@@ -441,7 +457,7 @@ void launch_frame_init(hipStream_t s, char* geom, char* bin /* may be NULL */, c
                        uint32_t V_init, uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S,
                        uint2* ranges /* zeroed, may be NULL */, uint32_t T,
                        uint32_t* work /* render counters zeroed, may be NULL */, char* zero_begin,
-                       size_t zero_bytes);
+                       size_t zero_bytes, bool geom_has_grad /* -> geometry header has_grad_rec */);
 void launch_bin_header(hipStream_t s, char* bin, uint32_t P, uint32_t Rcap, uint32_t W, uint32_t H,
                        uint32_t S, uint2* ranges /* zeroed, may be NULL */, uint32_t T,
                        uint32_t* work /* zeroed, may be NULL */);

@@ -112,56 +112,34 @@ __device__ __forceinline__ void sh_to_rgb(const int deg, const float* __restrict
 }
 
 // Per-workgroup sums of the tile counts (instances, and (Gaussian, super-tile) pairs of the
-// hierarchical binning) -> pre_counts[blockIdx]; publish_counts_kernel adds them up right behind
-// the preprocess launch, so num_rendered reaches the host ~70 us into the frame -- long before the
+// hierarchical binning) and min / max of the visible depth keys -> pre_counts[blockIdx].  They are
+// added up right behind the preprocess launch (sort.hip: by the first pass of the depth sort, or by
+// publish_counts_kernel), so num_rendered reaches the host ~100 us into the frame -- long before the
 // host has finished enqueuing the frame's remaining launches -- instead of after the whole binning
-// chain (rasterizer_impl.cu:284 reads it back after its InclusiveSum).  No global atomics.
+// chain (rasterizer_impl.cu:284 reads it back after its InclusiveSum), and the depth sort learns the
+// range of its keys.  No global atomics.
 __device__ __forceinline__ void block_count_sums(const uint32_t my_tiles, const uint32_t my_st,
-                                                 uint2* __restrict__ pre_counts) {
-  __shared__ uint32_t s_cnt[8];
-  uint32_t a = my_tiles, b = my_st;
+                                                 const uint32_t my_key /* CULLED_KEY: not visible */,
+                                                 uint4* __restrict__ pre_counts) {
+  __shared__ uint32_t s_cnt[16];
+  uint32_t a = my_tiles, b = my_st, mn = my_key, mx = my_key == CULLED_KEY ? 0u : my_key;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     a += __shfl_xor(a, o);
     b += __shfl_xor(b, o);
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
   }
-  if ((threadIdx.x & 63) == 0) { s_cnt[2 * (threadIdx.x >> 6)] = a; s_cnt[2 * (threadIdx.x >> 6) + 1] = b; }
+  if ((threadIdx.x & 63) == 0) {
+    const uint32_t w = threadIdx.x >> 6;
+    s_cnt[4 * w] = a; s_cnt[4 * w + 1] = b; s_cnt[4 * w + 2] = mn; s_cnt[4 * w + 3] = mx;
+  }
   __syncthreads();
   if (threadIdx.x == 0)
-    pre_counts[blockIdx.x] = make_uint2(s_cnt[0] + s_cnt[2] + s_cnt[4] + s_cnt[6],
-                                        s_cnt[1] + s_cnt[3] + s_cnt[5] + s_cnt[7]);
-}
-
-// One workgroup: sum of the per-workgroup counts -> pinned host words ([0] num_rendered, [1]
-// coarse pairs; saturating at 2^32 - 1) and the geometry header's spare words.
-__global__ void __launch_bounds__(1024)
-publish_counts_kernel(const uint2* __restrict__ pre_counts, const uint32_t nblocks,
-                      uint32_t* __restrict__ host_word, uint32_t* __restrict__ header_words) {
-  __shared__ unsigned long long s_r[16], s_c[16];
-  unsigned long long r = 0ull, c = 0ull;
-  for (uint32_t i = threadIdx.x; i < nblocks; i += 1024u) {
-    const uint2 v = pre_counts[i];
-    r += v.x; c += v.y;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    r += __shfl_xor(r, o);
-    c += __shfl_xor(c, o);
-  }
-  if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6] = r; s_c[threadIdx.x >> 6] = c; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    r = 0ull; c = 0ull;
-    for (int w = 0; w < 16; w++) { r += s_r[w]; c += s_c[w]; }
-    const uint32_t r32 = r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;
-    const uint32_t c32 = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
-    if (header_words) { header_words[0] = r32; header_words[1] = c32; }
-    if (host_word) {
-      host_word[0] = r32;
-      host_word[1] = c32;
-      __threadfence_system();
-    }
-  }
+    pre_counts[blockIdx.x] = make_uint4(s_cnt[0] + s_cnt[4] + s_cnt[8] + s_cnt[12],
+                                        s_cnt[1] + s_cnt[5] + s_cnt[9] + s_cnt[13],
+                                        min(min(s_cnt[2], s_cnt[6]), min(s_cnt[10], s_cnt[14])),
+                                        max(max(s_cnt[3], s_cnt[7]), max(s_cnt[11], s_cnt[15])));
 }
 
 __global__ void __launch_bounds__(256)
@@ -176,8 +154,8 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   int* __restrict__ radii, float4* __restrict__ rec,
                   uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
                   uint2* __restrict__ rects /* packed tile rectangles (hierarchical binning), or NULL */,
-                  uint32_t* __restrict__ ds_table0 /* [chunk][256] pass-0 counts of the fat depth sort, or NULL */,
-                  uint2* __restrict__ pre_counts /* [workgroups] (instances, coarse pairs) sums */,
+                  uint32_t* __restrict__ ds_table0 /* [chunk][DS_RADIX] pass-0 counts of the fat depth sort, or NULL */,
+                  uint4* __restrict__ pre_counts /* [workgroups] (instances, coarse pairs, min key, max key) */,
                   const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
   // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
   // loads.  Stage the workgroup's 256 x 12 B = 3 KB per array through LDS with 16-byte loads
@@ -207,11 +185,12 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   // sectors, fully coalesced; a lane-per-record store would touch 64 sectors per instruction).
   // Culled Gaussians get an all-zero record (radius 0, opacity 0): nothing ever gathers it.
   __shared__ float4 s_out[256 * REC_STRIDE];
-  // Pass-0 digit histogram of the depth sort (sort.hip, fat passes): the low byte of the depth
-  // key of every VISIBLE Gaussian, aggregated per workgroup in LDS; the 256 Gaussians of a
+  // Pass-0 digit histogram of the depth sort (sort.hip, fat passes): the low DS_BITS bits of the
+  // depth key of every VISIBLE Gaussian, aggregated per workgroup in LDS; the 256 Gaussians of a
   // workgroup lie in one 8192-key chunk, so it costs one global atomic per non-empty digit.
   __shared__ uint32_t s_dh[DS_RADIX];
-  s_dh[threadIdx.x] = 0u;
+#pragma unroll
+  for (int k = 0; k < DS_RADIX / 256; k++) s_dh[k * 256 + threadIdx.x] = 0u;
   const int idx = base + threadIdx.x;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   uint32_t my_key = CULLED_KEY, my_tiles = 0u, my_st = 0u;
@@ -282,11 +261,14 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   }
   if (ds_table0 != nullptr) {
     __syncthreads();
-    const uint32_t cnt = s_dh[threadIdx.x];
-    if (cnt != 0u)
-      atomicAdd(&ds_table0[(size_t)(blockIdx.x / (DS_CHUNK / 256)) * DS_RADIX + threadIdx.x], cnt);
+#pragma unroll
+    for (int k = 0; k < DS_RADIX / 256; k++) {
+      const uint32_t cnt = s_dh[k * 256 + threadIdx.x];
+      if (cnt != 0u)
+        atomicAdd(&ds_table0[(size_t)(blockIdx.x / (DS_CHUNK / 256)) * DS_RADIX + k * 256 + threadIdx.x], cnt);
+    }
   }
-  if (pre_counts != nullptr) block_count_sums(my_tiles, my_st, pre_counts);
+  if (pre_counts != nullptr) block_count_sums(my_tiles, my_st, my_key, pre_counts);
 }
 
 __global__ void __launch_bounds__(256)
@@ -363,10 +345,11 @@ preprocess_composed_kernel(const int P, const int D, const int M,
                            const float focal_y, int* __restrict__ radii, float4* __restrict__ rec,
                            uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
                            uint2* __restrict__ rects, uint32_t* __restrict__ ds_table0,
-                           uint2* __restrict__ pre_counts) {
+                           uint4* __restrict__ pre_counts) {
   __shared__ float4 s_out[256 * REC_STRIDE];
   __shared__ uint32_t s_dh[DS_RADIX];
-  s_dh[threadIdx.x] = 0u;
+#pragma unroll
+  for (int k = 0; k < DS_RADIX / 256; k++) s_dh[k * 256 + threadIdx.x] = 0u;
   const int base = blockIdx.x * 256;
   const int idx = base + threadIdx.x;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
@@ -431,17 +414,20 @@ preprocess_composed_kernel(const int P, const int D, const int M,
   }
   if (ds_table0 != nullptr) {
     __syncthreads();
-    const uint32_t cnt = s_dh[threadIdx.x];
-    if (cnt != 0u)
-      atomicAdd(&ds_table0[(size_t)(blockIdx.x / (DS_CHUNK / 256)) * DS_RADIX + threadIdx.x], cnt);
+#pragma unroll
+    for (int k = 0; k < DS_RADIX / 256; k++) {
+      const uint32_t cnt = s_dh[k * 256 + threadIdx.x];
+      if (cnt != 0u)
+        atomicAdd(&ds_table0[(size_t)(blockIdx.x / (DS_CHUNK / 256)) * DS_RADIX + k * 256 + threadIdx.x], cnt);
+    }
   }
-  if (pre_counts != nullptr) block_count_sums(my_tiles, my_st, pre_counts);
+  if (pre_counts != nullptr) block_count_sums(my_tiles, my_st, my_key, pre_counts);
 }
 
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
                                 uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                                uint32_t* ds_table0, uint2* pre_counts) {
+                                uint32_t* ds_table0, uint4* pre_counts) {
   if (P <= 0) return;
 #define PC_LAUNCH(M4)                                                                           \
   preprocess_composed_kernel<M4><<<(P + 255) / 256, 256, 0, s>>>(                                \
@@ -464,7 +450,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                       uint32_t* ds_table0, uint2* pre_counts) {
+                       uint32_t* ds_table0, uint4* pre_counts) {
   if (P <= 0) return;
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
@@ -473,10 +459,6 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
       pre_counts, ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
 }
 
-void launch_publish_counts(hipStream_t s, const uint2* pre_counts, uint32_t nblocks,
-                           uint32_t* host_word, uint32_t* header_words) {
-  publish_counts_kernel<<<1, 1024, 0, s>>>(pre_counts, nblocks, host_word, header_words);
-}
 
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations,

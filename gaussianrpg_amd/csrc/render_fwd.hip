@@ -671,10 +671,25 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 //                         mix of old and new bounds is a superset of the current box (the cull
 //                         stays conservative, results are unchanged).
 // Same arithmetic in the same order as blend_heavy: bit-identical images.
-// Spin loops are bounded (PC_SPIN_LIMIT): a protocol error ends the wave instead of hanging.
+// Spin loops are bounded (PC_SPIN_LIMIT): a protocol error ends the wave instead of hanging -- and
+// is REPORTED: the wave raises pc_timeout in the image blob's header and the calling thread's sticky
+// error word (pinned host memory), and the next entry point that thread calls fails with
+// GRPG_ERR_HIP (api.hip check_async_error; debug = true: the forward itself fails).  The pixels of
+// that quarter are wrong, nothing else is.  -DGRPG_PC_SPIN_LIMIT=0 builds the variant the timeout
+// test forces the path with (tests/test_gpu_pc_timeout.py).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t PC_DONE = 0xFFFFFFFFu;
-constexpr uint32_t PC_SPIN_LIMIT = 1u << 24;
+#ifndef GRPG_PC_SPIN_LIMIT
+#define GRPG_PC_SPIN_LIMIT (1u << 24)
+#endif
+constexpr uint32_t PC_SPIN_LIMIT = GRPG_PC_SPIN_LIMIT;
+
+__device__ __forceinline__ void pc_fail(const PCErr err, const int lane) {
+  if (lane == 0) {
+    if (err.header_word) *err.header_word = 1u;
+    if (err.host_word) { *err.host_word = 1u; __threadfence_system(); }
+  }
+}
 
 struct PCCtrl {
   uint32_t flag[2];
@@ -697,7 +712,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
                                             const int quarter, const uint32_t r_begin,
                                             const uint32_t r_end,
                                             const uint32_t* __restrict__ point_list,
-                                            const RecView rec) {
+                                            const RecView rec, const PCErr err) {
   const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
   const uint64_t lt = lanemask_lt();
   uint32_t in_pos = r_begin, head = 0, count = 0;
@@ -763,7 +778,8 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
       if (cnt > 0) {
         uint32_t spins = 0;
         while (pc_load(&ctl->flag[cur]) != 0u) {   // wait until the consumer released this buffer
-          if (pc_load(&ctl->stop) != 0u || ++spins > PC_SPIN_LIMIT) { stopped = true; break; }
+          if (pc_load(&ctl->stop) != 0u) { stopped = true; break; }
+          if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); stopped = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         if (stopped) break;
@@ -785,7 +801,8 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   if (!stopped) {   // end-of-list marker
     uint32_t spins = 0;
     while (pc_load(&ctl->flag[cur]) != 0u) {
-      if (pc_load(&ctl->stop) != 0u || ++spins > PC_SPIN_LIMIT) return;
+      if (pc_load(&ctl->stop) != 0u) return;
+      if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); return; }
       __builtin_amdgcn_s_sleep(1);
     }
     pc_store(&ctl->flag[cur], PC_DONE);
@@ -802,7 +819,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             float* __restrict__ out_depth,
                                             float* __restrict__ out_alpha,
                                             uint32_t* __restrict__ n_contrib, CkptWriter ckw,
-                                            const uint32_t len) {
+                                            const uint32_t len, const PCErr err) {
   const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
   const float pxf = (float)px;
   WavePix<1> st;
@@ -815,7 +832,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
   else for (;;) {
     uint32_t f, spins = 0;
     while ((f = pc_load(&ctl->flag[cur])) == 0u) {
-      if (++spins > PC_SPIN_LIMIT) { f = PC_DONE; break; }
+      if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); f = PC_DONE; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     if (f == PC_DONE) break;
@@ -885,7 +902,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                      const uint32_t pc_slots, const int xcd_on, const CkptArgs ck,
+                      const uint32_t pc_slots, const int xcd_on, const CkptArgs ck, const PCErr pc_err,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
@@ -922,11 +939,11 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
     if (wave < 2) {
       pc_consumer<WRITE_AUX>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
-                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb);
+                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err);
       if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
     } else
       pc_producer(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
-                  rb, re, point_list, rec);
+                  rb, re, point_list, rec, pc_err);
     return;
   }
   // Dispatch order (longest processing time first): class 0, class 1, the LIGHT tiles, class 2.
@@ -1094,7 +1111,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
                            uint32_t heavy_min, uint32_t R, bool aux, bool classified,
-                           const CkptArgs* ckp) {
+                           const CkptArgs* ckp, const PCErr pc_err) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   const CkptArgs ck = (aux && ckp) ? *ckp : CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
@@ -1118,11 +1135,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
     if (aux)                                                                                   \
       render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                        \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots, xcd, ck);                                             \
+          out_alpha, n_contrib, pc_slots, xcd, ck, pc_err);                                     \
     else                                                                                       \
       render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                       \
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots, xcd, ck);                                             \
+          out_alpha, n_contrib, pc_slots, xcd, ck, pc_err);                                     \
   } while (0)
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
   if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
@@ -1132,7 +1149,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
       render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, lds_pad, s>>>(
           ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
-          out_alpha, n_contrib, pc_slots, xcd, ck, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
+          out_alpha, n_contrib, pc_slots, xcd, ck, pc_err, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
       (void)hipMemcpyAsync(h.data(), d_trace, words * 4, hipMemcpyDeviceToHost, s);
       (void)hipStreamSynchronize(s);

@@ -16,14 +16,14 @@
 //  * fat (depth sort of the P Gaussians, P <= 4 M): 1024-thread workgroups own 8192 keys, the count
 //    table is [chunk][digit] and so small (245 rows at P = 2 M) that every workgroup sweeps it
 //    itself for its digit bases: a pass is ONE scatter launch plus one small histogram launch for
-//    the next pass (pass 0's table comes from preprocess_kernel) -- 7 launches instead of 12, and
-//    pass 0 drops the culled Gaussians, so passes 1-3 move V instead of P pairs.
+//    the next pass (pass 0's table comes from preprocess_kernel); pass 0 drops the culled
+//    Gaussians, so the later passes move V instead of P pairs; and THREE 9-bit passes over
+//    key - key_base settle the order whenever the visible depths span less than 2^27 key values
+//    (a fourth pass over the remaining 5 bits runs only when the device finds they do not).
 // Element counts that only the device knows (V visible Gaussians, R instances) are read from
 // device memory; grids are sized by the host-side upper bound and surplus workgroups exit.
 // Stability: a chunk is split wave-major, each wave walks its keys in rounds of 64 consecutive
 // keys, ranks are (digit, wave, round, lane)-ordered.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace grpg {
@@ -238,20 +238,34 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// Fat depth sort (P <= DS_MAX_CHUNKS * 8192): one scatter launch per 8-bit pass.
+// Fat depth sort (P <= DS_MAX_CHUNKS * 8192): one scatter launch per 9-bit pass, THREE passes.
 //
-// The count table of a pass is [chunk][digit] (u32).  A workgroup sweeps ALL rows itself
-// (245 rows x 1 KB at P = 2 M, L2-resident): per digit the sum over the earlier chunks (its base
-// inside the digit's region) and the grand total (exclusive scan over digits = start of the
+// The reference sorts all 32 depth bits (rasterizer_impl.cu:303-311).  Visible depths are floats
+// > 0.2 whose bit patterns span far fewer than 2^32 values: with key_base = the smallest visible
+// key rounded down to a multiple of 2^18, every visible key satisfies key - key_base < 2^27 as long
+// as the farthest visible Gaussian is less than ~65 000 times as far away as the nearest one.  The
+// order of the keys is the order of (key - key_base), and subtracting a multiple of 2^18 leaves the
+// low 18 bits alone: passes 0 and 1 take bits [0,9) and [9,18) of the RAW key (so preprocess can
+// histogram pass 0 before anybody knows the minimum), pass 2 takes bits [18,27) of key - key_base.
+// When the range test fails (key_far != 0, decided on the device from preprocess' per-workgroup
+// min / max), pass 2 writes into the spare buffers and pass 3 sorts the remaining bits [27,32) of
+// key - key_base; otherwise pass 2 writes the final arrays and the two launches of pass 3 exit at
+// once.  Either way the result is the exact stable (depth_bits, id) order, in the same arrays.
+//
+// The count table of a pass is [chunk][digit] (u32).  A workgroup sweeps the rows of ALL chunks
+// itself (245 rows x 2 KB at P = 2 M, L2-resident): per digit the sum over the earlier chunks (its
+// base inside the digit's region) and the grand total (exclusive scan over digits = start of the
 // region).  Pass 0 reads the P depth keys written by preprocess, whose workgroups also left
 // table 0 behind; culled Gaussians (CULLED_KEY) are dropped right there, so from pass 1 on the
 // arrays hold only the V visible ones.  V = sum of table 0, published by chunk 0 of pass 0.
-// The tables of passes 1-3 come from depth_hist_kernel, launched after the previous scatter.
+// The tables of the later passes come from depth_hist_kernel, launched after the previous scatter;
+// they are written for the ceil(V / 8192) chunks that hold data and swept for exactly those.
 // Measured dead ends: accumulating the offsets scan's per-2048 block sums in the last pass with one
 // global atomic per wave (23 k agent-scope atomics on ~45 cache lines: 175 us; the separate reduce
-// launch costs 5), and gathering the tile counts into sorted order in the last pass (one
-// 1024-thread workgroup per CU keeps too few random loads in flight: +38 us; the reduce launch of
-// the offsets scan does it instead).
+// launch costs 5), gathering the tile counts into sorted order in the last pass (one
+// 1024-thread workgroup per CU keeps too few random loads in flight: +38 us), the next pass's
+// counts by one global atomic per key (0.096 -> 0.42 ms), 11-bit digits (a [2048][chunks] table
+// costs more than the pass it saves), 512-thread workgroups.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, const uint32_t lane) {
 #pragma unroll
@@ -262,13 +276,27 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, const uint32_
   return v;
 }
 
+// digit of pass PASS; `base` = key_base (used from pass 2 on)
+template <int PASS>
+__device__ __forceinline__ uint32_t ds_digit(const uint32_t key, const uint32_t base) {
+  if (PASS == 0) return key & (DS_RADIX - 1);
+  if (PASS == 1) return (key >> DS_BITS) & (DS_RADIX - 1);
+  if (PASS == 2) return ((key - base) >> (2 * DS_BITS)) & (DS_RADIX - 1);
+  return (key - base) >> (3 * DS_BITS);   // 5 bits
+}
+
+// range[0] = key_base, range[1] = key_far (geometry header, written by pass 0's publishing workgroup)
+template <int PASS>
 __global__ void __launch_bounds__(DS_THREADS)
 depth_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_dev,
-                  const int shift, uint32_t* __restrict__ table /* [chunk][256] of this pass */) {
+                  const uint32_t* __restrict__ range,
+                  uint32_t* __restrict__ table /* [chunk][DS_RADIX] of this pass */) {
   __shared__ uint32_t h[DS_RADIX];
+  if (PASS == 3 && range[1] == 0u) return;   // three passes settle the order
   const uint32_t n = *n_dev;
   const uint32_t base = blockIdx.x * DS_CHUNK;
-  if (base >= n) return;   // rows beyond the data stay zero (frame_init)
+  if (base >= n) return;   // rows beyond the data are never swept
+  const uint32_t kb = PASS >= 2 ? range[0] : 0u;
   if (threadIdx.x < DS_RADIX) h[threadIdx.x] = 0;
   __syncthreads();
   uint32_t kk[DS_ITEMS];
@@ -280,7 +308,7 @@ depth_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict_
 #pragma unroll
   for (int k = 0; k < DS_ITEMS; k++) {
     const uint32_t idx = base + k * DS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(kk[k] >> shift) & (DS_RADIX - 1)], 1u);
+    if (idx < n) atomicAdd(&h[ds_digit<PASS>(kk[k], kb)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < DS_RADIX) table[(size_t)blockIdx.x * DS_RADIX + threadIdx.x] = h[threadIdx.x];
@@ -294,10 +322,10 @@ depth_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict_
 // 4 bytes per pair and pass.
 struct RectPayload {
   const uint2* rects_by_id;   // pass 0 input
-  const uint32_t* aux_in;     // passes 1..3 input (packed)
-  uint32_t* aux_out;          // passes 0..2 output (packed)
-  uint2* rect_sorted;         // pass 3 output
-  uint32_t* counts_sorted;    // pass 3 output: super-tiles per Gaussian, depth order
+  const uint32_t* aux_in;     // later passes' input (packed)
+  uint32_t* aux_out;          // output of a pass that is not the last (packed)
+  uint2* rect_sorted;         // the last pass' output
+  uint32_t* counts_sorted;    // the last pass' output: super-tiles per Gaussian, depth order
 };
 __device__ __forceinline__ uint32_t rect_pack(const uint2 r) {
   return (r.x & 0xFFu) | ((r.x >> 16) << 8) | ((r.y & 0xFFu) << 16) | ((r.y >> 16) << 24);
@@ -308,64 +336,113 @@ __device__ __forceinline__ uint2 rect_unpack(const uint32_t p) {
 
 // The frame's count publish rides in pass 0 (its last, usually partial, chunk's workgroup): the sum
 // of preprocess' per-workgroup (instances, coarse pairs) goes to the pinned host words and the
-// geometry header; the host's event is recorded behind this launch.  One launch fewer per frame.
+// geometry header, the min / max of the visible depth keys become key_base / key_far; the host's
+// event is recorded behind this launch.
 struct CountPublish {
-  const uint2* pre_counts;   // NULL: nothing to publish
+  const uint4* pre_counts;   // per preprocess workgroup: instances, coarse pairs, min key, max key
   uint32_t nblocks;
-  uint32_t* host_word;       // pinned, device-mapped: [0] num_rendered, [1] coarse pairs
-  uint32_t* header_words;    // geometry header R_pre, Rc_pre
+  uint32_t* host_word;       // pinned, device-mapped: [0] num_rendered, [1] coarse pairs (may be NULL)
+  uint32_t* header_words;    // geometry header: R_pre, Rc_pre, key_base, key_far
+};
+
+// Sum / min / max of preprocess' per-workgroup words -> header (+ pinned host words).  Called by
+// all threads of ONE workgroup of NT threads.
+template <int NT>
+__device__ __forceinline__ void publish_frame_counts(const CountPublish pub) {
+  constexpr int NW = NT / 64;
+  __shared__ unsigned long long s_pr[NW], s_pc[NW];
+  __shared__ uint32_t s_mn[NW], s_mx[NW];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long r = 0ull, c = 0ull;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  for (uint32_t i = tid; i < pub.nblocks; i += NT) {
+    const uint4 v = pub.pre_counts[i];
+    r += v.x; c += v.y;
+    mn = min(mn, v.z); mx = max(mx, v.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    r += __shfl_xor(r, o);
+    c += __shfl_xor(c, o);
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+  }
+  if (lane == 0) { s_pr[wave] = r; s_pc[wave] = c; s_mn[wave] = mn; s_mx[wave] = mx; }
+  __syncthreads();
+  if (tid == 0) {
+    r = 0ull; c = 0ull; mn = 0xFFFFFFFFu; mx = 0u;
+    for (int w = 0; w < NW; w++) {
+      r += s_pr[w]; c += s_pc[w];
+      mn = min(mn, s_mn[w]); mx = max(mx, s_mx[w]);
+    }
+    const uint32_t r32 = r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;   // saturating
+    const uint32_t c32 = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+    // nothing visible: mn > mx, any base will do
+    const uint32_t kbase = mn <= mx ? (mn & ~((1u << (2 * DS_BITS)) - 1u)) : 0u;
+    const uint32_t kfar = (mn <= mx && ((mx - kbase) >> (3 * DS_BITS)) != 0u) ? 1u : 0u;
+    if (pub.header_words) {
+      pub.header_words[0] = r32; pub.header_words[1] = c32;
+      pub.header_words[2] = kbase; pub.header_words[3] = kfar;
+    }
+    if (pub.host_word) { pub.host_word[0] = r32; pub.host_word[1] = c32; __threadfence_system(); }
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+publish_counts_kernel(const CountPublish pub) { publish_frame_counts<1024>(pub); }
+
+void launch_publish_counts(hipStream_t s, const uint4* pre_counts, uint32_t nblocks,
+                           uint32_t* host_word, uint32_t* header_words) {
+  const CountPublish pub = {pre_counts, nblocks, host_word, header_words};
+  publish_counts_kernel<<<1, 1024, 0, s>>>(pub);
+}
+
+// Where a pass writes.  Pass 2 chooses on the device: `near` when three passes settle the order
+// (it is the last pass then), `far` when pass 3 has to follow.
+struct PassOut {
+  uint32_t* keys;
+  uint32_t* vals;
 };
 
 template <int PASS, bool RECT>
 __global__ void __launch_bounds__(DS_THREADS)
 depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                     const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][256] */,
-                     const uint32_t nchunks, uint32_t* __restrict__ V_out, const RectPayload rp,
+                     const PassOut out_near, const PassOut out_far,
+                     const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][DS_RADIX] */,
+                     const uint32_t nchunks, uint32_t* __restrict__ V_out,
+                     const uint32_t* __restrict__ range /* key_base, key_far */, const RectPayload rp,
                      const CountPublish pub) {
-  __shared__ uint32_t s_keys[DS_CHUNK];
-  __shared__ uint32_t s_vals[DS_CHUNK];
-  __shared__ uint32_t s_aux[RECT ? DS_CHUNK : 1];
+  // keys | values | payload staged for the coalesced run writes; the per-wave partial column sums
+  // of the table sweep live in the first two thirds until the keys are staged
+  __shared__ uint32_t s_buf[(RECT ? 3 : 2) * DS_CHUNK];
   __shared__ uint32_t s_cnt[DS_WAVES * DS_RADIX];   // [wave][digit]: bank-conflict-free ranking
   __shared__ uint32_t s_gbase[DS_RADIX];
-  __shared__ uint32_t s_w[8];
-  // per-wave partial column sums of the table sweep live in s_keys until the keys are staged
-  uint32_t* s_pex = s_keys;                          // [DS_WAVES][DS_RADIX]
-  uint32_t* s_ptot = s_keys + DS_WAVES * DS_RADIX;   // [DS_WAVES][DS_RADIX]
-  static_assert(2 * DS_WAVES * DS_RADIX <= DS_CHUNK, "sweep partials must fit in s_keys");
+  __shared__ uint32_t s_w[2 * (DS_RADIX / 64)];
+  uint32_t* const s_keys = s_buf;
+  uint32_t* const s_vals = s_buf + DS_CHUNK;
+  uint32_t* const s_aux = s_buf + (RECT ? 2 : 0) * DS_CHUNK;
+  uint32_t* const s_pex = s_buf;                          // [DS_WAVES][DS_RADIX]
+  uint32_t* const s_ptot = s_buf + DS_WAVES * DS_RADIX;   // [DS_WAVES][DS_RADIX]
+  static_assert(2 * DS_WAVES * DS_RADIX <= 2 * DS_CHUNK, "sweep partials must fit in the staging area");
+  constexpr int DW = DS_RADIX / 64;   // waves whose threads own a digit
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t chunk = blockIdx.x;
-  constexpr int shift = 8 * PASS;
-  if (PASS == 0 && pub.pre_counts != nullptr && chunk == nchunks - 1u) {
-    __shared__ unsigned long long s_pr[DS_WAVES], s_pc[DS_WAVES];
-    unsigned long long r = 0ull, c = 0ull;
-    for (uint32_t i = tid; i < pub.nblocks; i += DS_THREADS) {
-      const uint2 v = pub.pre_counts[i];
-      r += v.x; c += v.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      r += __shfl_xor(r, o);
-      c += __shfl_xor(c, o);
-    }
-    if (lane == 0) { s_pr[wave] = r; s_pc[wave] = c; }
-    __syncthreads();
-    if (tid == 0) {
-      r = 0ull; c = 0ull;
-      for (int w = 0; w < DS_WAVES; w++) { r += s_pr[w]; c += s_pc[w]; }
-      const uint32_t r32 = r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;   // saturating, like publish_counts_kernel
-      const uint32_t c32 = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
-      if (pub.header_words) { pub.header_words[0] = r32; pub.header_words[1] = c32; }
-      if (pub.host_word) { pub.host_word[0] = r32; pub.host_word[1] = c32; __threadfence_system(); }
-    }
-  }
+  const uint32_t far = PASS >= 2 ? range[1] : 0u;
+  if (PASS == 3 && far == 0u) return;   // pass 2 was the last one
+  const uint32_t kb = PASS >= 2 ? range[0] : 0u;
+  const bool last = PASS == 3 || (PASS == 2 && far == 0u);
+  uint32_t* const keys_out = (PASS == 2 && far != 0u) ? out_far.keys : out_near.keys;
+  uint32_t* const vals_out = (PASS == 2 && far != 0u) ? out_far.vals : out_near.vals;
+  if (PASS == 0 && pub.pre_counts != nullptr && chunk == nchunks - 1u) publish_frame_counts<DS_THREADS>(pub);
 
   // ---- the chunk's own loads go out first: they overlap the table sweep below.  Pass 0 moves
   // P keys; later passes move the V visible ones (published by chunk 0 of pass 0). ----
   const uint32_t n_in = PASS == 0 ? P : *V_out;
+  const uint32_t nrows = PASS == 0 ? nchunks : min(nchunks, (n_in + DS_CHUNK - 1) / DS_CHUNK);
   const uint32_t chunk_base = chunk * DS_CHUNK;
   const uint32_t chunk_n = chunk_base < n_in ? min((uint32_t)DS_CHUNK, n_in - chunk_base) : 0u;
+  if (PASS > 0 && chunk_n == 0u) return;   // a chunk beyond the data (pass 0: chunk 0 still owes V)
   uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS], aux[RECT ? DS_ITEMS : 1];
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
@@ -379,28 +456,36 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   }
 
   // ---- sweep the count table: per digit, sum over earlier chunks and over all chunks ----
-  // A wave reads whole 1 KB rows (lane l: digits 4l..4l+3, one 16-byte load); wave w owns rows
-  // w, w+16, ...; 8 rows are in flight per wave, so 245 rows cost two memory round trips.
+  // A wave reads whole 2 KB rows (lane l: digits 8l..8l+7, two 16-byte loads); wave w owns rows
+  // w, w+16, ...; 8 rows (16 loads) are in flight per wave: 245 rows cost two round trips.
   {
     const uint4* t4 = reinterpret_cast<const uint4*>(table);
-    uint4 ex = make_uint4(0u, 0u, 0u, 0u), tot = ex;
+    uint4 exa = make_uint4(0u, 0u, 0u, 0u), exb = exa, tota = exa, totb = exa;
     constexpr int SW = 8;
-    for (uint32_t r0 = wave; r0 < nchunks; r0 += DS_WAVES * SW) {
-      uint4 v[SW];
+    for (uint32_t r0 = wave; r0 < nrows; r0 += DS_WAVES * SW) {
+      uint4 va[SW], vb[SW];
 #pragma unroll
       for (int k = 0; k < SW; k++) {
         const uint32_t r = r0 + (uint32_t)k * DS_WAVES;
-        v[k] = r < nchunks ? t4[(size_t)r * (DS_RADIX / 4) + lane] : make_uint4(0u, 0u, 0u, 0u);
+        const bool in = r < nrows;
+        va[k] = in ? t4[(size_t)r * (DS_RADIX / 4) + 2 * lane] : make_uint4(0u, 0u, 0u, 0u);
+        vb[k] = in ? t4[(size_t)r * (DS_RADIX / 4) + 2 * lane + 1] : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int k = 0; k < SW; k++) {
         const uint32_t r = r0 + (uint32_t)k * DS_WAVES;
-        tot.x += v[k].x; tot.y += v[k].y; tot.z += v[k].z; tot.w += v[k].w;
-        if (r < chunk) { ex.x += v[k].x; ex.y += v[k].y; ex.z += v[k].z; ex.w += v[k].w; }
+        tota.x += va[k].x; tota.y += va[k].y; tota.z += va[k].z; tota.w += va[k].w;
+        totb.x += vb[k].x; totb.y += vb[k].y; totb.z += vb[k].z; totb.w += vb[k].w;
+        if (r < chunk) {
+          exa.x += va[k].x; exa.y += va[k].y; exa.z += va[k].z; exa.w += va[k].w;
+          exb.x += vb[k].x; exb.y += vb[k].y; exb.z += vb[k].z; exb.w += vb[k].w;
+        }
       }
     }
-    reinterpret_cast<uint4*>(s_pex + wave * DS_RADIX)[lane] = ex;
-    reinterpret_cast<uint4*>(s_ptot + wave * DS_RADIX)[lane] = tot;
+    reinterpret_cast<uint4*>(s_pex + wave * DS_RADIX)[2 * lane] = exa;
+    reinterpret_cast<uint4*>(s_pex + wave * DS_RADIX)[2 * lane + 1] = exb;
+    reinterpret_cast<uint4*>(s_ptot + wave * DS_RADIX)[2 * lane] = tota;
+    reinterpret_cast<uint4*>(s_ptot + wave * DS_RADIX)[2 * lane + 1] = totb;
   }
 #pragma unroll
   for (int k = 0; k < (DS_RADIX * DS_WAVES) / DS_THREADS; k++) s_cnt[k * DS_THREADS + tid] = 0;
@@ -413,15 +498,17 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     if (lane == 63) s_w[wave] = inc;
   }
   __syncthreads();
-  const uint32_t n_all = s_w[0] + s_w[1] + s_w[2] + s_w[3];   // elements this pass moves (= V)
+  uint32_t n_all = 0;   // elements this pass moves (= V)
+#pragma unroll
+  for (int w = 0; w < DW; w++) n_all += s_w[w];
   if (tid < DS_RADIX) {
     uint32_t before = 0;
 #pragma unroll
-    for (int w = 0; w < 3; w++) before += (uint32_t)w < wave ? s_w[w] : 0u;
+    for (int w = 0; w < DW - 1; w++) before += (uint32_t)w < wave ? s_w[w] : 0u;
     s_gbase[tid] = before + inc - dtot + dex;   // first output position of (digit, this chunk)
   }
   if (PASS == 0 && chunk == 0 && tid == 0) *V_out = n_all;
-  if (chunk_n == 0u) return;   // whole workgroup (a chunk beyond the data)
+  if (chunk_n == 0u) return;   // whole workgroup (pass 0: a chunk beyond the data)
 
   // ---- rank (wave w owns the 512 consecutive keys [512 w, 512 w + 512)) ----
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -431,10 +518,10 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     // pass 0 drops culled Gaussians; later passes hold visible ones only (a visible depth key is
     // the bit pattern of a float > 0.2, never CULLED_KEY)
     const bool valid = local < chunk_n && (PASS > 0 || key[i] != CULLED_KEY);
-    const uint32_t d = (key[i] >> shift) & (DS_RADIX - 1);
+    const uint32_t d = ds_digit<PASS>(key[i], kb) & (DS_RADIX - 1);
     uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < (PASS == 3 ? 32 - 3 * DS_BITS : DS_BITS); b++) {
       const uint64_t bal = __builtin_amdgcn_ballot_w64(((d >> b) & 1u) != 0u);
       const uint32_t mine = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
       peers &= ~(bal ^ (((uint64_t)mine << 32) | mine));
@@ -446,20 +533,22 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   }
   __syncthreads();
 
-  // ---- thread d < 256 owns digit d: local start slots of its 16 (digit, wave) runs ----
+  // ---- thread d < DS_RADIX owns digit d: local start slots of its 16 (digit, wave) runs ----
   uint32_t c[DS_WAVES], dsum = 0, inc2 = 0;
   if (tid < DS_RADIX) {
 #pragma unroll
     for (int w = 0; w < DS_WAVES; w++) { c[w] = s_cnt[w * DS_RADIX + tid]; dsum += c[w]; }
     inc2 = wave_inclusive_sum(dsum, lane);
-    if (lane == 63) s_w[4 + wave] = inc2;
+    if (lane == 63) s_w[DW + wave] = inc2;
   }
   __syncthreads();
-  const uint32_t nvalid = s_w[4] + s_w[5] + s_w[6] + s_w[7];
+  uint32_t nvalid = 0;
+#pragma unroll
+  for (int w = 0; w < DW; w++) nvalid += s_w[DW + w];
   if (tid < DS_RADIX) {
     uint32_t before = 0;
 #pragma unroll
-    for (int w = 0; w < 3; w++) before += (uint32_t)w < wave ? s_w[4 + w] : 0u;
+    for (int w = 0; w < DW - 1; w++) before += (uint32_t)w < wave ? s_w[DW + w] : 0u;
     const uint32_t dstart = before + inc2 - dsum;
     uint32_t run = dstart;
 #pragma unroll
@@ -470,7 +559,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
     if (rnk[i] != 0xFFFFFFFFu) {
-      const uint32_t d = (key[i] >> shift) & (DS_RADIX - 1);
+      const uint32_t d = ds_digit<PASS>(key[i], kb) & (DS_RADIX - 1);
       const uint32_t slot = s_cnt[wave * DS_RADIX + d] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
@@ -485,11 +574,11 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const uint32_t j = i * DS_THREADS + tid;
     if (j < nvalid) {
       const uint32_t k = s_keys[j];
-      const uint32_t g = s_gbase[(k >> shift) & (DS_RADIX - 1)] + j;
+      const uint32_t g = s_gbase[ds_digit<PASS>(k, kb) & (DS_RADIX - 1)] + j;
       keys_out[g] = k;
       vals_out[g] = s_vals[j];
       if (RECT) {
-        if (PASS < 3) {
+        if (PASS < 2 || !last) {
           rp.aux_out[g] = s_aux[j];
         } else {
           const uint2 r = rect_unpack(s_aux[j]);
@@ -504,40 +593,48 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 // Depth sort of the P (key, id) pairs; ids are implicit in pass 0.  Result: (key_a, val_a) hold
 // the V visible pairs in (depth_bits, id) order, *V_out = V (the per-Gaussian tile counts are
 // brought into sorted order by the offsets scan's reduce launch -- or, with the rectangle payload
-// below, arrive in sorted order with the last pass).  ds_table must be zero except
-// for the rows of pass 0 (preprocess).  7 launches.
+// below, arrive in sorted order with the last pass).  Table 0 of ds_table must hold preprocess'
+// pass-0 counts; pre_counts its per-workgroup (instances, coarse pairs, min key, max key); `range`
+// = the geometry header's (key_base, key_far) words, written by pass 0 when publish_here, by
+// launch_publish_counts before this call otherwise.  key_a (the raw keys by id) is consumed;
+// (key_b, val_b) and (key_c, val_c) are scratch.  7 launches, the last two of which exit at once
+// unless the depth range needs the fourth pass.
 // rects_by_id != NULL (hierarchical binning, grid <= 255 x 255 tiles): the tile rectangles ride along
-// (RectPayload above); aux_a / aux_b are two scratch arrays of P words, rect_sorted [P] and
+// (RectPayload above); aux_a / aux_b / aux_c are scratch arrays of P words, rect_sorted [P] and
 // counts_sorted [P] receive the rectangles and super-tile counts in depth order.  aux_a may alias
-// rect_sorted (it is dead before pass 3 writes that array).
+// rect_sorted (it is dead before the last pass writes that array); aux_b and aux_c must not.
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
-                    uint32_t* val_b, uint32_t* ds_table, uint32_t nchunks, uint32_t* V_out,
-                    const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint2* rect_sorted,
-                    uint32_t* counts_sorted, const uint2* pre_counts, uint32_t pre_nblocks,
-                    uint32_t* count_host_word, uint32_t* count_header_words, hipEvent_t count_event) {
+                    uint32_t* val_b, uint32_t* key_c, uint32_t* val_c, uint32_t* ds_table,
+                    uint32_t nchunks, uint32_t* V_out, const uint32_t* range,
+                    const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint32_t* aux_c,
+                    uint2* rect_sorted, uint32_t* counts_sorted, const uint4* pre_counts,
+                    uint32_t pre_nblocks, bool publish_here, uint32_t* count_host_word,
+                    uint32_t* count_header_words, hipEvent_t count_event) {
   if (P == 0) return;
   const size_t tsz = (size_t)nchunks * DS_RADIX;
   const bool rect = rects_by_id != nullptr;
-#define DS_SCATTER(PASS, KI, VI, KO, VO, AI, AO)                                                 \
+#define DS_SCATTER(PASS, KI, VI, KN, VN, KF, VF, AI, AO)                                         \
   do {                                                                                           \
     const RectPayload rp = {rects_by_id, AI, AO, rect_sorted, counts_sorted};                    \
-    const CountPublish pub = {PASS == 0 ? pre_counts : nullptr, pre_nblocks, count_host_word,    \
-                              count_header_words};                                               \
+    const CountPublish pub = {(PASS == 0 && publish_here) ? pre_counts : nullptr, pre_nblocks,   \
+                              count_host_word, count_header_words};                              \
+    const PassOut on = {KN, VN}, of = {KF, VF};                                                  \
     if (rect)                                                                                    \
       depth_scatter_kernel<PASS, true><<<nchunks, DS_THREADS, 0, s>>>(                           \
-          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp, pub);                    \
+          KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, rp, pub);             \
     else                                                                                         \
       depth_scatter_kernel<PASS, false><<<nchunks, DS_THREADS, 0, s>>>(                          \
-          KI, VI, KO, VO, P, ds_table + PASS * tsz, nchunks, V_out, rp, pub);                    \
+          KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, rp, pub);             \
   } while (0)
-  DS_SCATTER(0, key_a, nullptr, key_b, val_b, nullptr, aux_b);
-  if (pre_counts != nullptr && count_event != nullptr) (void)hipEventRecord(count_event, s);
-  depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 8, ds_table + 1 * tsz);
-  DS_SCATTER(1, key_b, val_b, key_a, val_a, aux_b, aux_a);
-  depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_a, V_out, 16, ds_table + 2 * tsz);
-  DS_SCATTER(2, key_a, val_a, key_b, val_b, aux_a, aux_b);
-  depth_hist_kernel<<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, 24, ds_table + 3 * tsz);
-  DS_SCATTER(3, key_b, val_b, key_a, val_a, aux_b, nullptr);
+  DS_SCATTER(0, key_a, nullptr, key_b, val_b, nullptr, nullptr, nullptr, aux_a);
+  if (publish_here && count_event != nullptr) (void)hipEventRecord(count_event, s);
+  depth_hist_kernel<1><<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, range, ds_table + 1 * tsz);
+  DS_SCATTER(1, key_b, val_b, key_c, val_c, nullptr, nullptr, aux_a, aux_b);
+  depth_hist_kernel<2><<<nchunks, DS_THREADS, 0, s>>>(key_c, V_out, range, ds_table + 2 * tsz);
+  // three passes settle it: c -> a (final).  Otherwise c -> b, and pass 3: b -> a.
+  DS_SCATTER(2, key_c, val_c, key_a, val_a, key_b, val_b, aux_b, aux_c);
+  depth_hist_kernel<3><<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, range, ds_table + 3 * tsz);
+  DS_SCATTER(3, key_b, val_b, key_a, val_a, nullptr, nullptr, aux_c, nullptr);
 #undef DS_SCATTER
 }
 
@@ -571,11 +668,7 @@ bool radix_sort_pairs(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t
   radix_scatter_kernel<CB, IT><<<(nchunks + (IT / RS_ITEMS) - 1) / (IT / RS_ITEMS), RS_THREADS, 0, s>>>( \
       kin, (p == 0 && vals_iota) ? nullptr : vin, kout, vout, n, n_dev, shift, bits, table,   \
       totals, nchunks, p == passes - 1 ? gather_src : nullptr, gather_dst)
-    // GRPG_RS_WIDE=m (experiment): bit p of m set = pass p of a 7-bit tile partition ranks 4096 keys
-    // per workgroup (16 per thread)
-    static const int wide = [] { const char* e = getenv("GRPG_RS_WIDE"); return e ? atoi(e) : 0; }();
-    if (bits == 8) RS_SCATTER(8, 8);        // depth sort
-    else if (bits == 7 && ((wide >> p) & 1)) RS_SCATTER(7, 16);
+    if (bits == 8) RS_SCATTER(8, 8);        // depth sort of very large P
     else if (bits == 7) RS_SCATTER(7, 8);   // tile partition of a 1920x1280 frame (14 bits)
     else RS_SCATTER(0, 8);
 #undef RS_SCATTER
@@ -589,15 +682,11 @@ int radix_sort_num_passes(int begin_bit, int end_bit) {
   const int nbits = end_bit - begin_bit;
   return nbits <= 0 ? 0 : (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
 }
-// Digit width of pass p: the bits are spread evenly over the passes (14 bits -> 7 + 7).
-// GRPG_RADIX_FIRST_BITS=b (experiment): a two-pass sort takes b bits first and the rest second
-// (a narrower first digit on unordered input scatters longer runs).
+// Digit width of pass p: the bits are spread evenly over the passes (14 bits -> 7 + 7; measured
+// against 6 + 8, 8 + 6 and 4096-key workgroups: within noise or worse).
 int radix_pass_bits(int begin_bit, int end_bit, int p) {
   const int passes = radix_sort_num_passes(begin_bit, end_bit);
   const int nbits = end_bit - begin_bit;
-  static const int first = [] { const char* e = getenv("GRPG_RADIX_FIRST_BITS"); return e ? atoi(e) : 0; }();
-  if (passes == 2 && first > 0 && first < nbits && nbits - first <= RS_MAX_BITS && first <= RS_MAX_BITS)
-    return p == 0 ? first : nbits - first;
   int shift = 0;
   int bits = 0;
   for (int q = 0; q <= p; q++) {

@@ -181,9 +181,15 @@ std::tuple<int, int> FrameStatus(const int ticket, const bool wait) {
   return std::make_tuple(0, 0);
 }
 
+// full_intermediates: the reference's binding ALWAYS returns dL_dcolors [P,3] and dL_dcov3D [P,6]
+// (rasterize_points.cu:166-176,219) -- the per-Gaussian colour gradient and the 3D-covariance
+// gradient, real values even when the colours came from SH / the covariance from scale + rotation.
+// _C.rasterize_gaussians_backward (the reference's name) does the same.  The autograd Function
+// never looks at them unless the corresponding optional input was given, so it calls
+// _C.rasterize_gaussians_backward_lean, which does not materialise the unused ones ([0,3] / [0,6]).
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
-RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor& means3D,
+RasterizeGaussiansBackwardImpl(const torch::Tensor& background, const torch::Tensor& means3D,
                            const torch::Tensor& radii, const torch::Tensor& colors,
                            const torch::Tensor& scales, const torch::Tensor& rotations,
                            const float scale_modifier, const torch::Tensor& cov3D_precomp,
@@ -196,7 +202,7 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
                            const torch::Tensor& geomBuffer, const int R,
                            const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
                            const torch::Tensor& alphas, const torch::Tensor& semantics,
-                           const bool debug) {
+                           const bool debug, const bool full_intermediates) {
   require_device(means3D);
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
   const int P = means3D.size(0);
@@ -220,7 +226,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   // (float atomics straight into it) is zero-filled.  Gradients of absent optional inputs
   // (colors_precomp, cov3D_precomp) and the two pure intermediates of the reference's binding
   // (dL_dconic, dL_ddepths) are not materialised at all: the library takes NULL for them.
-  const bool want_colors = colors.numel() != 0, want_cov = cov3D_precomp.numel() != 0;
+  const bool want_colors = full_intermediates || colors.numel() != 0;
+  const bool want_cov = full_intermediates || cov3D_precomp.numel() != 0;
   torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o);
   torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
   torch::Tensor dL_dcolors = torch::empty({want_colors ? P : 0, GRPG_NUM_CHANNELS}, o);
@@ -271,6 +278,31 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
   return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                          dL_dscales, dL_drotations, dL_dsemantic);
 }
+
+#define GRPG_BWD_PARAMS                                                                          \
+  const torch::Tensor &background, const torch::Tensor &means3D, const torch::Tensor &radii,     \
+      const torch::Tensor &colors, const torch::Tensor &scales, const torch::Tensor &rotations,  \
+      const float scale_modifier, const torch::Tensor &cov3D_precomp,                            \
+      const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix, const float tan_fovx,    \
+      const float tan_fovy, const torch::Tensor &dL_dout_color,                                  \
+      const torch::Tensor &dL_dout_depth, const torch::Tensor &dL_dout_alpha,                    \
+      const torch::Tensor &dL_dout_semantic, const torch::Tensor &sh, const int degree,          \
+      const torch::Tensor &campos, const torch::Tensor &geomBuffer, const int R,                 \
+      const torch::Tensor &binningBuffer, const torch::Tensor &imageBuffer,                      \
+      const torch::Tensor &alphas, const torch::Tensor &semantics, const bool debug
+#define GRPG_BWD_ARGS                                                                            \
+  background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,           \
+      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,    \
+      dL_dout_semantic, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,    \
+      semantics, debug
+// the reference's entry point: shapes exactly as rasterize_points.cu:166-176,219
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansBackward(GRPG_BWD_PARAMS) { return RasterizeGaussiansBackwardImpl(GRPG_BWD_ARGS, true); }
+// additive: what the autograd Function calls
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansBackwardLean(GRPG_BWD_PARAMS) { return RasterizeGaussiansBackwardImpl(GRPG_BWD_ARGS, false); }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix,
                           torch::Tensor& projmatrix) {
@@ -756,6 +788,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("frame_status", &FrameStatus, pybind11::arg("ticket"), pybind11::arg("wait") = true);
   m.def("distCUDA2", &distCUDA2);
   m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
+  m.def("rasterize_gaussians_backward_lean", &RasterizeGaussiansBackwardLean);
   m.def("mark_visible", &markVisible);
   m.def("rasterize_gaussians_filter", &RasterizeGaussiansFilter);
   // additions (not in the reference module)

@@ -82,13 +82,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if rs.debug:
             saved = _snapshot(call)
             try:
-                grads = _C.rasterize_gaussians_backward(*call)
+                grads = _C.rasterize_gaussians_backward_lean(*call)
             except Exception:
                 torch.save(saved, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         else:
-            grads = _C.rasterize_gaussians_backward(*call)
+            grads = _C.rasterize_gaussians_backward_lean(*call)
         (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations,
          g_semantics) = grads
         # one gradient per forward input, in forward-argument order (reference :152-163).
@@ -176,6 +176,10 @@ class GaussianRasterizer(nn.Module):
         rs = self.raster_settings
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         shs = _empty() if shs is None else shs
         colors_precomp = _empty() if colors_precomp is None else colors_precomp
         scales = _empty() if scales is None else scales

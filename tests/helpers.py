@@ -77,3 +77,35 @@ def assert_image_close(name, got, ref, fragile=None, atol=ATOL, rtol=RTOL, max_f
     fa = FRAGILE_ATOL if fragile_atol is None else fragile_atol
     assert ((err / scale) * frag[None]).max() <= fa, "%s: fragile px err %.3e (bound %.1e)" % (
         name, ((err / scale) * frag[None]).max(), fa)
+
+
+def gaussians_fed_by_fragile_pixels(o, tile=16):
+    """bool[P]: Gaussians the oracle evaluated at a threshold-FRAGILE pixel with a footprint that
+    passes, or nearly passes, the alpha test there.  At such a pixel an implementation whose exp()
+    differs in the last bits may legitimately take the other branch of one accept / reject decision;
+    that changes this pixel's transmittance for every later splat, i.e. the pixel's share of the
+    gradient of EVERY Gaussian blended there.  Gradient elements of these Gaussians are exempt from
+    the element-wise bar (rtol 1e-3 / atol 1e-5) and are held to the array-level bars only."""
+    frag = np.asarray(o["fragile"], dtype=bool)
+    H, W = frag.shape
+    gx = (W + tile - 1) // tile
+    pl = np.asarray(o["point_list"]).astype(np.int64)
+    rg = np.asarray(o["ranges"]).astype(np.int64).reshape(-1, 2)
+    ncon = np.asarray(o["n_contrib"]).astype(np.int64).reshape(H, W)
+    m2d = np.asarray(o["means2D"], dtype=np.float64)
+    co = np.asarray(o["conic_opacity"], dtype=np.float64)
+    fed = np.zeros(m2d.shape[0], dtype=bool)
+    ys, xs = np.nonzero(frag)
+    for y, x in zip(ys, xs):
+        t = (y // tile) * gx + (x // tile)
+        b, e = rg[t]
+        e = min(e, b + ncon[y, x] + 2)        # + the entries a flipped termination would add
+        if e <= b:
+            continue
+        ids = pl[b:e]
+        dx = m2d[ids, 0] - x
+        dy = m2d[ids, 1] - y
+        power = -0.5 * (co[ids, 0] * dx * dx + co[ids, 2] * dy * dy) - co[ids, 1] * dx * dy
+        alpha = np.minimum(0.99, co[ids, 3] * np.exp(np.minimum(power, 0.0)))
+        fed[ids[(power <= 1e-3) & (alpha >= 0.5 / 255.0)]] = True
+    return fed

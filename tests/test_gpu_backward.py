@@ -3,9 +3,10 @@
 
 The reference sums float atomics in an unspecified order, so gradients are compared with a
 tolerance: per array, relative L2 error <= 1e-3 (measured: 1e-6 .. 6e-4), >= 99.5 % of the elements
-within 2e-3 * max|ref|, and >= 98.5 % of the elements within SURVEY §8(d)'s rtol 1e-3 / atol 1e-5
-(times max|ref|; measured: 98.9 % on the 18 k-entry tiles, >= 99.8 % elsewhere -- the rest are fed by
-threshold-fragile pixels, which may legitimately flip one contribution).
+within 2e-3 * max|ref|, and SURVEY §8(d)'s element-wise bar rtol 1e-3 / atol 1e-5 (times max|ref|)
+for the elements of every Gaussian that no threshold-fragile pixel feeds (a fragile pixel may
+legitimately flip one contribution, which changes that pixel's share of every Gaussian blended
+there: helpers.gaussians_fed_by_fragile_pixels; the exempted share is recorded per array).
 """
 import numpy as np
 import pytest
@@ -13,7 +14,7 @@ import torch
 
 import oracle
 from gaussianrpg_amd import harness as hz
-from helpers import oracle_kwargs
+from helpers import gaussians_fed_by_fragile_pixels, oracle_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +26,18 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995):
+# share of the NON-exempt elements that may still miss the strict element-wise bar: float atomics sum
+# in an order of their own, and an element whose terms cancel (|sum| << sum of |terms|) carries the
+# rounding of the large terms.  Measured on the MI355X over the whole suite (profiles/round4_parity_stats.json).
+STRICT_MISS_FRAC = 2e-4
+
+
+def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995, exempt=None):
+    """Array-level bars for every element: relative L2 <= 1e-3 and >= 99.5 % within 2e-3 max|ref|.
+    SURVEY §8(d) config 5's element-wise bar -- rtol 1e-3 / atol 1e-5 (relative to the array's
+    largest element: the test losses are random planes, not unit-scale) -- for every element of
+    every Gaussian that no threshold-fragile pixel feeds (`exempt`: bool[P], see
+    helpers.gaussians_fed_by_fragile_pixels); the exempted share is recorded."""
     import os
     from helpers import PARITY_STATS
     got = np.asarray(got, np.float64).reshape(ref.shape)
@@ -35,16 +47,23 @@ def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995):
     scale = np.abs(ref).max() + 1e-30
     l2 = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
     ok = (np.abs(got - ref) <= elem_tol * scale).mean()
-    # SURVEY §8(d) config 5 states rtol 1e-3 / atol 1e-5 (atol relative to the array's largest
-    # element here: the test losses are random planes, not unit-scale): recorded for every array,
-    # dumped with the parity statistics at session end
-    strict = (np.abs(got - ref) <= 1e-5 * scale + 1e-3 * np.abs(ref)).mean()
+    within = np.abs(got - ref) <= 1e-5 * scale + 1e-3 * np.abs(ref)
+    strict_all = within.mean()
+    if exempt is None:
+        exempt = np.zeros(ref.shape[0], dtype=bool)
+    keep = ~np.asarray(exempt, dtype=bool)
+    w2 = within.reshape(ref.shape[0], -1)
+    miss = int((~w2[keep]).sum())
+    n_keep = int(w2[keep].size)
     PARITY_STATS.append(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0],
                              plane="grad:" + name, pixels=int(ref.size), rel_l2=float(l2),
-                             frac_within_rtol1e3_atol1e5=float(strict)))
+                             frac_within_rtol1e3_atol1e5=float(strict_all),
+                             exempt_gaussians_frac=float(np.mean(exempt)),
+                             nonexempt_elements=n_keep, nonexempt_beyond_strict=miss))
     assert l2 <= rel_l2 and ok >= frac, "%s: relL2 %.3e, within-tol fraction %.5f" % (name, l2, ok)
-    # the strict element-wise bar holds for all but the elements a threshold-fragile pixel feeds
-    assert strict >= 0.985, "%s: only %.4f of the elements within rtol 1e-3 / atol 1e-5 max|ref|" % (name, strict)
+    assert miss <= STRICT_MISS_FRAC * n_keep + 1, (
+        "%s: %d of %d elements of Gaussians no fragile pixel feeds miss rtol 1e-3 / atol 1e-5 max|ref| "
+        "(%.2e; exempt Gaussians: %.3f)" % (name, miss, n_keep, miss / max(n_keep, 1), float(np.mean(exempt))))
 
 
 def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0):
@@ -69,6 +88,7 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0):
                        rotations=None if use_cov else sc.rotations, cov3D_precomp=cov,
                        semantics=sem, **okw)
     ref = oracle.backward(o, gc, gd, ga, gs)
+    fed = gaussians_fed_by_fragile_pixels(o)
 
     camd = hz.CameraTensors(H, W, cam.tanfovx, cam.tanfovy, cam.viewmatrix.to(dev),
                             cam.projmatrix.to(dev), cam.campos.to(dev))
@@ -91,22 +111,22 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0):
         loss = loss + (semantic * gs.to(dev)).sum()
     loss.backward()
     torch.cuda.synchronize()
-    _grad_close("dL_dmeans3D", means.grad.cpu(), ref["dL_dmeans3D"])
-    _grad_close("dL_dmeans2D", means2D.grad.cpu(), ref["dL_dmeans2D"])
-    _grad_close("dL_dopacity", opac.grad.cpu(), ref["dL_dopacity"])
+    _grad_close("dL_dmeans3D", means.grad.cpu(), ref["dL_dmeans3D"], exempt=fed)
+    _grad_close("dL_dmeans2D", means2D.grad.cpu(), ref["dL_dmeans2D"], exempt=fed)
+    _grad_close("dL_dopacity", opac.grad.cpu(), ref["dL_dopacity"], exempt=fed)
     if use_colors:
-        _grad_close("dL_dcolors", col.grad.cpu(), ref["dL_dcolors"])
+        _grad_close("dL_dcolors", col.grad.cpu(), ref["dL_dcolors"], exempt=fed)
     else:
-        _grad_close("dL_dsh", shs.grad.cpu(), ref["dL_dsh"])
+        _grad_close("dL_dsh", shs.grad.cpu(), ref["dL_dsh"], exempt=fed)
         nact = (sc.sh_degree + 1) ** 2
         assert float(shs.grad[:, nact:].abs().max() if shs.shape[1] > nact else 0.0) == 0.0
     if use_cov:
-        _grad_close("dL_dcov3D", covd.grad.cpu(), ref["dL_dcov3D"])
+        _grad_close("dL_dcov3D", covd.grad.cpu(), ref["dL_dcov3D"], exempt=fed)
     else:
-        _grad_close("dL_dscales", scales.grad.cpu(), ref["dL_dscales"])
-        _grad_close("dL_drotations", rots.grad.cpu(), ref["dL_drotations"])
+        _grad_close("dL_dscales", scales.grad.cpu(), ref["dL_dscales"], exempt=fed)
+        _grad_close("dL_drotations", rots.grad.cpu(), ref["dL_drotations"], exempt=fed)
     if S:
-        _grad_close("dL_dsemantic", semd.grad.cpu(), ref["dL_dsemantic"])
+        _grad_close("dL_dsemantic", semd.grad.cpu(), ref["dL_dsemantic"], exempt=fed)
     # densification statistic: z = sum |dx|+|dy| must be >= |x|,|y| sums (backward.cu:627-628)
     m2 = means2D.grad
     assert bool((m2[:, 2] + 1e-6 >= m2[:, 0].abs()).all())
@@ -305,9 +325,13 @@ def test_backward_matches_committed_golden(dev):
         means3D=leaves["means3D"], means2D=None, opacities=leaves["opacity"], shs=leaves["shs"],
         scales=leaves["scales"], rotations=leaves["rotations"])
     ((color * t("grad_color")).sum() + (depth * t("grad_depth")).sum() + (alpha * t("grad_alpha")).sum()).backward()
+    from helpers import fixture_oracle_inputs
+    fed = gaussians_fed_by_fragile_pixels(oracle.forward(
+        fx["means3D"], fx["opacity"], shs=fx["shs"], scales=fx["scales"], rotations=fx["rotations"],
+        **fixture_oracle_inputs(fx)))
     for k, r in (("means3D", "dL_dmeans3D"), ("opacity", "dL_dopacity"), ("shs", "dL_dsh"),
                  ("scales", "dL_dscales"), ("rotations", "dL_drotations")):
-        _grad_close(r, leaves[k].grad.cpu(), fx[r])
+        _grad_close(r, leaves[k].grad.cpu(), fx[r], exempt=fed)
 
 
 def test_toy_fit_psnr_parity(dev):

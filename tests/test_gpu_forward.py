@@ -226,6 +226,60 @@ def test_equal_depth_ties_keep_id_order(dev):
     _check(_rasterize(dev, dup, cam), o, max_fragile_frac=0.2)
 
 
+def test_depth_range_beyond_27_bits_takes_the_fourth_sort_pass(dev):
+    """The depth sort orders key - key_base in three 9-bit passes when the visible depth keys span
+    less than 2^27 values (farthest / nearest depth below ~65 000) and adds a fourth pass on the device
+    otherwise (csrc/sort.hip).  Depths from 0.21 to 2e6 need it; the same cloud pushed away to
+    1000 .. 2e6 does not; a scene in millimetres (every depth beyond 13 km in key units of a metre
+    scene) does not either.  Order and everything downstream must equal the oracle's full 32-bit
+    key order (rasterizer_impl.cu:303-311) bit for bit in all three."""
+    g = torch.Generator().manual_seed(77)
+    base = hz.toy_scene(4000, seed=31, sh_degree=1, depth=6.0, spread=2.0)
+    P = base.means3D.shape[0]
+
+    def stretched(zmin, zmax):
+        # log-uniform depths: every exponent between zmin and zmax is populated; lateral position and
+        # scale grow with the depth so that the far ones stay visible
+        z = torch.exp(torch.rand(P, generator=g) * (np.log(zmax) - np.log(zmin)) + np.log(zmin))
+        m = base.means3D.clone()
+        m[:, 0] = (torch.rand(P, generator=g) - 0.5) * 0.6 * z
+        m[:, 1] = (torch.rand(P, generator=g) - 0.5) * 0.4 * z
+        m[:, 2] = z
+        sc = base.scales * (z[:, None] / 6.0)
+        return hz.Scene(m, base.opacity, sc, base.rotations, base.shs, 1)
+
+    cam = hz.trajectory_camera(0, W=160, H=96)
+    for zmin, zmax, far in ((0.21, 2.0e6, True), (1000.0, 2.0e6, False), (3.0e4, 9.0e5, False)):
+        sc = stretched(zmin, zmax)
+        o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                           **oracle_kwargs(cam, 1))
+        keys = o["depths"][o["radii"] > 0].view(np.uint32)
+        span = int(keys.max()) - (int(keys.min()) & ~0x3FFFF)
+        assert (span >= 1 << 27) == far, (zmin, zmax, span)
+        assert (o["radii"] > 0).sum() > 1000
+        _check(_rasterize(dev, sc, cam), o, max_fragile_frac=0.2)
+
+
+def test_more_than_4M_gaussians_take_the_classic_sort_passes(dev):
+    """P > 512 x 8192 = 4 194 304: the fat depth sort's per-workgroup table sweep would grow
+    quadratically, so the depth sort runs as classic histogram / digit-scan / scatter passes over the
+    full 32-bit keys (culled Gaussians sort last), the counts are published by their own launch and
+    binning falls back to emit + partition.  Small splats on a small image keep the oracle cheap."""
+    P = 4_250_000
+    g = torch.Generator().manual_seed(5)
+    means = torch.randn(P, 3, generator=g) * torch.tensor([6.0, 4.0, 3.0])
+    means[:, 2] += 7.0
+    scales = torch.exp(np.log(0.004) + 0.3 * torch.randn(P, 3, generator=g))
+    q = torch.randn(P, 4, generator=g)
+    sc = hz.Scene(means, torch.sigmoid(torch.randn(P, 1, generator=g)), scales,
+                  q / q.norm(dim=1, keepdim=True), torch.rand(P, 1, 3, generator=g), 0)
+    cam = hz.trajectory_camera(0, W=320, H=208)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, 0))
+    assert (o["radii"] == 0).sum() > 100_000 and (o["radii"] > 0).sum() > 500_000
+    _check(_rasterize(dev, sc, cam), o, max_fragile_frac=0.2)
+
+
 def test_mark_visible_and_filter(dev):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     sc, cam = hz.street_scene(30000, seed=21), hz.trajectory_camera(4, W=480, H=320)
@@ -381,22 +435,20 @@ def test_streams_and_threads_give_identical_frames(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"GRPG_RENDER_PC": "0"}, {"GRPG_PC_MUL": "1"},
                                  {"GRPG_RENDER_VARIANT": "1", "GRPG_HEAVY_MIN": "64"},
-                                 {"GRPG_DEPTH_SORT": "classic"}, {"GRPG_SYNC_R": "1"},
+                                 {"GRPG_SYNC_R": "1"},
                                  {"GRPG_RCAP_TEST": "3000"}, {"GRPG_RCAP_TEST": "3000:3000000"},
                                  {"GRPG_BINNING": "sort"},
-                                 {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"},
-                                 {"GRPG_SORT_RECT": "0"}, {"GRPG_PUBLISH_FOLD": "0"}])
+                                 {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"}])
 def test_alternative_code_paths(env):
     """The experiment switches are read once per process, so the parity cases are re-run in a
     subprocess: no producer/consumer pairs; pairs for EVERY heavy tile; light path with one splat
-    per iteration and a low heavy threshold; the classic three-kernel depth-sort passes; the
+    per iteration and a low heavy threshold; the
     reference-like mid-frame wait for num_rendered (exact binning-blob size); a binning capacity
     guess of 3000 instances, so that every frame overflows it and re-runs its tail (hierarchical
     binning: first with the coarse list overflowing too, then with only the point list); the sort-based
-    binning (emit + stable partition) instead of the hierarchical one, also with overflows; the
-    coarse scan gathering the tile rectangles by sorted id instead of receiving them from the depth
-    sort (the path of grids beyond 255 x 255 tiles); num_rendered published by its own launch behind
-    preprocess instead of by the depth sort's first pass."""
+    binning (emit + stable partition) instead of the hierarchical one, also with overflows.  (The
+    classic depth-sort passes with their separate count publish, and the coarse scan's rectangle
+    gather, are reached by inputs: test_more_than_4M_gaussians_..., test_grid_wider_than_255_tiles.)"""
     import os
     import subprocess
     import sys
