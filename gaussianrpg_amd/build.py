@@ -127,6 +127,11 @@ VARIANTS = {
     # (render_fwd.hip pc_fail, tests/test_gpu_pc_timeout.py)
     "pcspin0": {"render_fwd.hip": ["-DGRPG_PC_SPIN_LIMIT=0"]},
 }
+# experiment builds (not built by build_all): python -c "from gaussianrpg_amd import build; build.build_variant('dstrace')"
+EXPERIMENT_VARIANTS = {
+    # phase timestamps of the depth sort's scatter passes (tools/ds_trace.py)
+    "dstrace": {"sort.hip": ["-DGRPG_DS_TRACE"]},
+}
 
 
 def variant_path(name):
@@ -138,6 +143,7 @@ def build_variant(name, force=False):
     units VARIANTS[name] lists, which are recompiled with the extra flags."""
     build_native()
     hipcc = _hipcc()
+    spec = VARIANTS.get(name) or EXPERIMENT_VARIANTS[name]
     out = variant_path(name)
     vobj = os.path.join(ROOT, "build", "obj_" + name)
     os.makedirs(vobj, exist_ok=True)
@@ -145,7 +151,7 @@ def build_variant(name, force=False):
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for unit, extra in HIP_UNITS.items():
-        if unit not in VARIANTS[name]:
+        if unit not in spec:
             objs.append(os.path.join(OBJ, unit.replace(".hip", ".o")))
             continue
         src = os.path.join(CSRC, unit)
@@ -153,7 +159,7 @@ def build_variant(name, force=False):
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
             _run([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                  "-Wall", "-Wno-unused-function"] + extra + VARIANTS[name][unit] + ["-c", src, "-o", obj])
+                  "-Wall", "-Wno-unused-function"] + extra + spec[unit] + ["-c", src, "-o", obj])
     if force or _newer(out, objs):
         _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs +
              ["-Wl,--enable-new-dtags", "-Wl,-rpath,/opt/rocm/lib"])

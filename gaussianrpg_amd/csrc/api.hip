@@ -73,6 +73,7 @@ struct DeferSlot {
   int result = 0;           // resolved: num_rendered or GRPG_ERR_CAPACITY
   uint32_t Rcap = 0, Ccap = 0;
   bool hier = false;
+  bool with_pass3 = true;   // the frame was enqueued with the fourth depth-sort pass
   CapKey key{-1, 0, 0, 0};
   int generation = 0;       // ticket = generation * DEFER_SLOTS + slot: a recycled slot's old tickets expire
 };
@@ -96,6 +97,7 @@ struct CapHint {
   CapKey key{-1, 0, 0, 0};
   uint32_t high = 0;      // decaying high-water mark of num_rendered
   uint32_t high_c = 0;    // same for the coarse (Gaussian, super-tile) count of the hierarchical binning
+  bool far = true;        // the last frame's depth keys needed the fourth sort pass (sort.hip key_far)
   uint64_t stamp = 0;     // last use (LRU replacement)
   bool valid = false;
 };
@@ -116,7 +118,8 @@ uint32_t padded_capacity(uint32_t r) {
   const uint64_t c = ((uint64_t)r + r / 4 + 65536 + 65535) / 65536 * 65536;
   return (uint32_t)(c > 0x7FFF0000ull ? 0x7FFF0000ull : c);
 }
-uint32_t capacity_from_hint(const CapKey& k, uint32_t* coarse_cap) {
+uint32_t capacity_from_hint(const CapKey& k, uint32_t* coarse_cap, bool* far) {
+  *far = true;   // no history: enqueue the (normally idle) fourth depth-sort pass
   // test hook "R" or "R:Rc": forced capacities, to exercise the overflow / redo paths
   static const char* forced_env = getenv("GRPG_RCAP_TEST");
   if (forced_env) {
@@ -132,12 +135,13 @@ uint32_t capacity_from_hint(const CapKey& k, uint32_t* coarse_cap) {
       const uint32_t cap = padded_capacity(h.high);
       const uint32_t cc = h.high_c ? padded_capacity(h.high_c) : cap;
       *coarse_cap = cc < cap ? cc : cap;     // a (Gaussian, super-tile) pair holds >= 1 instance
+      *far = h.far;
       return cap;
     }
   *coarse_cap = 0u;
   return 0u;
 }
-void update_hint(const CapKey& k, uint32_t R, uint32_t Rc) {
+void update_hint(const CapKey& k, uint32_t R, uint32_t Rc, bool far) {
   std::lock_guard<std::mutex> lk(g_hint_mu);
   CapHint* slot = nullptr;
   for (auto& h : g_hints)
@@ -158,6 +162,7 @@ void update_hint(const CapKey& k, uint32_t R, uint32_t Rc) {
   const uint32_t dc = slot->high_c - slot->high_c / 64;
   slot->high_c = Rc > dc ? Rc : dc;
   if (slot->high_c > slot->high) slot->high_c = slot->high;
+  slot->far = far;
   slot->stamp = ++g_hint_clock;
 }
 
@@ -471,7 +476,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                  float tan_fovx, float tan_fovy, float* out_color,
                  float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
                  void* hip_stream, const grpg_model_segment* segs, int nseg, unsigned flags = 0u,
-                 DeferSlot* defer = nullptr) {
+                 DeferSlot* defer = nullptr, bool force_pass3 = false) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
@@ -557,8 +562,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     };
     const CapKey ck = {dev, P, width, height};
     uint32_t Ccap = 0u;
-    uint32_t Rcap = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? capacity_from_hint(ck, &Ccap) : 0u;
+    bool hint_far = true;
+    uint32_t Rcap = g_binning_mode.load() == GRPG_BINNING_SPECULATIVE ? capacity_from_hint(ck, &Ccap, &hint_far) : 0u;
     const bool speculative = Rcap != 0u;
+    // Fourth pass of the depth sort (sort.hip): needed when the visible depth keys span >= 2^27
+    // values -- a property of the scene's scale that does not change from frame to frame.  Its two
+    // launches are only enqueued when the previous frame of this shape needed them (or nothing is
+    // known yet); a frame that turns out to need them without having them is rendered again.
+    const bool with_pass3 = force_pass3 || !speculative || hint_far;
     char* bin = nullptr;
     BinLayout BL{};
     if (speculative) {
@@ -629,12 +640,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       uint32_t* val_c = (uint32_t*)(geom + GL.val_c);
       if (rect_sorted_by_sort)   // scratch: rect_sorted's own first half, the not yet written offsets, aux_c
         depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, key_c, val_c, ds_table,
-                       GL.nchunks_ds, &gh->V, &gh->key_base, rects, (uint32_t*)rect_sorted, offsets,
+                       GL.nchunks_ds, &gh->V, &gh->key_base, with_pass3,
+                       rects, (uint32_t*)rect_sorted, offsets,
                        (uint32_t*)(geom + GL.aux_c), rect_sorted, tiles_sorted, pre_counts, pnb, true,
                        pub_ptr, &gh->R_pre, pub_ev);
       else
         depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, key_c, val_c, ds_table,
-                       GL.nchunks_ds, &gh->V, &gh->key_base, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       GL.nchunks_ds, &gh->V, &gh->key_base, with_pass3,
+                       nullptr, nullptr, nullptr, nullptr, nullptr,
                        nullptr, pre_counts, pnb, true, pub_ptr, &gh->R_pre, pub_ev);
       sorted_gid = val_a;
     } else {          // culled keys sort last (tile count 0); V stays P
@@ -798,6 +811,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
         // deferred frame: the count is checked by grpg_frame_status, nothing to wait for here
         defer->state = 1;
         defer->Rcap = Rcap; defer->Ccap = Ccap; defer->hier = hier; defer->key = ck;
+        defer->with_pass3 = with_pass3 || !fat_sort;
         tm.finish();
         return 0;
       }
@@ -805,7 +819,18 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipEventSynchronize(pub_ev));
     R = (defer ? defer->host_ptr : hw->host_ptr)[0];
     if (hier) Rc_seen = (defer ? defer->host_ptr : hw->host_ptr)[1];
+    const bool far_seen = fat_sort && (defer ? defer->host_ptr : hw->host_ptr)[2] != 0u;
     if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
+    if (far_seen && !with_pass3) {
+      // the scene's depth range grew beyond what three sort passes order: this frame's lists are in
+      // the wrong order.  Remember it and render the frame again, this time with the fourth pass.
+      update_hint(ck, R, Rc_seen, true);
+      return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user,
+                          P, D, M, S, background, width, height, means3D, shs, colors_precomp, semantics,
+                          opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                          cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, out_semantic, radii,
+                          debug, hip_stream, segs, nseg, flags, defer, true);
+    }
     if (!speculative || R > Rcap || (hier && Rc_seen > Ccap)) {
       // first frame of a shape / exact mode: carve for the count just read.  Capacity overflow: the
       // speculative tail clamped its work to the old capacities and its results are discarded; both
@@ -825,7 +850,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       if (int rc = run_tail()) return rc;
     }
     if (R > 0x7FFFFFFFu) return fail(GRPG_ERR_INVALID_ARGUMENT, "num_rendered exceeds int32");
-    update_hint(ck, R, Rc_seen);
+    update_hint(ck, R, Rc_seen, far_seen);
     tm.finish();
     if (defer) { defer->state = 2; defer->result = (int)R; }   // no capacity history: ran synchronously
   } else {
@@ -858,9 +883,11 @@ int defer_resolve(DeferSlot& d, bool wait) {
     if (q != hipSuccess) return fail(GRPG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
   }
   const uint32_t R = d.host_ptr[0], Rc = d.hier ? d.host_ptr[1] : 0u;
-  // a clamped coarse list undercounts R; either overflow invalidates the frame's outputs
-  const bool ok = R <= d.Rcap && (!d.hier || Rc <= d.Ccap) && R <= 0x7FFFFFFFu;
-  update_hint(d.key, R > Rc ? R : Rc, Rc);   // (an undercounted R is at least the coarse count)
+  const bool far = d.host_ptr[2] != 0u;
+  // a clamped coarse list undercounts R; either overflow invalidates the frame's outputs -- and so
+  // does a depth range that needed the fourth sort pass the frame was enqueued without
+  const bool ok = R <= d.Rcap && (!d.hier || Rc <= d.Ccap) && R <= 0x7FFFFFFFu && (!far || d.with_pass3);
+  update_hint(d.key, R > Rc ? R : Rc, Rc, far);   // (an undercounted R is at least the coarse count)
   d.state = 2;
   d.result = ok ? (int)R : GRPG_ERR_CAPACITY;
   return d.result;
@@ -886,7 +913,7 @@ DeferSlot* defer_acquire(int* ticket) {
     if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     d.dev = dev;
   }
-  d.host_ptr[0] = 0u; d.host_ptr[1] = 0u;
+  d.host_ptr[0] = 0u; d.host_ptr[1] = 0u; d.host_ptr[2] = 0u;
   d.state = 0; d.result = 0;
   d.generation = (d.generation + 1) & 0xFFFFF;
   *ticket = d.generation * DEFER_SLOTS + idx;

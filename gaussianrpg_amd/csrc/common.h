@@ -16,6 +16,9 @@ constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;  // depth key of a culled Gaussian 
 // A point-list entry is  (sub-tile mask << 28) | Gaussian id.  Bit 28+w is set when the splat can
 // reach the w-th 16x4 quarter of its tile (conservative rectangle cull evaluated once at emit
 // time, binning.hip); render reads the bit before it touches the 48-byte record.  Hence P < 2^28.
+// (8x8 squares instead of 16x4 strips were built and measured in round 4 -- tools/experiments/
+// subtile_8x8.patch, DESIGN.md section 5: 4 % fewer survivors in the forward, but the point-list fill
+// and the backward lose more than the forward render gains.)
 constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
 constexpr int SUBTILE_SHIFT = 28;
 
@@ -346,6 +349,7 @@ int radix_sort_first_pass_bits(int begin_bit, int end_bit);
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
                     uint32_t* val_b, uint32_t* key_c, uint32_t* val_c, uint32_t* ds_table,
                     uint32_t nchunks, uint32_t* V_out, const uint32_t* range /* header: key_base, key_far */,
+                    bool with_pass3 /* enqueue the (normally idle) fourth pass */,
                     // hierarchical binning: the rectangles ride along (all NULL otherwise)
                     const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint32_t* aux_c,
                     uint2* rect_sorted, uint32_t* counts_sorted,

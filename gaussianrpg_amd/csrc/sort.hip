@@ -341,7 +341,7 @@ __device__ __forceinline__ uint2 rect_unpack(const uint32_t p) {
 struct CountPublish {
   const uint4* pre_counts;   // per preprocess workgroup: instances, coarse pairs, min key, max key
   uint32_t nblocks;
-  uint32_t* host_word;       // pinned, device-mapped: [0] num_rendered, [1] coarse pairs (may be NULL)
+  uint32_t* host_word;       // pinned, device-mapped: [0] num_rendered, [1] coarse pairs, [2] key_far (may be NULL)
   uint32_t* header_words;    // geometry header: R_pre, Rc_pre, key_base, key_far
 };
 
@@ -384,7 +384,10 @@ __device__ __forceinline__ void publish_frame_counts(const CountPublish pub) {
       pub.header_words[0] = r32; pub.header_words[1] = c32;
       pub.header_words[2] = kbase; pub.header_words[3] = kfar;
     }
-    if (pub.host_word) { pub.host_word[0] = r32; pub.host_word[1] = c32; __threadfence_system(); }
+    if (pub.host_word) {
+      pub.host_word[0] = r32; pub.host_word[1] = c32; pub.host_word[2] = kfar;
+      __threadfence_system();
+    }
   }
 }
 
@@ -404,14 +407,25 @@ struct PassOut {
   uint32_t* vals;
 };
 
+#ifdef GRPG_DS_TRACE   // experiment build (tools/gpu_ds_trace.sh): phase timestamps of a few workgroups
+__device__ unsigned long long g_ds_trace[4][4][10];   // [pass][probe workgroup][phase]
+#define DS_TRACE(PH)                                                                             \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 50 || blockIdx.x == 120 || blockIdx.x == 170)) \
+      g_ds_trace[PASS][blockIdx.x == 0 ? 0 : (blockIdx.x == 50 ? 1 : (blockIdx.x == 120 ? 2 : 3))][PH] = wall_clock64(); \
+  } while (0)
+#else
+#define DS_TRACE(PH) do {} while (0)
+#endif
+
 template <int PASS, bool RECT>
 __global__ void __launch_bounds__(DS_THREADS)
 depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      const PassOut out_near, const PassOut out_far,
                      const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][DS_RADIX] */,
                      const uint32_t nchunks, uint32_t* __restrict__ V_out,
-                     const uint32_t* __restrict__ range /* key_base, key_far */, const RectPayload rp,
-                     const CountPublish pub) {
+                     const uint32_t* __restrict__ range /* key_base, key_far */, const int allow_far,
+                     const RectPayload rp, const CountPublish pub) {
   // keys | values | payload staged for the coalesced run writes; the per-wave partial column sums
   // of the table sweep live in the first two thirds until the keys are staged
   __shared__ uint32_t s_buf[(RECT ? 3 : 2) * DS_CHUNK];
@@ -428,7 +442,11 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t chunk = blockIdx.x;
-  const uint32_t far = PASS >= 2 ? range[1] : 0u;
+  DS_TRACE(0);
+  // allow_far == 0: the host enqueued no fourth pass behind pass 2 (the previous frames of this shape
+  // did not need one); should THIS frame need it, its order is wrong and the host, which sees key_far
+  // next to num_rendered, renders the frame again with the fourth pass (api.hip)
+  const uint32_t far = (PASS >= 2 && allow_far) ? range[1] : 0u;
   if (PASS == 3 && far == 0u) return;   // pass 2 was the last one
   const uint32_t kb = PASS >= 2 ? range[0] : 0u;
   const bool last = PASS == 3 || (PASS == 2 && far == 0u);
@@ -444,6 +462,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   const uint32_t chunk_n = chunk_base < n_in ? min((uint32_t)DS_CHUNK, n_in - chunk_base) : 0u;
   if (PASS > 0 && chunk_n == 0u) return;   // a chunk beyond the data (pass 0: chunk 0 still owes V)
   uint32_t key[DS_ITEMS], val[DS_ITEMS], rnk[DS_ITEMS], aux[RECT ? DS_ITEMS : 1];
+  uint2 rraw[(RECT && PASS == 0) ? DS_ITEMS : 1];   // pass 0: packed only when staged (nothing waits for the loads here)
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
     const uint32_t local = wave * (DS_ITEMS * 64) + i * 64 + lane;
@@ -451,13 +470,20 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const bool inb = local < chunk_n;
     key[i] = inb ? keys_in[idx] : CULLED_KEY;
     val[i] = PASS == 0 ? idx : (inb ? vals_in[idx] : 0u);
-    if (RECT)   // a culled Gaussian's rectangle was never written: loaded, never used
-      aux[i] = !inb ? 0u : (PASS == 0 ? rect_pack(rp.rects_by_id[idx]) : rp.aux_in[idx]);
+    if (RECT) {   // a culled Gaussian's rectangle was never written: loaded, never used
+      if (PASS == 0) rraw[i] = inb ? rp.rects_by_id[idx] : make_uint2(0u, 0u);
+      else aux[i] = inb ? rp.aux_in[idx] : 0u;
+    }
   }
 
+  DS_TRACE(1);
   // ---- sweep the count table: per digit, sum over earlier chunks and over all chunks ----
   // A wave reads whole 2 KB rows (lane l: digits 8l..8l+7, two 16-byte loads); wave w owns rows
   // w, w+16, ...; 8 rows (16 loads) are in flight per wave: 245 rows cost two round trips.
+  // (Measured: group rows -- the chunk rows of 16 chunks summed, so that a workgroup sweeps 31
+  // instead of 245 rows -- save 3.5 us per pass, but producing them costs far more: +21 us in
+  // preprocess for the second atomic per digit, +60 us per histogram launch for the release / acquire
+  // fences of a last-arriver reduction (an agent-scope fence writes back and invalidates the XCD's L2).)
   {
     const uint4* t4 = reinterpret_cast<const uint4*>(table);
     uint4 exa = make_uint4(0u, 0u, 0u, 0u), exb = exa, tota = exa, totb = exa;
@@ -487,9 +513,11 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     reinterpret_cast<uint4*>(s_ptot + wave * DS_RADIX)[2 * lane] = tota;
     reinterpret_cast<uint4*>(s_ptot + wave * DS_RADIX)[2 * lane + 1] = totb;
   }
+  DS_TRACE(2);
 #pragma unroll
   for (int k = 0; k < (DS_RADIX * DS_WAVES) / DS_THREADS; k++) s_cnt[k * DS_THREADS + tid] = 0;
   __syncthreads();
+  DS_TRACE(3);
   uint32_t dex = 0, dtot = 0, inc = 0;
   if (tid < DS_RADIX) {
 #pragma unroll
@@ -510,6 +538,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   if (PASS == 0 && chunk == 0 && tid == 0) *V_out = n_all;
   if (chunk_n == 0u) return;   // whole workgroup (pass 0: a chunk beyond the data)
 
+  DS_TRACE(4);
   // ---- rank (wave w owns the 512 consecutive keys [512 w, 512 w + 512)) ----
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -531,7 +560,9 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     rnk[i] = valid ? prev + before : 0xFFFFFFFFu;
     if (valid && before == 0) s_cnt[wave * DS_RADIX + d] = prev + (uint32_t)__popcll(peers);
   }
+  DS_TRACE(5);
   __syncthreads();
+  DS_TRACE(6);
 
   // ---- thread d < DS_RADIX owns digit d: local start slots of its 16 (digit, wave) runs ----
   uint32_t c[DS_WAVES], dsum = 0, inc2 = 0;
@@ -563,10 +594,11 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       const uint32_t slot = s_cnt[wave * DS_RADIX + d] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
-      if (RECT) s_aux[slot] = aux[i];
+      if (RECT) s_aux[slot] = PASS == 0 ? rect_pack(rraw[i]) : aux[i];
     }
   }
   __syncthreads();
+  DS_TRACE(7);
 
   // ---- coalesced run writes ----
 #pragma unroll
@@ -588,31 +620,34 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       }
     }
   }
+  DS_TRACE(8);
 }
 
 // Depth sort of the P (key, id) pairs; ids are implicit in pass 0.  Result: (key_a, val_a) hold
 // the V visible pairs in (depth_bits, id) order, *V_out = V (the per-Gaussian tile counts are
 // brought into sorted order by the offsets scan's reduce launch -- or, with the rectangle payload
 // below, arrive in sorted order with the last pass).  Table 0 of ds_table must hold preprocess'
-// pass-0 counts; pre_counts its per-workgroup (instances, coarse pairs, min key, max key); `range`
-// = the geometry header's (key_base, key_far) words, written by pass 0 when publish_here, by
-// launch_publish_counts before this call otherwise.  key_a (the raw keys by id) is consumed;
-// (key_b, val_b) and (key_c, val_c) are scratch.  7 launches, the last two of which exit at once
-// unless the depth range needs the fourth pass.
+// pass-0 counts; pre_counts = preprocess'
+// per-workgroup (instances, coarse pairs, min key, max key); `range` = the geometry header's
+// (key_base, key_far) words, written by pass 0 when publish_here, by launch_publish_counts before
+// this call otherwise.  key_a (the raw keys by id) is consumed; (key_b, val_b) and (key_c, val_c) are
+// scratch.  5 launches; with_pass3: two more, which exit at once unless the frame's depth range
+// needs the fourth pass.  !with_pass3 and key_far != 0 (the host learns it with num_rendered): the
+// order is wrong, the caller renders the frame again with_pass3.
 // rects_by_id != NULL (hierarchical binning, grid <= 255 x 255 tiles): the tile rectangles ride along
 // (RectPayload above); aux_a / aux_b / aux_c are scratch arrays of P words, rect_sorted [P] and
 // counts_sorted [P] receive the rectangles and super-tile counts in depth order.  aux_a may alias
 // rect_sorted (it is dead before the last pass writes that array); aux_b and aux_c must not.
 void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a, uint32_t* key_b,
                     uint32_t* val_b, uint32_t* key_c, uint32_t* val_c, uint32_t* ds_table,
-                    uint32_t nchunks, uint32_t* V_out, const uint32_t* range,
-                    const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b, uint32_t* aux_c,
-                    uint2* rect_sorted, uint32_t* counts_sorted, const uint4* pre_counts,
-                    uint32_t pre_nblocks, bool publish_here, uint32_t* count_host_word,
-                    uint32_t* count_header_words, hipEvent_t count_event) {
+                    uint32_t nchunks, uint32_t* V_out, const uint32_t* range, bool with_pass3, const uint2* rects_by_id, uint32_t* aux_a, uint32_t* aux_b,
+                    uint32_t* aux_c, uint2* rect_sorted, uint32_t* counts_sorted,
+                    const uint4* pre_counts, uint32_t pre_nblocks, bool publish_here,
+                    uint32_t* count_host_word, uint32_t* count_header_words, hipEvent_t count_event) {
   if (P == 0) return;
   const size_t tsz = (size_t)nchunks * DS_RADIX;
   const bool rect = rects_by_id != nullptr;
+  const int allow_far = with_pass3 ? 1 : 0;
 #define DS_SCATTER(PASS, KI, VI, KN, VN, KF, VF, AI, AO)                                         \
   do {                                                                                           \
     const RectPayload rp = {rects_by_id, AI, AO, rect_sorted, counts_sorted};                    \
@@ -621,22 +656,35 @@ void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a,
     const PassOut on = {KN, VN}, of = {KF, VF};                                                  \
     if (rect)                                                                                    \
       depth_scatter_kernel<PASS, true><<<nchunks, DS_THREADS, 0, s>>>(                           \
-          KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, rp, pub);             \
+          KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, allow_far, rp, pub);  \
     else                                                                                         \
       depth_scatter_kernel<PASS, false><<<nchunks, DS_THREADS, 0, s>>>(                          \
-          KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, rp, pub);             \
+          KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, allow_far, rp, pub);  \
   } while (0)
+#define DS_HIST(PASS, K)                                                                         \
+  depth_hist_kernel<PASS><<<nchunks, DS_THREADS, 0, s>>>(K, V_out, range, ds_table + PASS * tsz)
   DS_SCATTER(0, key_a, nullptr, key_b, val_b, nullptr, nullptr, nullptr, aux_a);
   if (publish_here && count_event != nullptr) (void)hipEventRecord(count_event, s);
-  depth_hist_kernel<1><<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, range, ds_table + 1 * tsz);
+  DS_HIST(1, key_b);
   DS_SCATTER(1, key_b, val_b, key_c, val_c, nullptr, nullptr, aux_a, aux_b);
-  depth_hist_kernel<2><<<nchunks, DS_THREADS, 0, s>>>(key_c, V_out, range, ds_table + 2 * tsz);
+  DS_HIST(2, key_c);
   // three passes settle it: c -> a (final).  Otherwise c -> b, and pass 3: b -> a.
   DS_SCATTER(2, key_c, val_c, key_a, val_a, key_b, val_b, aux_b, aux_c);
-  depth_hist_kernel<3><<<nchunks, DS_THREADS, 0, s>>>(key_b, V_out, range, ds_table + 3 * tsz);
-  DS_SCATTER(3, key_b, val_b, key_a, val_a, nullptr, nullptr, aux_c, nullptr);
+  if (with_pass3) {   // both launches exit at once when key_far == 0
+    DS_HIST(3, key_b);
+    DS_SCATTER(3, key_b, val_b, key_a, val_a, nullptr, nullptr, aux_c, nullptr);
+  }
+#undef DS_HIST
 #undef DS_SCATTER
 }
+
+#ifdef GRPG_DS_TRACE
+}  // namespace grpg
+extern "C" __attribute__((visibility("default"))) int grpg_debug_ds_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grpg::g_ds_trace), sizeof(grpg::g_ds_trace));
+}
+namespace grpg {
+#endif
 
 int radix_pass_bits(int begin_bit, int end_bit, int p);
 

@@ -249,7 +249,15 @@ def test_depth_range_beyond_27_bits_takes_the_fourth_sort_pass(dev):
         return hz.Scene(m, base.opacity, sc, base.rotations, base.shs, 1)
 
     cam = hz.trajectory_camera(0, W=160, H=96)
-    for zmin, zmax, far in ((0.21, 2.0e6, True), (1000.0, 2.0e6, False), (3.0e4, 9.0e5, False)):
+    # All scenes share (P, W, H), i.e. one capacity / depth-range hint (csrc/api.hip): the fourth pass'
+    # two launches are only enqueued while the previous frame needed them (or nothing is known yet).
+    # Order: first frame (no history: four passes enqueued) | near (still enqueued, idle) | near (three
+    # passes only) | FAR (three passes enqueued, the device reports key_far, the frame is rendered again
+    # with four) | far (four) | a scene in millimetres: near again.
+    cases = ((1000.0, 2.0e6, False), (1000.0, 2.0e6, False), (3.0e4, 9.0e5, False), (0.21, 2.0e6, True),
+             (0.21, 2.0e6, True), (3.0e4, 9.0e5, False))
+    scenes = []
+    for zmin, zmax, far in cases:
         sc = stretched(zmin, zmax)
         o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
                            **oracle_kwargs(cam, 1))
@@ -258,6 +266,28 @@ def test_depth_range_beyond_27_bits_takes_the_fourth_sort_pass(dev):
         assert (span >= 1 << 27) == far, (zmin, zmax, span)
         assert (o["radii"] > 0).sum() > 1000
         _check(_rasterize(dev, sc, cam), o, max_fragile_frac=0.2)
+        scenes.append((sc, o, far))
+    # a DEFERRED far frame enqueued on a near history must report "render me again", and the
+    # synchronous re-render (what trajectory.DeferredFrames does) gives the right image
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianrpg_amd.rasterizer import frame_ok
+    camd = hz.trajectory_camera(0, W=160, H=96, device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 1)))
+    near, far_ = scenes[2], scenes[3]
+    for sc, o, expect_ok in ((near[0], near[1], True), (far_[0], far_[1], False)):
+        d = sc.to(dev)
+        if not expect_ok:   # make the history "near" again first
+            dn = near[0].to(dev)
+            rast(means3D=dn.means3D, means2D=None, opacities=dn.opacity, shs=dn.shs, scales=dn.scales,
+                 rotations=dn.rotations)
+        ticket, color, *_ = rast.forward_deferred(d.means3D, d.opacity, shs=d.shs, scales=d.scales,
+                                                  rotations=d.rotations)
+        assert frame_ok(ticket) == expect_ok
+        if not expect_ok:
+            color = rast(means3D=d.means3D, means2D=None, opacities=d.opacity, shs=d.shs, scales=d.scales,
+                         rotations=d.rotations)[0]
+        torch.cuda.synchronize()
+        assert_image_close("color", color.cpu().numpy(), o["color"] - 0.0, o["fragile"], max_fragile_frac=0.2)
 
 
 def test_more_than_4M_gaussians_take_the_classic_sort_passes(dev):
