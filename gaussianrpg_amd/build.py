@@ -131,6 +131,9 @@ VARIANTS = {
 EXPERIMENT_VARIANTS = {
     # phase timestamps of the depth sort's scatter passes (tools/ds_trace.py)
     "dstrace": {"sort.hip": ["-DGRPG_DS_TRACE"]},
+    # per-wave trace of the render (GRPG_RENDER_TRACE=<file>, tools/trace_render.py) and the loop
+    # counters / ablation switches of the blend backward (GRPG_BWD_STATS, GRPG_BWD_ABLATE)
+    "trace": {"render_fwd.hip": ["-DGRPG_TRACE"], "render_bwd.hip": ["-DGRPG_TRACE"]},
 }
 
 

@@ -98,6 +98,8 @@ struct CapHint {
   uint32_t high = 0;      // decaying high-water mark of num_rendered
   uint32_t high_c = 0;    // same for the coarse (Gaussian, super-tile) count of the hierarchical binning
   bool far = true;        // the last frame's depth keys needed the fourth sort pass (sort.hip key_far)
+  uint32_t once = 0, once_c = 0;   // grpg_set_capacity_hint: exact capacities for the next frame only
+  bool seen = false;      // a frame of this shape has reported its counts (high / high_c / far are real)
   uint64_t stamp = 0;     // last use (LRU replacement)
   bool valid = false;
 };
@@ -120,18 +122,18 @@ uint32_t padded_capacity(uint32_t r) {
 }
 uint32_t capacity_from_hint(const CapKey& k, uint32_t* coarse_cap, bool* far) {
   *far = true;   // no history: enqueue the (normally idle) fourth depth-sort pass
-  // test hook "R" or "R:Rc": forced capacities, to exercise the overflow / redo paths
-  static const char* forced_env = getenv("GRPG_RCAP_TEST");
-  if (forced_env) {
-    const long r = atol(forced_env);
-    const char* c = strchr(forced_env, ':');
-    *coarse_cap = (uint32_t)(c ? atol(c + 1) : r);
-    return (uint32_t)r;
-  }
   std::lock_guard<std::mutex> lk(g_hint_mu);
   for (auto& h : g_hints)
     if (h.valid && same_key(h.key, k)) {
       h.stamp = ++g_hint_clock;
+      if (h.once != 0u) {   // grpg_set_capacity_hint: exactly what the caller promised, once
+        const uint32_t cap = h.once, cc = h.once_c;
+        h.once = 0u; h.once_c = 0u;
+        *coarse_cap = cc;
+        *far = true;
+        return cap;
+      }
+      if (!h.seen) break;   // only ever seeded: no history yet
       const uint32_t cap = padded_capacity(h.high);
       const uint32_t cc = h.high_c ? padded_capacity(h.high_c) : cap;
       *coarse_cap = cc < cap ? cc : cap;     // a (Gaussian, super-tile) pair holds >= 1 instance
@@ -163,6 +165,7 @@ void update_hint(const CapKey& k, uint32_t R, uint32_t Rc, bool far) {
   slot->high_c = Rc > dc ? Rc : dc;
   if (slot->high_c > slot->high) slot->high_c = slot->high;
   slot->far = far;
+  slot->seen = true;
   slot->stamp = ++g_hint_clock;
 }
 
@@ -211,16 +214,6 @@ int ensure_device() {
     return fail(GRPG_ERR_NO_DEVICE,
                 "no usable HIP device (libgrpg_rasterizer has no CPU fallback by design)");
   return GRPG_OK;
-}
-
-// Tiles whose list holds at least this many splats are rendered as four 16x4 sub-tiles
-// (render_fwd.hip).  Tunable for experiments through GRPG_HEAVY_MIN.
-uint32_t heavy_tile_min() {
-  static const uint32_t v = [] {
-    const char* e = getenv("GRPG_HEAVY_MIN");
-    return e ? (uint32_t)strtoul(e, nullptr, 10) : 256u;   // measured sweep: 64..1024, best 256
-  }();
-  return v;
 }
 
 // Tile binning algorithm: "hier" (hier_binning.hip, default) or "sort" (emit + stable partition).
@@ -427,6 +420,32 @@ int grpg_set_binning_algorithm(int alg) {
 int grpg_reset_capacity_hints(void) {
   std::lock_guard<std::mutex> lk(g_hint_mu);
   for (auto& h : g_hints) h = CapHint{};
+  return GRPG_OK;
+}
+int grpg_set_capacity_hint(int P, int width, int height, unsigned instances, unsigned coarse_pairs) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  if (P <= 0 || width <= 0 || height <= 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "bad shape");
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const CapKey k = {dev, P, width, height};
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  CapHint* slot = nullptr;
+  for (auto& h : g_hints)
+    if (h.valid && same_key(h.key, k)) { slot = &h; break; }
+  if (!slot) {
+    slot = &g_hints[0];
+    for (auto& h : g_hints) {
+      if (!h.valid) { slot = &h; break; }
+      if (h.stamp < slot->stamp) slot = &h;
+    }
+    *slot = CapHint{};
+    slot->key = k;
+    slot->valid = true;
+  }
+  slot->once = instances ? instances : 1u;
+  slot->once_c = coarse_pairs ? coarse_pairs : 1u;
+  slot->stamp = ++g_hint_clock;
   return GRPG_OK;
 }
 
@@ -676,17 +695,18 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                            (uint32_t*)(img + IL.bwd_ctl), (BlobHeader*)binp,
                            (uint32_t)(L.total / 256), ckpt_slots(cap)};
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
-                            out_color, out_depth, out_alpha, n_contrib, work, heavy_tile_min(), cap,
+                            out_color, out_depth, out_alpha, n_contrib, work, tile_classes(S), cap,
                             (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified,
                             with_ckpt ? &ck : nullptr,
-                            PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3});
+                            PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3},
+                            S > 0 ? semantics : nullptr, S, out_semantic);
       STAGE_CHECK("render");
       if (debug)   // the stage check has synchronised: a hand-over timeout of THIS frame is known
         if (int rc = check_async_error(hw)) return rc;
       tm.mark(7);
-      if (S > 0) {
-        launch_render_semantic(stream, ranges, point_list, rec, semantics, S, width, height, cam.gx,
-                               cam.gy, out_semantic);
+      if (S > RENDER_NSEM) {   // the first RENDER_NSEM planes rode in the render launch
+        launch_render_semantic(stream, ranges, point_list, rec, semantics, S, RENDER_NSEM, width, height,
+                               cam.gx, cam.gy, out_semantic);
         STAGE_CHECK("semantic render");
       }
       tm.mark(-1);
@@ -775,7 +795,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                         (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
                         (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
                         (uint32_t*)(binp + L.tile_start), ranges, &gh->R, nullptr,
-                        &gh->Rc, (BlobHeader*)binp, cap, ccap, work, heavy_tile_min());
+                        &gh->Rc, (BlobHeader*)binp, cap, ccap, work, tile_classes(S));
       STAGE_CHECK("tile counts");
       launch_hier_fill(stream, binp + L.seg_desc, (const uint32_t*)(binp + L.nseg), L.max_seg, ckey, cval, rec,
                        cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),

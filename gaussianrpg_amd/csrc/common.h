@@ -297,6 +297,22 @@ inline ImgLayout img_layout(size_t T, size_t N) {
   return L;
 }
 
+// Work-list classes of the render (render_fwd.hip; the backward reuses the lists): a tile list of
+//   >= c0_min entries: producer / consumer wave pairs      >= c1_min, >= heavy_min: four quarter waves
+//   shorter: one wave per tile (light).
+// A frame with semantic planes sends every non-empty tile down the heavy path (heavy_min = 1), whose
+// one-pixel-per-lane waves carry the extra accumulators.
+constexpr uint32_t RENDER_PC_MIN = 8192, RENDER_C1_MIN = 2048, RENDER_HEAVY_MIN = 256;
+constexpr int RENDER_NSEM = 16;   // semantic channels fused into the main render launch
+static_assert(RENDER_HEAVY_MIN <= CK_LONG_MIN, "lists with blend checkpoints must take the heavy path");
+struct TileClasses { uint32_t c0_min, c1_min, heavy_min; };
+inline TileClasses tile_classes(int S) {
+  return TileClasses{RENDER_PC_MIN, RENDER_C1_MIN, S > 0 ? 1u : RENDER_HEAVY_MIN};
+}
+__host__ __device__ inline int tile_class(const uint32_t len, const TileClasses tc) {
+  return len >= tc.c0_min ? 0 : (len >= tc.c1_min ? 1 : (len >= tc.heavy_min ? 2 : 3));
+}
+
 // ------------------------------- launchers (one per .hip TU) ---------------------------
 struct CameraArgs {
   const float* view;    // device [16]
@@ -395,7 +411,7 @@ void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals
                        uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,
                        const uint32_t* Rc_dev, BlobHeader* bin_header, uint32_t R_cap,
                        uint32_t coarse_cap, uint32_t* work /* render work lists [4 + 4T] */,
-                       uint32_t heavy_min);
+                       TileClasses cls);
 void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_total, uint32_t max_seg,
                       const uint32_t* ckey_sorted, const uint32_t* cval_sorted, const RecView rec,
                       int gx, int gy,
@@ -418,16 +434,17 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] u32 scratch */,
-                           uint32_t heavy_min, uint32_t R /* num_rendered */,
+                           TileClasses cls, uint32_t R /* num_rendered */,
                            bool aux /* track + write n_contrib (needed by the backward only) */,
                            bool classified /* work lists already built (hier_binning.hip) */,
                            const CkptArgs* ck /* aux only: blend checkpoints for the backward, or NULL */,
-                           const PCErr pc_err);
-void render_class_multipliers(uint32_t* c0_mul, uint32_t* c1_mul);   // render_fwd.hip
-uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min);   // render_fwd.hip
+                           const PCErr pc_err, const float* semantics /* [P][S] or NULL */, int S,
+                           float* out_semantic /* the first min(S, RENDER_NSEM) planes are written here */);
+uint32_t render_pc_slots(uint32_t R);   // render_fwd.hip
+// channels [c_begin, S) of the semantic planes (stand-alone kernel)
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                            const RecView rec, const float* semantics, int S, int W, int H, int gx,
-                            int gy, float* out_semantic);
+                            const RecView rec, const float* semantics, int S, int c_begin, int W, int H,
+                            int gx, int gy, float* out_semantic);
 
 void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const RecView rec, const float* semantics, int S, int W, int H, int gx,

@@ -235,7 +235,7 @@ hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
                     uint32_t* __restrict__ R_out, uint32_t* __restrict__ host_word,
                     const uint32_t* __restrict__ Rc_dev, BlobHeader* __restrict__ bin_header,
                     const uint32_t R_cap, const uint32_t coarse_cap, uint32_t* __restrict__ work,
-                    const uint32_t heavy_min, const uint32_t c0_mul, const uint32_t c1_mul) {
+                    const TileClasses tc) {
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_carry;
   __shared__ uint32_t s_cls[4];
@@ -297,8 +297,7 @@ hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
         ranges[t] = v[k] ? make_uint2(min(ex, R_cap), min(ex + v[k], R_cap)) : make_uint2(0u, 0u);
       }
       const uint32_t len = min(ex + v[k], R_cap) - min(ex, R_cap);
-      const uint64_t hm = heavy_min;
-      cls[k] = t >= T ? -1 : (len >= c0_mul * hm ? 0 : (len >= c1_mul * hm ? 1 : (len >= hm ? 2 : 3)));
+      cls[k] = t >= T ? -1 : tile_class(len, tc);
       n01 += cls[k] == 0 ? 1u : (cls[k] == 1 ? 0x10000u : 0u);
       n23 += cls[k] == 2 ? 1u : (cls[k] == 3 ? 0x10000u : 0u);
       ex += v[k];
@@ -479,7 +478,7 @@ void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals
                        int gx, int gy, uint32_t* seg_table, uint32_t* tile_tot,
                        uint32_t* tile_start, uint2* ranges, uint32_t* R_out, uint32_t* host_word,
                        const uint32_t* Rc_dev, BlobHeader* bin_header, uint32_t R_cap,
-                       uint32_t coarse_cap, uint32_t* work, uint32_t heavy_min) {
+                       uint32_t coarse_cap, uint32_t* work, TileClasses cls) {
   const int sgx = (gx + STILE - 1) / STILE;
   const uint32_t T = (uint32_t)gx * (uint32_t)gy;
   SegDesc* seg = (SegDesc*)seg_desc;
@@ -492,10 +491,8 @@ void launch_hier_count(hipStream_t s, uint2* cranges, const uint32_t* run_totals
                                                               nullptr, NS, cranges, st_seg, max_seg);
   }
   hb_tile_prefix_kernel<<<NS, 1024, 0, s>>>(st_seg, seg_table, sgx, gx, gy, tile_tot);
-  uint32_t c0_mul, c1_mul;
-  render_class_multipliers(&c0_mul, &c1_mul);
   hb_tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_tot, tile_start, ranges, R_out, host_word, Rc_dev,
-                                         bin_header, R_cap, coarse_cap, work, heavy_min, c0_mul, c1_mul);
+                                         bin_header, R_cap, coarse_cap, work, cls);
 }
 
 void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_total, uint32_t max_seg,

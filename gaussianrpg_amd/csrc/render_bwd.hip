@@ -586,26 +586,26 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
                             uint32_t R) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
-  // GRPG_BWD_SEG=0: ignore the forward's checkpoints (every list is one chain again)
-  static const int seg_on = [] { const char* e = getenv("GRPG_BWD_SEG"); return e ? atoi(e) : 1; }();
   uint32_t items_cap = 0;
-  // the forward left (tile, segment) items behind; their number is on the device, bounded here by
-  // the sum of ckpt_tile_cap over lists of >= CK_LONG_MIN entries
-  if (seg_on && S <= 0 && bin_hdr && ck_count && bwd_ctl) items_cap = ckpt_slots(R);
-  // experiment switch: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
-  static const int ablate = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
-  // GRPG_BWD_WIDE (default 1): the forward's shortest heavy class (lists of 256 .. 2047 entries) is
-  // walked by two half-tile waves at 2 pixels per lane like the light tiles -- one reduction + atomic
-  // per (half tile, splat) instead of one per quarter.  The kernel is VALU-bound and a third of its
-  // cycles are that reduction: 515 -> 489 us at config 5, 645 -> 573 us on the 2 M-Gaussian scene
-  // (0 = quarter waves for every heavy tile; lists of 2048 .. 4095 entries as half tiles: slower,
-  // their chains become the tail).
-  static const int wide = [] { const char* e = getenv("GRPG_BWD_WIDE"); return e ? atoi(e) : 1; }();
-  // GRPG_BWD_STATS=1: per-launch loop counters printed to stderr (synchronises: experiments only)
+  // the forward left (tile, segment) items behind (S = 0 training forwards only); their number is on
+  // the device, bounded here by the sum of ckpt_tile_cap over lists of >= CK_LONG_MIN entries.
+  // Without them (semantic frames) every list is walked as one chain.
+  if (S <= 0 && bin_hdr && ck_count && bwd_ctl) items_cap = ckpt_slots(R);
+  // The forward's shortest heavy class (lists of 256 .. 2047 entries) is walked by two half-tile
+  // waves at 2 pixels per lane like the light tiles -- one reduction + atomic per (half tile, splat)
+  // instead of one per quarter.  The kernel is VALU-bound and a third of its cycles are that
+  // reduction: 515 -> 489 us at config 5, 645 -> 573 us on the 2 M-Gaussian scene (quarter waves for
+  // every heavy tile, or half tiles for lists of 2048 .. 4095 entries as well: slower).
+  const int wide = 1;
+  int ablate = 0;
+  unsigned long long* stats = nullptr;
+#ifdef GRPG_TRACE   // experiment build: ablation switch and per-launch loop counters (synchronises)
+  // GRPG_BWD_ABLATE: 1 = no atomics, 2 = no reduction either, 4 = traversal + alpha only
+  static const int ablate_env = [] { const char* e = getenv("GRPG_BWD_ABLATE"); return e ? atoi(e) : 0; }();
+  ablate = ablate_env;
   static const int want_stats = [] { const char* e = getenv("GRPG_BWD_STATS"); return e ? atoi(e) : 0; }();
   static unsigned long long* stats_dev = nullptr;
   static size_t stats_cap = 0;
-  unsigned long long* stats = nullptr;
   const int grid_max = ntiles + ntiles / 2 + 1 + (int)ckpt_slots(R);
   const size_t stats_words = 8ull * (size_t)grid_max * RB_WAVES;
   if (want_stats) {
@@ -618,31 +618,25 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
     (void)hipMemsetAsync(stats_dev, 0, stats_words * sizeof(unsigned long long), s);
     stats = stats_dev;
   }
+#endif
 #define RB_ARGS                                                                                  \
   ranges, point_list, rec, semantics, S, W, H, gx, (uint32_t)ntiles, work, bg, alphas, n_contrib, \
       dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, grad_rec, dL_dsemantic, ablate, wide, stats, \
       bin_hdr, ck_count, bwd_ctl, items_cap
-  // nheavy + ceil(LIGHT_SPLIT nlight / 4) <= ntiles for LIGHT_SPLIT <= 2 ... not for nheavy ~ ntiles/2:
-  // launch nheavy_max + light workgroups = ntiles + ntiles/2 + 1, surplus workgroups exit at once.
-  // Light tiles: two waves per tile at 2 pixels per lane (default): the kernel then fits 128 VGPRs
-  // = 4 waves per SIMD.  One wave at 4 pixels per lane (GRPG_BWD_LIGHT=4: 160 VGPRs, 3 waves per
-  // SIMD) and GRPG_BWD_WAVES=1 (no register cap) measure within 1 % of it under rocprofv3 at
-  // config 5; GRPG_BWD_WAVES=5 (96 VGPRs, 36 spilled) is 8 % slower.
-  static const int light4 = [] { const char* e = getenv("GRPG_BWD_LIGHT"); return e && atoi(e) == 4; }();
-  const int grid = (light4 ? ntiles : ntiles + ntiles / 2 + 1) + (int)items_cap;
+  // nheavy + ceil(2 nlight / 4) workgroups at most = ntiles + ntiles / 2 + 1; surplus ones exit at once.
+  // Light tiles: two waves per tile at 2 pixels per lane: the kernel then fits 128 VGPRs = 4 waves per
+  // SIMD (one wave at 4 pixels per lane / 160 VGPRs and an uncapped allocation measured within 1 %;
+  // 96 VGPRs with 36 spilled: 8 % slower).
+  const int grid = ntiles + ntiles / 2 + 1 + (int)items_cap;
   if (S <= 0) {
-    static const int minw = [] { const char* e = getenv("GRPG_BWD_WAVES"); return e ? atoi(e) : 4; }();
-    if (light4) render_backward_kernel<0, 1><<<grid, 256, 0, s>>>(RB_ARGS);
-    else if (minw >= 5) render_backward_kernel<0, 2, 5><<<grid, 256, 0, s>>>(RB_ARGS);
-    else if (minw == 4) render_backward_kernel<0, 2, 4><<<grid, 256, 0, s>>>(RB_ARGS);
-    else render_backward_kernel<0, 2><<<grid, 256, 0, s>>>(RB_ARGS);
+    render_backward_kernel<0, 2, 4><<<grid, 256, 0, s>>>(RB_ARGS);
   } else if (S <= 4) {
-    if (light4) render_backward_kernel<4, 1><<<grid, 256, 0, s>>>(RB_ARGS);
-    else render_backward_kernel<4, 2><<<grid, 256, 0, s>>>(RB_ARGS);
+    render_backward_kernel<4, 2><<<grid, 256, 0, s>>>(RB_ARGS);
   } else {
     render_backward_kernel<32, 1><<<ntiles, 256, 0, s>>>(RB_ARGS);   // S <= 32 (reference: 20)
   }
 #undef RB_ARGS
+#ifdef GRPG_TRACE
   if (stats) {
     std::vector<unsigned long long> h(stats_words);
     (void)hipStreamSynchronize(s);
@@ -666,6 +660,7 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
             (waves[0] + waves[1]) ? (double)cyc_sum / (double)(waves[0] + waves[1]) : 0.0, cyc_max, trips_of_longest,
             reach_of_longest, small1, small4, small8);
   }
+#endif
 }
 
 }  // namespace grpg

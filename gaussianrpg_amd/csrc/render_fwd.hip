@@ -45,17 +45,17 @@ namespace grpg {
 constexpr int RW_WAVES = 4;
 
 // ------------------------------------------------------------------------------------------
-// Tile classification into work lists (order inside a list is irrelevant to results):
-//   class 0: len >= 8*heavy_min   class 1: len >= 2*heavy_min   class 2: len >= heavy_min
-//   (all three rendered as four 16x4 sub-tiles)                  class 3: light (one wave/tile)
+// Tile classification into work lists (order inside a list is irrelevant to results; thresholds:
+// common.h TileClasses):
+//   class 0: producer / consumer wave pairs   class 1, class 2: four quarter waves
+//   class 3: light (one wave per tile)
 // Workgroups are handed out class 0 first, so the longest lists start first (LPT order).
 // counts[4] pre-zeroed by the launcher; lists[c] = work + 4 + c*T.
 // ------------------------------------------------------------------------------------------
 constexpr int NUM_CLASSES = 4;
 
 __global__ void __launch_bounds__(256)
-classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
-                      const uint32_t heavy_min, const uint32_t c0_mul, const uint32_t c1_mul,
+classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges, const TileClasses tc,
                       uint32_t* __restrict__ work) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63;
@@ -63,8 +63,7 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges,
   if (t < T) {
     const uint2 r = ranges[t];
     const uint32_t len = r.y - r.x;
-    const uint64_t hm = heavy_min;
-    cls = len >= c0_mul * hm ? 0 : (len >= c1_mul * hm ? 1 : (len >= hm ? 2 : 3));
+    cls = tile_class(len, tc);
   }
   // wave-aggregated slot allocation: one atomic per (wave, class) instead of one per tile
   // (9600 same-address atomics serialise at ~11 ns each = 100 us, measured)
@@ -97,10 +96,29 @@ struct WavePix {   // per-lane blending state of PX pixels
   uint64_t done[PX];       // lane masks: pixel k of the lane is saturated / outside the image
 };
 
+// N-channel "semantic" planes (forward.cu:442-444: out_semantic[ch] += semantic[ch] alpha T): NSEM
+// accumulators per pixel next to the colour ones, fed by the SAME blend weights -- the heavy path
+// (one pixel per lane) carries them; the semantic row of a splat is wave-uniform, so it arrives
+// through the scalar unit (s_load) and costs the vector ALU one fma per channel and (wave, splat).
+template <int NSEM>
+struct SemAcc { float v[NSEM > 0 ? NSEM : 1]; };
+struct SemSrc { const float* semantics; int S; };   // [P][S]
+template <int NSEM>
+__device__ __forceinline__ void sem_accumulate(SemAcc<NSEM>& sa, const SemSrc src, const uint32_t id_uniform,
+                                               const float w) {
+  if (NSEM == 0) return;
+  const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id_uniform);
+  const float* __restrict__ row = src.semantics + (size_t)id * (size_t)src.S;
+#pragma unroll
+  for (int c = 0; c < NSEM; c++) sa.v[c] = fmaf(row[c < src.S ? c : 0], w, sa.v[c]);   // c >= S: never written out
+}
+
 // In-order blend of one splat into pixel k (forward.cu:425-440); ok_m = lanes that accept it.
-template <int PX, bool AUX = true>
+template <int PX, bool AUX = true, int NSEM = 0>
 __device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uint64_t ok_m,
-                                          const float alpha, const float4 col, const uint32_t pos) {
+                                          const float alpha, const float4 col, const uint32_t pos,
+                                          SemAcc<NSEM>* sa = nullptr, const SemSrc src = SemSrc{nullptr, 0},
+                                          const uint32_t id = 0u) {
   const v2f tw = (v2f){1.0f - alpha, alpha} * (v2f){s.T[k], s.T[k]};   // T (1 - alpha), alpha T
   const uint64_t lt_m = lanes(tw.x < 0.0001f);
   const uint64_t live = ok_m & ~s.done[k];
@@ -119,6 +137,7 @@ __device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uin
   }
   s.T[k] = cont ? tw.x : s.T[k];
   if (AUX) s.last[k] = cont ? pos : s.last[k];   // n_contrib: only a later backward needs it
+  if (NSEM > 0) sem_accumulate<NSEM>(*sa, src, id, w);
 }
 
 // LDS slot of a compacted survivor, light path (REC_F4 = 3 float4):
@@ -208,24 +227,27 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
 // Heavy path (1 pixel per lane): survivors are stored in PAIRS so that two splats are evaluated
 // per packed instruction.  LDS block of a pair (PAIR_F4 = 6 float4, same 48 B per splat):
 //   [0] gx0 gx1 gy0 gy1   [1] A0 A1 B0 B1   [2] C0 C1 op0 op1
-//   [3] r0 g0 b0 depth0   [4] r1 g1 b1 depth1   [5] pos0 pos1 - -
+//   [3] r0 g0 b0 depth0   [4] r1 g1 b1 depth1   [5] pos0 pos1 id0 id1 (ids: semantic frames only)
 constexpr int PAIR_F4 = 2 * REC_F4;
 
+template <bool WITH_ID = false>
 __device__ __forceinline__ void store_pair_half(float4* __restrict__ my, const int slot,
                                                 const float gx, const float gy, const SplatQ q,
                                                 const float op, const float4 col,
-                                                const uint32_t pos) {
+                                                const uint32_t pos, const uint32_t id = 0u) {
   float4* blk = my + (slot >> 1) * PAIR_F4;
   float* f = reinterpret_cast<float*>(blk) + (slot & 1);
   f[0] = gx; f[2] = gy; f[4] = q.A; f[6] = q.B; f[8] = q.C; f[10] = op;
   blk[3 + (slot & 1)] = col;
   f[20] = __uint_as_float(pos);
+  if (WITH_ID) f[22] = __uint_as_float(id);
 }
 
 // Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
-template <bool AUX = true>
+template <bool AUX = true, int NSEM = 0>
 __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
-                                           const int j0, const float pxf, const float pyf) {
+                                           const int j0, const float pxf, const float pyf,
+                                           SemAcc<NSEM>* sa = nullptr, const SemSrc sem = SemSrc{nullptr, 0}) {
   const float4* blk = my + (j0 >> 1) * PAIR_F4;
   float alpha[4];
   uint64_t ok[4];
@@ -274,6 +296,11 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
         s.last[0] = in_mask(ok[2 * h] & live) ? __float_as_uint(pp.x) : s.last[0];
         s.last[0] = in_mask(ok[2 * h + 1] & live) ? __float_as_uint(pp.y) : s.last[0];
       }
+      if (NSEM > 0) {   // the same weights feed the semantic planes, in list order
+        const float4 pp = blk[h * PAIR_F4 + 5];
+        sem_accumulate<NSEM>(*sa, sem, __float_as_uint(pp.z), w[2 * h]);
+        sem_accumulate<NSEM>(*sa, sem, __float_as_uint(pp.w), w[2 * h + 1]);
+      }
     }
     s.T[0] = T;
     return true;
@@ -281,8 +308,10 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
 #pragma unroll
   for (int h = 0; h < 2; h++) {   // some pixel terminates in this quad: the exact per-splat blend
     const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4], pp = blk[h * PAIR_F4 + 5];
-    blend_one<1, AUX>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x));
-    blend_one<1, AUX>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y));
+    blend_one<1, AUX, NSEM>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x), sa, sem,
+                            __float_as_uint(pp.z));
+    blend_one<1, AUX, NSEM>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y), sa, sem,
+                            __float_as_uint(pp.w));
   }
   return true;
 }
@@ -500,7 +529,16 @@ __device__ __forceinline__ void ckpt_publish_items(const CkptArgs& ck, const int
     if (base + k < ck.slots) items[base + k] = make_uint2(tile, k);
 }
 
-template <bool TRACE, bool AUX = true>
+// writes the wave's semantic accumulators (channels < min(S, NSEM)); semantics get no background
+template <int NSEM>
+__device__ __forceinline__ void sem_write(const SemAcc<NSEM>& sa, const int S, float* __restrict__ out_semantic,
+                                          const size_t HW, const size_t pix) {
+#pragma unroll
+  for (int c = 0; c < NSEM; c++)
+    if (c < S) out_semantic[(size_t)c * HW + pix] = sa.v[c];
+}
+
+template <bool TRACE, bool AUX = true, int NSEM = 0>
 __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
                                             uint32_t* __restrict__ qpos, const int lane,
                                             const int quarter, const uint32_t r_begin,
@@ -513,7 +551,11 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                                             float* __restrict__ out_depth,
                                             float* __restrict__ out_alpha,
                                             uint32_t* __restrict__ n_contrib, WaveTrace* tr,
-                                            CkptWriter ckw) {
+                                            CkptWriter ckw, const SemSrc sem = SemSrc{nullptr, 0},
+                                            float* __restrict__ out_semantic = nullptr) {
+  SemAcc<NSEM> sa;
+#pragma unroll
+  for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
   const int px = x0 + (lane & 15);
   const int py = y0 + (lane >> 4);
   const float pxf = (float)px;
@@ -536,7 +578,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     win[q] = i < r_end ? point_list[i] : 0u;
   }
   float4 a = make_float4(0, 0, 0, 0), b = a, c = a;   // current batch (records arrived)
-  uint32_t pos = 0;
+  uint32_t pos = 0, idc = 0;
   uint32_t ncur = 0;
 
   for (;;) {
@@ -590,12 +632,12 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     // ---- POP: next batch of up to 64 survivors, start its record gather ----
     const uint32_t nn = min(count, (uint32_t)WAVE);
     float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
-    uint32_t pos_n = 0;
+    uint32_t pos_n = 0, id_n = 0;
     if ((uint32_t)lane < nn) {
       const uint32_t slot = (head + lane) & (QCAP - 1);
-      const uint32_t id = qid[slot];
+      id_n = qid[slot];
       pos_n = qpos[slot];
-      rec.load(id, a_n, b_n, c_n);
+      rec.load(id_n, a_n, b_n, c_n);
     }
     head = (head + nn) & (QCAP - 1);
     count -= nn;
@@ -608,18 +650,18 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
       const uint64_t mask = __ballot(keep);
       const int cnt = (int)__popcll(mask);
       if (keep)
-        store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
-                        make_float4(b.w, c.x, c.y, a.z), pos);
+        store_pair_half<(NSEM > 0)>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                                    make_float4(b.w, c.x, c.y, a.z), pos, idc);
       if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
         const SplatQ zq = {0.f, 0.f, 0.f};
-        store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+        store_pair_half<(NSEM > 0)>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
       }
       if (TRACE) tr->survivors += (uint32_t)cnt;
       __builtin_amdgcn_wave_barrier();
       const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
       if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
       for (int j0 = 0; j0 < cnt; j0 += 4) {
-        const bool blended = blend_quad<AUX>(st, my, j0, pxf, (float)py);
+        const bool blended = blend_quad<AUX, NSEM>(st, my, j0, pxf, (float)py, &sa, sem);
         if (TRACE && blended) tr->blends++;
       }
       if (TRACE) {
@@ -633,7 +675,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
       if (AUX) ckpt_batch_end(ckw, lane, st, (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)ncur - 1));
       __builtin_amdgcn_wave_barrier();
     }
-    a = a_n; b = b_n; c = c_n; pos = pos_n; ncur = nn;
+    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
     if (ncur == 0 && in_pos >= r_end) break;   // ring empty (count == 0 here) and list exhausted
   }
   if (AUX) ckpt_finish(ckw, lane, st, r_end - r_begin);
@@ -648,6 +690,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     out_alpha[pix] = 1.0f - st.T[0];
     out_depth[pix] = st.CbD[0].y;
     if (AUX) n_contrib[pix] = st.last[0];
+    if (NSEM > 0) sem_write<NSEM>(sa, sem.S, out_semantic, HW, pix);
   }
 }
 
@@ -706,6 +749,7 @@ __device__ __forceinline__ void pc_store(uint32_t* p, const uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+template <bool WITH_ID = false>
 __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
                                             uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
                                             PCCtrl* __restrict__ ctl, const int lane,
@@ -723,7 +767,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
     win[q] = i < r_end ? point_list[i] : 0u;
   }
   float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-  uint32_t pos = 0, ncur = 0;
+  uint32_t pos = 0, idc = 0, ncur = 0;
   int cur = 0;
   bool stopped = false;
   for (;;) {
@@ -759,12 +803,12 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
     // ---- POP ----
     const uint32_t nn = min(count, (uint32_t)WAVE);
     float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
-    uint32_t pos_n = 0;
+    uint32_t pos_n = 0, id_n = 0;
     if ((uint32_t)lane < nn) {
       const uint32_t slot = (head + lane) & (QCAP - 1);
-      const uint32_t id = qid[slot];
+      id_n = qid[slot];
       pos_n = qpos[slot];
-      rec.load(id, a_n, b_n, c_n);
+      rec.load(id_n, a_n, b_n, c_n);
     }
     head = (head + nn) & (QCAP - 1);
     count -= nn;
@@ -785,17 +829,17 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
         if (stopped) break;
         float4* my = cur ? buf1 : buf0;
         if (keep)
-          store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
-                          make_float4(b.w, c.x, c.y, a.z), pos);
+          store_pair_half<WITH_ID>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                                   make_float4(b.w, c.x, c.y, a.z), pos, idc);
         if (lane < ((4 - (cnt & 3)) & 3)) {
           const SplatQ zq = {0.f, 0.f, 0.f};
-          store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+          store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
         }
         pc_store(&ctl->flag[cur], (uint32_t)cnt + 1u);
         cur ^= 1;
       }
     }
-    a = a_n; b = b_n; c = c_n; pos = pos_n; ncur = nn;
+    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
     if (ncur == 0 && in_pos >= r_end) break;
   }
   if (!stopped) {   // end-of-list marker
@@ -809,7 +853,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   }
 }
 
-template <bool AUX = true>
+template <bool AUX = true, int NSEM = 0>
 __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             const float4* __restrict__ buf1,
                                             PCCtrl* __restrict__ ctl, const int lane,
@@ -819,7 +863,12 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             float* __restrict__ out_depth,
                                             float* __restrict__ out_alpha,
                                             uint32_t* __restrict__ n_contrib, CkptWriter ckw,
-                                            const uint32_t len, const PCErr err) {
+                                            const uint32_t len, const PCErr err,
+                                            const SemSrc sem = SemSrc{nullptr, 0},
+                                            float* __restrict__ out_semantic = nullptr) {
+  SemAcc<NSEM> sa;
+#pragma unroll
+  for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
   const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
   const float pxf = (float)px;
   WavePix<1> st;
@@ -838,7 +887,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     if (f == PC_DONE) break;
     const int cnt = (int)(f - 1u);
     const float4* my = cur ? buf1 : buf0;
-    for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad<AUX>(st, my, j0, pxf, (float)py);
+    for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad<AUX, NSEM>(st, my, j0, pxf, (float)py, &sa, sem);
     if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
       const float* blk = reinterpret_cast<const float*>(my + ((cnt - 1) >> 1) * PAIR_F4);
       ckpt_batch_end(ckw, lane, st,
@@ -874,35 +923,29 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     out_alpha[pix] = 1.0f - st.T[0];
     out_depth[pix] = st.CbD[0].y;
     if (AUX) n_contrib[pix] = st.last[0];
+    if (NSEM > 0) sem_write<NSEM>(sa, sem.S, out_semantic, HW, pix);
   }
 }
 
-// XCD-aware work assignment (experiment, off by default: see launch_render_forward).  The
-// hardware places workgroup b on XCD b mod 8 and every XCD has its own L2.  Consecutive entries of a work list are neighbouring tiles (classify appends runs of up
-// to 64 consecutive tile ids), and neighbouring tiles gather the same Gaussians' records -- so
-// workgroup i of the n that walk a list takes item  j * n/8 + i/8  (j = i mod 8): each XCD works on
-// one contiguous eighth of the list and re-finds its neighbours' records in its own L2.
-__device__ __forceinline__ uint32_t xcd_contiguous(const uint32_t i, const uint32_t n, const int on) {
-  if (!on) return i;
-  const uint32_t per = n >> 3, rem = n & 7u, j = i & 7u, k = i >> 3;
-  return j * per + min(j, rem) + k;   // bijection on [0, n): k < per + (j < rem) whenever i < n
-}
-
-#ifndef GRPG_RENDER_MIN_WAVES
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
 // 112 KB of LDS per CU so that the other stream's sort workgroups can co-reside) measured slightly
 // ahead of 5 (96 VGPRs, 136 B of scratch per lane): 0.327 vs 0.333 ms, 1640 vs 1600 frames/s.
-#define GRPG_RENDER_MIN_WAVES 4
-#endif
-template <bool WRITE_AUX, int GPI_L, bool TRACE = false>
-__global__ void __launch_bounds__(256, GRPG_RENDER_MIN_WAVES)
+// A frame with semantic planes (NSEM > 0) carries NSEM more accumulators per lane: 2 waves per SIMD.
+constexpr int RENDER_MIN_WAVES = 4;
+
+// Measured and removed: XCD-contiguous work assignment (0.248 vs 0.232 ms:
+// neighbouring tiles are similarly long, contiguous eighths unbalance the XCDs), occupancy capped
+// with unused LDS, one splat per iteration in the light path, persistent waves.
+template <bool WRITE_AUX, int GPI_L, bool TRACE = false, int NSEM = 0>
+__global__ void __launch_bounds__(256, NSEM > 0 ? 2 : RENDER_MIN_WAVES)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RecView rec, const int W, const int H, const int gx,
                       const uint32_t T, const uint32_t* __restrict__ work,
                       const float* __restrict__ bg,
                       float* __restrict__ out_color, float* __restrict__ out_depth,
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                      const uint32_t pc_slots, const int xcd_on, const CkptArgs ck, const PCErr pc_err,
+                      const uint32_t pc_slots, const CkptArgs ck, const PCErr pc_err,
+                      const SemSrc sem, float* __restrict__ out_semantic,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
@@ -918,10 +961,10 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     ck.bin_hdr->ckpt_off256 = ck.off256;   // tells the backward where this frame's checkpoints are
     ck.bin_hdr->ckpt_slots = ck.slots;
   }
-  // pc_slots > 0: class 0 holds the few longest tiles; each is rendered by two workgroups (half
-  // tiles) with a producer and a consumer wave per quarter.  The first pc_slots workgroups are
-  // reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
-  if (pc_slots != 0u && blockIdx.x < pc_slots) {
+  // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each is rendered by two
+  // workgroups (half tiles) with a producer and a consumer wave per quarter.  The first pc_slots
+  // workgroups are reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
+  if (blockIdx.x < pc_slots) {
     if (blockIdx.x >= 2u * n0) return;
     const uint32_t tile = lists[blockIdx.x >> 1];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
@@ -938,41 +981,38 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     }
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
     if (wave < 2) {
-      pc_consumer<WRITE_AUX>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
-                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err);
+      pc_consumer<WRITE_AUX, NSEM>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
+                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err, sem,
+                  out_semantic);
       if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
     } else
-      pc_producer(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
+      pc_producer<(NSEM > 0)>(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
                   rb, re, point_list, rec, pc_err);
     return;
   }
   // Dispatch order (longest processing time first): class 0, class 1, the LIGHT tiles, class 2.
   // A light tile is a whole tile on one wave (measured 40-70 us for 100-250 entries), longer than
   // a quarter wave of a class-2 tile (20-30 us), so it must not come last.
-  const uint32_t nh0 = pc_slots != 0u ? 0u : n0;   // class 0 rendered above in pc mode
-  const uint32_t nlong = nh0 + n1;
   const uint32_t nlwg = (nlight + RW_WAVES - 1) / RW_WAVES;
   const uint32_t b0 = blockIdx.x - pc_slots;
-  const bool is_heavy = b0 < nlong || b0 >= nlong + nlwg;
-  const uint32_t b = b0 < nlong ? b0 : (is_heavy ? b0 - nlwg : b0 - nlong);   // index in its kind
+  const bool is_heavy = b0 < n1 || b0 >= n1 + nlwg;
+  const uint32_t b = b0 < n1 ? b0 : (is_heavy ? b0 - nlwg : b0 - n1);   // index in its kind
   if (is_heavy) {
-    if (b >= nlong + n2) return;
+    if (b >= n1 + n2) return;
     // heavy tile: four independent 16x4 sub-tiles, 1 pixel per lane, 4 splats per iteration
-    const uint32_t tile = b < nh0 ? lists[xcd_contiguous(b, nh0, xcd_on)]
-                                  : (b < nh0 + n1 ? lists[T + xcd_contiguous(b - nh0, n1, xcd_on)]
-                                                  : lists[2 * T + xcd_contiguous(b - nh0 - n1, n2, xcd_on)]);
+    const uint32_t tile = b < n1 ? lists[T + b] : lists[2 * T + (b - n1)];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
     tr_tile = tile; tr_len = re - rb;
-    blend_heavy<TRACE, WRITE_AUX>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
+    blend_heavy<TRACE, WRITE_AUX, NSEM>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
                        ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
-                       out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re));
+                       out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re), sem, out_semantic);
     if (WRITE_AUX && wave == 0) ckpt_publish_items(ck, lane, tile, re - rb);
   } else {
     if (b >= nlwg) return;
-    const uint32_t li = xcd_contiguous(b, nlwg, xcd_on) * RW_WAVES + (uint32_t)wave;
+    const uint32_t li = b * RW_WAVES + (uint32_t)wave;
     if (li >= nlight) return;   // whole wave exits together; no workgroup barriers are used
     const uint32_t tile = lists[3 * (size_t)T + li];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
@@ -983,8 +1023,17 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     blend_rect<4, GPI_L, WRITE_AUX, TRACE>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE, W, H,
                                            point_list, rec, bg, out_color, out_depth, out_alpha,
                                            n_contrib, &tr, ablate);
+    if (NSEM > 0) {
+      // a semantic frame sends every non-empty tile down the heavy path (tile_classes): what arrives
+      // here holds no splat at all -- its semantic planes are zero (they get no background)
+      const int px = tx * TILE + (lane & 15), py0 = ty * TILE + (lane >> 4) * 4;
+      const size_t HW = (size_t)H * W;
+      for (int k = 0; k < 4; k++)
+        if (px < W && py0 + k < H)
+          for (int c = 0; c < sem.S && c < NSEM; c++) out_semantic[(size_t)c * HW + (size_t)(py0 + k) * W + px] = 0.f;
+    }
   }
-  if (TRACE && lane == 0) {   // per-wave trace record (debug tool, GRPG_RENDER_TRACE=<file>)
+  if (TRACE && lane == 0) {   // per-wave trace record (experiment build -DGRPG_TRACE)
     const uint64_t t_end = wall_clock64();
     uint32_t* o = trace + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
     o[0] = tr_tile; o[1] = tr_len; o[2] = tr.batches; o[3] = tr.survivors; o[4] = tr.blends;
@@ -1080,76 +1129,40 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
   }
 }
 
-// Producer/consumer wave pairs for the few longest tiles (GRPG_RENDER_PC=0 turns them off):
-// class 0 then means >= GRPG_PC_MUL x heavy_min entries (default 32 -> 8192) and classes 1, 2
-// >= 8x / >= 1x heavy_min; without it the classes are >= 8x, >= 2x, >= 1x (LPT order only).
-bool render_pc_enabled() {
-  static const int pc = [] { const char* e = getenv("GRPG_RENDER_PC"); return e ? atoi(e) : 1; }();
-  return pc != 0;
-}
-uint32_t render_pc_mul() {
-  static const uint32_t m = [] { const char* e = getenv("GRPG_PC_MUL"); return e ? (uint32_t)atoi(e) : 32u; }();
-  return m < 1u ? 1u : m;
-}
-// workgroups reserved for half tiles of class 0: at most R / (pc_mul * heavy_min) tiles can be
-// that long, two workgroups each; 0 = producer/consumer mode off.  The forward and the backward of
-// one frame must agree (both derive it from num_rendered and the same environment).
-uint32_t render_pc_slots(uint32_t R, uint32_t heavy_min) {
-  if (!render_pc_enabled()) return 0u;
-  return 2u * (uint32_t)((size_t)R / ((size_t)render_pc_mul() * heavy_min) + 1);
-}
-
-// Class thresholds of the work lists, as multiples of heavy_min (see classify_tiles_kernel).
-void render_class_multipliers(uint32_t* c0_mul, uint32_t* c1_mul) {
-  const bool pc = render_pc_enabled();
-  *c0_mul = pc ? render_pc_mul() : 8u;
-  *c1_mul = pc ? 8u : 2u;
-}
+// workgroups reserved for half tiles of class 0 (producer / consumer wave pairs): at most
+// R / RENDER_PC_MIN tiles can be that long, two workgroups each.  The forward and the backward of one
+// frame agree on it (both derive it from num_rendered).
+uint32_t render_pc_slots(uint32_t R) { return 2u * (uint32_t)((size_t)R / RENDER_PC_MIN + 1); }
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,
                            float* out_color, float* out_depth, float* out_alpha,
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
-                           uint32_t heavy_min, uint32_t R, bool aux, bool classified,
-                           const CkptArgs* ckp, const PCErr pc_err) {
+                           const TileClasses cls, uint32_t R, bool aux, bool classified,
+                           const CkptArgs* ckp, const PCErr pc_err, const float* semantics, int S,
+                           float* out_semantic) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   const CkptArgs ck = (aux && ckp) ? *ckp : CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
-  // work[0..3] were zeroed by write_headers_kernel (same stream, earlier in the frame)
-  const bool pc = render_pc_enabled();
-  const uint32_t pc_mul = render_pc_mul();
-  const uint32_t pc_slots = render_pc_slots(R, heavy_min);
-  // GRPG_RENDER_LDS_PAD (experiment): unused dynamic LDS per workgroup, to cap the kernel's occupancy
-  static const uint32_t lds_pad = [] { const char* e = getenv("GRPG_RENDER_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
+  // work[0..3] were zeroed by frame_init_kernel (same stream, earlier in the frame)
+  const uint32_t pc_slots = render_pc_slots(R);
   // classified: the hierarchical binning's tile scan has already built the work lists
   if (!classified)
-    classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, heavy_min,
-                                                              pc ? pc_mul : 8u, pc ? 8u : 2u, work);
-  // measured: OFF is faster (render 0.232 vs 0.248 ms) -- neighbouring tiles are also similarly
-  // LONG, so a contiguous eighth of a list per XCD unbalances the XCDs by more than the L2 hits save
-  static const int xcd = [] { const char* e = getenv("GRPG_XCD_SWIZZLE"); return e ? atoi(e) : 0; }();
+    classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, cls, work);
+  const SemSrc sem = {semantics, S};
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
   // aux == false (no backward will follow): n_contrib is neither tracked nor written
-#define RF_LAUNCH(GL)                                                                          \
-  do {                                                                                         \
-    if (aux)                                                                                   \
-      render_forward_kernel<true, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                        \
-          ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots, xcd, ck, pc_err);                                     \
-    else                                                                                       \
-      render_forward_kernel<false, GL><<<ntiles + pc_slots, 256, lds_pad, s>>>(                       \
-          ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,  \
-          out_alpha, n_contrib, pc_slots, xcd, ck, pc_err);                                     \
-  } while (0)
+#define RF_ARGS ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, \
+                out_alpha, n_contrib, pc_slots, ck, pc_err, sem, out_semantic
+#ifdef GRPG_TRACE   // experiment build: per-wave cycle counts and survivor statistics to a file
   static const char* trace_path = getenv("GRPG_RENDER_TRACE");
-  if (trace_path) {   // debug tool: per-wave cycle counts and survivor statistics to a file
+  if (trace_path && S == 0) {
     uint32_t* d_trace = nullptr;
     const size_t words = (size_t)(ntiles + pc_slots) * RW_WAVES * 17;
     if (hipMalloc((void**)&d_trace, words * 4) == hipSuccess) {
       (void)hipMemsetAsync(d_trace, 0xFF, words * 4, s);
-      render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, lds_pad, s>>>(
-          ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth,
-          out_alpha, n_contrib, pc_slots, xcd, ck, pc_err, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
+      render_forward_kernel<true, 1, true><<<ntiles + pc_slots, 256, 0, s>>>(
+          RF_ARGS, d_trace, getenv("GRPG_RENDER_ABLATE") ? atoi(getenv("GRPG_RENDER_ABLATE")) : 0);
       std::vector<uint32_t> h(words);
       (void)hipMemcpyAsync(h.data(), d_trace, words * 4, hipMemcpyDeviceToHost, s);
       (void)hipStreamSynchronize(s);
@@ -1158,22 +1171,31 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
       return;
     }
   }
-  // splats per inner iteration of the light (4 pixels per lane) path; the heavy path always
-  // evaluates quads.  GRPG_RENDER_VARIANT=1 selects 1 (experiment switch; 2 measured best).
-  static const int variant = [] { const char* e = getenv("GRPG_RENDER_VARIANT"); return e ? atoi(e) : 0; }();
-  if (variant == 1) RF_LAUNCH(1);
-  else RF_LAUNCH(2);
-#undef RF_LAUNCH
+#endif
+  // the light (4 pixels per lane) path evaluates two splats per inner iteration (one: measured
+  // slower); the heavy path always evaluates quads
+  if (S > 0) {
+    // semantic planes ride in the heavy path: up to RENDER_NSEM channels in this launch, the rest
+    // (S > RENDER_NSEM) in the stand-alone kernel below
+    if (aux) render_forward_kernel<true, 2, false, RENDER_NSEM><<<ntiles + pc_slots, 256, 0, s>>>(RF_ARGS);
+    else render_forward_kernel<false, 2, false, RENDER_NSEM><<<ntiles + pc_slots, 256, 0, s>>>(RF_ARGS);
+  } else {
+    if (aux) render_forward_kernel<true, 2><<<ntiles + pc_slots, 256, 0, s>>>(RF_ARGS);
+    else render_forward_kernel<false, 2><<<ntiles + pc_slots, 256, 0, s>>>(RF_ARGS);
+  }
+#undef RF_ARGS
 }
 
+// channels [c_begin, S) of the semantic planes by the stand-alone kernel (the first RENDER_NSEM ride
+// in the main render launch)
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                            const RecView rec, const float* semantics, int S, int W, int H, int gx,
-                            int gy, float* out_semantic) {
+                            const RecView rec, const float* semantics, int S, int c_begin, int W, int H,
+                            int gx, int gy, float* out_semantic) {
   const int ntiles = gx * gy;
-  if (ntiles <= 0 || S <= 0) return;
+  if (ntiles <= 0 || S <= c_begin) return;
   const int blocks = (ntiles + RW_WAVES - 1) / RW_WAVES;
   constexpr int NCH = 4;
-  for (int c0 = 0; c0 < S; c0 += NCH)
+  for (int c0 = c_begin; c0 < S; c0 += NCH)
     render_semantic_kernel<NCH><<<blocks, 256, 0, s>>>(ranges, point_list, rec, semantics, S, c0,
                                                        W, H, gx, ntiles, out_semantic);
 }

@@ -820,6 +820,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     if (grpg_set_binning_mode(mode) != GRPG_OK) raise_abi_error("grpg_set_binning_mode", -1);
   });
   m.def("reset_capacity_hints", []() { grpg_reset_capacity_hints(); });
+  // (P, width, height, instances, coarse pairs): exact capacities for the next forward of that shape
+  m.def("set_capacity_hint", [](int P, int W, int H, unsigned R, unsigned Rc) {
+    const int rc = grpg_set_capacity_hint(P, W, H, R, Rc);
+    if (rc != GRPG_OK) raise_abi_error("grpg_set_capacity_hint", rc);
+  });
   m.def("get_binning_algorithm", []() { return grpg_get_binning_algorithm(); });
   m.def("set_binning_algorithm", [](int alg) {
     if (grpg_set_binning_algorithm(alg) != GRPG_OK) raise_abi_error("grpg_set_binning_algorithm", -1);

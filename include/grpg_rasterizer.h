@@ -323,6 +323,15 @@ GRPG_API int grpg_set_binning_mode(int mode);
 /* Forget the remembered num_rendered high-water marks (the next grpg_forward of every shape waits
  * for the count before it sizes the binning blob). */
 GRPG_API int grpg_reset_capacity_hints(void);
+/* Tell the library what to expect of the NEXT forward of a shape (P, width, height) on the current
+ * device: its binning blob is carved for exactly `instances` tile instances and `coarse_pairs`
+ * (Gaussian, super-tile) pairs (each at least 1; coarse_pairs is ignored by the sort-based binning) and
+ * the frame is enqueued without the first-frame wait for the count -- a caller that knows a scene's
+ * num_rendered from an earlier run skips the synchronous first frame.  One-shot: the frame after
+ * that goes by the remembered marks again.  A frame that outgrows what it was promised is rendered
+ * again by grpg_forward itself (grpg_forward_deferred: GRPG_ERR_CAPACITY), like any capacity overflow;
+ * the tests use that to drive the overflow paths. */
+GRPG_API int grpg_set_capacity_hint(int P, int width, int height, unsigned instances, unsigned coarse_pairs);
 /* Tile binning algorithm of grpg_forward (process-wide): GRPG_BINNING_ALG_HIER (default;
  * csrc/hier_binning.hip: coarse (Gaussian, 8x8-tile super-tile) pairs partitioned by super-tile,
  * then per-tile counts and a direct fill of the point list) or GRPG_BINNING_ALG_SORT (environment

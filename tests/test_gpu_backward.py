@@ -194,8 +194,10 @@ def test_backward_long_lists_partial_tiles(dev):
          miss_frac=STRICT_MISS_FRAC_LONG_LISTS)
 
 
-def _long_list_gradients(dev, backward_twice=False):
-    """Gradients of the 10-18 k-entry scene for a fixed loss; no oracle (used to compare schedules)."""
+def _long_list_gradients(dev, backward_twice=False, with_semantic_plane=False):
+    """Gradients of the 10-18 k-entry scene for a fixed loss; no oracle (used to compare schedules).
+    with_semantic_plane: one semantic channel the loss does not touch rides along -- same gradients,
+    but a semantic frame leaves no blend checkpoints, so the backward walks every list as one chain."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     sc = hz.toy_scene(40000, seed=21, sh_degree=1, depth=6.0, spread=0.8, scale=0.015)
     cam = hz.trajectory_camera(0, W=64, H=64, device=dev)
@@ -206,8 +208,9 @@ def _long_list_gradients(dev, backward_twice=False):
     leaves = [t.to(dev).clone().requires_grad_(True)
               for t in (sc.means3D, sc.opacity, sc.shs, sc.scales, sc.rotations)]
     means2D = torch.zeros(sc.means3D.shape[0], 3, device=dev, requires_grad=True)
+    sem = torch.rand(sc.means3D.shape[0], 1, generator=g).to(dev) if with_semantic_plane else None
     color, radii, depth, alpha, _ = rast(means3D=leaves[0], means2D=means2D, opacities=leaves[1],
-                                         shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+                                         shs=leaves[2], scales=leaves[3], rotations=leaves[4], semantics=sem)
     loss = (color * gc).sum() + 0.1 * (depth * gd).sum() + (alpha * ga).sum()
     out = []
     for _ in range(2 if backward_twice else 1):
@@ -271,42 +274,38 @@ def test_backward_twice_on_one_forward(dev):
         assert np.isfinite(a).all() and _rel_l2(a, b) < 1e-5
 
 
-def test_backward_segments_match_single_chain(dev, tmp_path):
-    """The segmented walk of long lists (forward checkpoints, default) against the same library
-    walking every list as one chain (GRPG_BWD_SEG=0, read once per process: a child process)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    out = str(tmp_path / "chain.npz")
-    code = ("import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
-            "import test_gpu_backward as t\n"
-            "g = t._long_list_gradients(torch.device('cuda:0'))[0]\n"
-            "np.savez(%r, *g)\n" % (here, os.path.dirname(here), out))
-    env = dict(os.environ, GRPG_BWD_SEG="0")
-    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
-    chain = np.load(out)
+def test_backward_segments_match_single_chain(dev):
+    """The segmented walk of long lists (blend checkpoints left by the training forward) against the
+    single-chain walk of the same lists.  The chain walk is what a frame WITH semantic planes gets (it
+    leaves no checkpoints, csrc/api.hip with_ckpt): the same scene with one semantic channel the loss
+    ignores must give the same gradients to rounding."""
     seg = _long_list_gradients(dev)[0]
-    for i, a in enumerate(seg):
-        b = chain["arr_%d" % i]
+    chain = _long_list_gradients(dev, with_semantic_plane=True)[0]
+    for i, (a, b) in enumerate(zip(seg, chain)):
         assert _rel_l2(a, b) < 2e-4, (i, _rel_l2(a, b))
 
 
-@pytest.mark.parametrize("env", [{"GRPG_BINNING": "sort"}, {"GRPG_RENDER_PC": "0"}, {"GRPG_PC_MUL": "1"},
-                                 {"GRPG_RCAP_TEST": "3000"}, {"GRPG_BWD_WIDE": "0"}, {"GRPG_BWD_LIGHT": "4"}])
-def test_backward_alternative_code_paths(env):
-    """Switches read once per process, hence a child process each: the sort-based binning blob (other
-    layout in front of the checkpoints); long tiles without / only with producer-consumer pairs in
-    the forward (the consumer writes the checkpoints there); a capacity guess every frame overflows,
-    so the checkpoints come from the re-run tail; quarter waves for every heavy tile; one wave per
-    light tile."""
-    import os
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "test_backward_long_lists or test_backward_street or test_backward_twice"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("path", ["sort_binning", "overflow"])
+def test_backward_alternative_code_paths(dev, path):
+    """The sort-based binning blob (another layout in front of the checkpoints) and a binning blob
+    promised too little (grpg_set_capacity_hint), so that the training forward overflows and the
+    checkpoints come from its re-run tail: long-list and street gradients against the oracle."""
+    from gaussianrpg_amd.rasterizer import _C
+    alg = _C.get_binning_algorithm()
+    try:
+        if path == "sort_binning":
+            _C.set_binning_algorithm(0)
+        for sc, cam, bg, seed, mf in (
+                (hz.toy_scene(40000, seed=21, sh_degree=1, depth=6.0, spread=0.8, scale=0.015),
+                 hz.trajectory_camera(0, W=64, H=64), torch.tensor([0.1, 0.4, 0.2]), 11, STRICT_MISS_FRAC_LONG_LISTS),
+                (hz.street_scene(30000, seed=31), hz.trajectory_camera(5, W=480, H=320), torch.zeros(3), 5,
+                 STRICT_MISS_FRAC)):
+            if path == "overflow":
+                _C.set_capacity_hint(sc.means3D.shape[0], cam.image_width, cam.image_height, 3000, 3000)
+            _run(dev, sc, cam, bg, seed=seed, miss_frac=mf)
+    finally:
+        _C.set_binning_algorithm(alg)
+        _C.reset_capacity_hints()
 
 
 def test_backward_colors_and_cov_precomp(dev):

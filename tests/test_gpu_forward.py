@@ -125,9 +125,10 @@ def test_forward_matches_committed_golden(dev, name):
             assert_image_close(k, got[k], fx[k], fx["fragile"])
 
 
-@pytest.mark.parametrize("S", [3, 15])
+@pytest.mark.parametrize("S", [3, 15, 20])
 def test_semantic_channels(dev, S):
-    # script/test_gaussian_rasterization.py:73-87 runs S=15
+    # script/test_gaussian_rasterization.py:73-87 runs S=15; up to 16 channels ride in the render
+    # launch (csrc/render_fwd.hip SemAcc), S = 20 adds the stand-alone kernel for channels 16..19
     sc, cam = hz.toy_scene(2000, seed=12, sh_degree=1), hz.trajectory_camera(0, W=160, H=96)
     sem = torch.rand(2000, S, generator=torch.Generator().manual_seed(S))
     o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
@@ -462,28 +463,52 @@ def test_streams_and_threads_give_identical_frames(dev):
         assert torch.equal(out2[i], ref[i])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"GRPG_RENDER_PC": "0"}, {"GRPG_PC_MUL": "1"},
-                                 {"GRPG_RENDER_VARIANT": "1", "GRPG_HEAVY_MIN": "64"},
-                                 {"GRPG_SYNC_R": "1"},
-                                 {"GRPG_RCAP_TEST": "3000"}, {"GRPG_RCAP_TEST": "3000:3000000"},
-                                 {"GRPG_BINNING": "sort"},
-                                 {"GRPG_BINNING": "sort", "GRPG_RCAP_TEST": "3000"}])
-def test_alternative_code_paths(env):
-    """The experiment switches are read once per process, so the parity cases are re-run in a
-    subprocess: no producer/consumer pairs; pairs for EVERY heavy tile; light path with one splat
-    per iteration and a low heavy threshold; the
-    reference-like mid-frame wait for num_rendered (exact binning-blob size); a binning capacity
-    guess of 3000 instances, so that every frame overflows it and re-runs its tail (hierarchical
-    binning: first with the coarse list overflowing too, then with only the point list); the sort-based
-    binning (emit + stable partition) instead of the hierarchical one, also with overflows.  (The
-    classic depth-sort passes with their separate count publish, and the coarse scan's rectangle
-    gather, are reached by inputs: test_more_than_4M_gaussians_..., test_grid_wider_than_255_tiles.)"""
-    import os
-    import subprocess
-    import sys
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
-                        "-k", "test_forward_matches_oracle or test_giant_splat"],
-                       env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+@pytest.fixture
+def restore_policy():
+    """Binning policy switches are process-wide: put the defaults back whatever the test did."""
+    from gaussianrpg_amd.rasterizer import _C
+    alg = _C.get_binning_algorithm()
+    yield _C
+    _C.set_binning_mode(0)
+    _C.set_binning_algorithm(alg)
+    _C.reset_capacity_hints()
+
+
+ALT_PATHS = {
+    # the reference-like schedule: wait for num_rendered in mid-frame, carve the exact size
+    "exact_mode": dict(mode=1),
+    # a binning blob promised 3000 instances / 3000 coarse pairs: every frame overflows both and re-runs
+    # its tail (hierarchical binning: the count comes from the classic scan first)
+    "overflow_both": dict(hint=(3000, 3000)),
+    # only the point list overflows
+    "overflow_instances": dict(hint=(3000, 3_000_000)),
+    # emit + stable partition instead of the hierarchical binning
+    "sort_binning": dict(alg=0),
+    "sort_binning_overflow": dict(alg=0, hint=(3000, 3000)),
+}
+
+
+@pytest.mark.parametrize("path", list(ALT_PATHS))
+def test_alternative_code_paths(dev, restore_policy, path):
+    """The parity cases through the schedules the defaults do not take, selected through the
+    library's own (documented, additive) policy calls -- grpg_set_binning_mode,
+    grpg_set_binning_algorithm, grpg_set_capacity_hint -- in this process.  (The classic depth-sort
+    passes with their separate count publish, the coarse scan's rectangle gather and the fourth sort
+    pass are reached by inputs: test_more_than_4M_gaussians_..., test_grid_wider_than_255_tiles,
+    test_depth_range_beyond_27_bits_....)"""
+    _C = restore_policy
+    cfg = ALT_PATHS[path]
+    if "mode" in cfg:
+        _C.set_binning_mode(cfg["mode"])
+    if "alg" in cfg:
+        _C.set_binning_algorithm(cfg["alg"])
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    for case in CASES:
+        sc, cam = CASES[case]()
+        o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                           **oracle_kwargs(cam, sc.sh_degree, bg=bg))
+        if "hint" in cfg:   # consumed by the first of _rasterize's two calls; the second takes the normal
+            # path and must give bit-identical outputs (asserted inside _rasterize)
+            _C.set_capacity_hint(sc.means3D.shape[0], cam.image_width, cam.image_height, *cfg["hint"])
+        got = _rasterize(dev, sc, cam, bg=bg)
+        _check(got, o, max_fragile_frac=0.2 if case == "smoke_overdraw" else 0.05)

@@ -1,5 +1,8 @@
 """Debug tool (GPU box): dump per-wave cycle counts of the render kernel for bench frame 0.
-usage: GRPG_RENDER_TRACE=gpurun_out/trace.bin python tools/trace_render.py"""
+The trace code only exists in the experiment build (python -c "from gaussianrpg_amd import build;
+build.build_variant('trace')"):
+usage: LD_PRELOAD=$PWD/build/variants/libgrpg_rasterizer_trace.so GRPG_RENDER_TRACE=gpurun_out/trace.bin \
+       python tools/trace_render.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
