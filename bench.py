@@ -30,7 +30,7 @@ Extra objects in the line:
                   HIP events on the op's stream around the launch with one frame in flight (a pass of
                   20 frames right behind the timed region; agrees with the rocprofv3 average committed
                   under profiles/), vs 8 TB/s.  `traffic` = HBM bytes per launch from the committed PMC
-                  passes of this round (profiles/round3_traffic.json), null if absent.
+                  passes of this round (profiles/round4_traffic.json), null if absent.
   roofline_overlapped  the same kernel's wall duration INSIDE the timed region, where several
                   frames share the chip: time-sharing, not the kernel's speed.
   roofline_valu   the render kernel's real bound: VALU busy time from the committed PMC pass
@@ -86,6 +86,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=P_GAUSS, help="override P (debugging only)")
+    ap.add_argument("--checkpoint", default=None,
+                    help="a trained scene of the reference instead of the synthetic one: trained_model/"
+                         "iteration_N.pth (StreetGaussianModel.save_state_dict) or point_cloud.ply; the "
+                         "static models (background) are rendered along the synthetic drive "
+                         "(gaussianrpg_amd/checkpoint.py).  Not the BASELINE workload: reported as data = "
+                         "'checkpoint:<file>'")
+    ap.add_argument("--checkpoint-models", default=None,
+                    help="comma-separated model names to render (default: every static model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the config-5 fwd+bwd side leg")
@@ -386,7 +394,19 @@ def main():
     global STAGES
     STAGES = STAGES_HIER if _C.get_binning_algorithm() == 1 else STAGES_SORT
 
-    scene_cpu = hz.street_scene(args.gaussians, seed=SCENE_SEED, sh_degree=1)
+    if args.checkpoint:
+        from gaussianrpg_amd import checkpoint as ckpt
+        loaded = ckpt.load_checkpoint(args.checkpoint)
+        names = args.checkpoint_models.split(",") if args.checkpoint_models else None
+        scene_cpu = ckpt.activated_scene(loaded, names)
+        if rank == 0:
+            print("checkpoint %s: models %s, rendering %d Gaussians, SH degree %d" % (
+                args.checkpoint, {n: loaded.num_gaussians([n]) for n in loaded.names()},
+                scene_cpu.means3D.shape[0], scene_cpu.sh_degree), file=sys.stderr, flush=True)
+        args.no_train = True          # the train leg and the CPU baseline are defined on the synthetic scenes
+        args.no_cpu_baseline = True
+    else:
+        scene_cpu = hz.street_scene(args.gaussians, seed=SCENE_SEED, sh_degree=1)
     sc = scene_cpu.to(dev)
     P = sc.means3D.shape[0]
     M = sc.shs.shape[1]
@@ -696,7 +716,7 @@ def main():
         # MI355X_MICROARCH.md prescribes), if a profile of this same workload AND this round's kernels
         # has been committed; otherwise null.  Not measurable inside this process.
         traffic, pmc, pmc_file = None, None, None
-        for name in ("round3_traffic.json",):
+        for name in ("round4_traffic.json", "round3_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 wl = tr.get("workload", {})
@@ -772,10 +792,13 @@ def main():
             "metric": "frames/sec @1920x1280, ~2M Gaussians; achieved HBM GB/s vs peak",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: scene-002-like synthetic street scene (seed %d), "
+            "vs_baseline": None, "dtype": "f32",
+            "data": ("checkpoint:" + os.path.basename(args.checkpoint)) if args.checkpoint else "synthetic",
+            "config": {"workload": (("trained scene %s (static models), " % os.path.basename(args.checkpoint))
+                                    if args.checkpoint else
+                                    "configs[2]: scene-002-like synthetic street scene (seed %d), " % SCENE_SEED) +
                                    "forward op + clamp + uint8 pack per frame, %d-pose drive, "
-                                   "frames sharded round-robin over ranks" % (SCENE_SEED, NUM_FRAMES),
+                                   "frames sharded round-robin over ranks" % NUM_FRAMES,
                        "P": P, "V_avg": V_avg, "R_avg": R_avg, "T": T_tiles, "width": W,
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
                        "streams_per_gpu": ns, "binning_mode": "exact" if args.binning_mode else "speculative",

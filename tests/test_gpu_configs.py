@@ -421,3 +421,47 @@ def test_direct_cabi_forward_call(dev):
     np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
     assert_image_close("color", color.cpu().numpy(), o["color"], o["fragile"])
     assert len(keep) == 3      # geometry, image and binning blobs, each requested once (no overflow here)
+
+
+@pytest.mark.gpu
+def test_trained_model_files_render(dev, tmp_path):
+    """A scene stored the way the reference stores trained models (.pth state dict and point_cloud.ply,
+    gaussianrpg_amd/checkpoint.py) comes back through the loader and renders like the oracle renders
+    the activated tensors; the actors of the same file join through the fused composition."""
+    from gaussianrpg_amd import checkpoint as ckpt
+    from gaussianrpg_amd.composed import ActorPose, ComposedRasterizer, ModelParams
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.street_scene(20000, seed=3)
+    op = sc.opacity.clamp(1e-6, 1 - 1e-6)
+    bgm = ModelParams(sc.means3D, torch.log(sc.scales), sc.rotations, torch.log(op / (1 - op)),
+                      sc.shs[:, :1, :].contiguous(), sc.shs[:, 1:, :].contiguous())
+    g = torch.Generator().manual_seed(1)
+    car = ModelParams(torch.randn(300, 3, generator=g) * torch.tensor([2.0, 0.8, 0.7]),
+                      torch.randn(300, 3, generator=g) * 0.3 - 2.5, torch.randn(300, 4, generator=g),
+                      torch.randn(300, 1, generator=g) + 1.0, torch.rand(300, 3, 3, generator=g),
+                      0.1 * torch.randn(300, 3, 3, generator=g))
+    models = {"background": bgm, "obj_001": car}
+    cam = hz.trajectory_camera(3, W=480, H=320)
+    camd = hz.trajectory_camera(3, W=480, H=320, device=dev)
+    for fname in ("iteration_1.pth", "point_cloud.ply"):
+        path = str(tmp_path / fname)
+        if fname.endswith(".ply"):
+            ckpt.write_ply(path, models)
+        else:
+            torch.save(ckpt.state_dict_of(models), path)
+        loaded = ckpt.load_checkpoint(path)
+        assert loaded.names() == ["background", "obj_001"]
+        flat = ckpt.activated_scene(loaded)              # the static model
+        o = oracle.forward(flat.means3D, flat.opacity, shs=flat.shs, scales=flat.scales,
+                           rotations=flat.rotations, **oracle_kwargs(cam, 1))
+        d = flat.to(dev)
+        rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 1)))
+        color, radii, depth, alpha, _ = rast(means3D=d.means3D, means2D=None, opacities=d.opacity, shs=d.shs,
+                                             scales=d.scales, rotations=d.rotations)
+        np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+        assert_image_close("color", color.cpu().numpy(), o["color"], o["fragile"])
+        # background + the actor, placed 12 m ahead: the fused composition takes the raw parameters
+        ms, ps = ckpt.scene_models(loaded, dev, poses={"obj_001": ActorPose([1.0, 0, 0, 0], [0.5, 1.0, 12.0], 0.25)})
+        c2, r2, d2, a2 = ComposedRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 1)))(ms, ps)
+        assert r2.shape[0] == 20300 and int((r2[20000:] > 0).sum()) > 100
+        assert torch.equal(r2[:20000], radii) and float((c2 - color).abs().max()) > 1e-3   # the car is in the picture
