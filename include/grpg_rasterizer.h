@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRPG_ABI_VERSION 3
+#define GRPG_ABI_VERSION 4   /* 4: grpg_set_capacity_hint, asynchronous-error reporting, backward argument checks */
 
 /* Exported symbol (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -53,9 +53,15 @@ enum {
   GRPG_OK = 0,
   GRPG_ERR_INVALID_ARGUMENT = -1,
   GRPG_ERR_NO_DEVICE = -2,
-  GRPG_ERR_HIP = -3,        /* a HIP call or kernel failed; see grpg_last_error() */
+  GRPG_ERR_HIP = -3,        /* a HIP call or kernel failed; see grpg_last_error().  Also how an ASYNCHRONOUS
+                             * device-side failure of an earlier frame surfaces (today: a producer / consumer
+                             * hand-over of the render that timed out): the next forward / backward /
+                             * frame-status call of the thread fails with it, once -- that earlier frame's
+                             * image is invalid.  debug = 1: the forward that suffered it fails itself. */
   GRPG_ERR_ALLOC = -4,      /* a grpg_alloc_fn returned NULL */
-  GRPG_ERR_BAD_BUFFER = -5, /* a blob handed to grpg_backward was not produced by grpg_forward */
+  GRPG_ERR_BAD_BUFFER = -5, /* a blob handed to grpg_backward was not produced by grpg_forward -- or by a
+                             * forward that said no backward would follow (GRPG_FORWARD_NO_BACKWARD: its
+                             * geometry blob has no room for the backward's gradient records) */
   GRPG_ERR_CAPACITY = -6,   /* grpg_frame_status: the deferred frame overflowed its capacity; redo it */
   GRPG_ERR_NOT_READY = -7   /* grpg_frame_status(wait = 0): the frame's count has not arrived yet */
 };
@@ -347,7 +353,10 @@ GRPG_API int grpg_set_binning_algorithm(int alg);
  * R is the value grpg_forward returned.  geom/binning/image buffers are the blobs it filled -- by
  * grpg_forward or grpg_forward_flags WITHOUT GRPG_FORWARD_NO_BACKWARD (an evaluation frame's
  * geometry blob has no room for the gradient records the backward accumulates in its tail; the
- * geometry blob is therefore written by this call, the other two are only read).
+ * geometry blob is therefore written by this call, the other two are only read).  The library
+ * remembers which of the last 64 geometry blobs were carved with that room and refuses a blob it knows
+ * to lack it (GRPG_ERR_BAD_BUFFER) instead of writing out of bounds; debug = 1 additionally reads the
+ * blobs' headers (has_grad_rec, pc_timeout, P / R / W / H).
  * A forward a backward may follow (S == 0) also asks its binning callback for room behind the
  * point list for blend checkpoints of the tile lists with >= 4096 entries (6 KB per 1365 instances of
  * capacity): the backward starts independent walks from them instead of walking
@@ -362,7 +371,11 @@ GRPG_API int grpg_set_binning_algorithm(int alg);
  * for culled Gaussians), so they may arrive uninitialised -- a caller that zero-fills all eleven
  * like the reference's binding gets the same results.  dL_dconic and dL_ddepth (intermediates the
  * reference's binding never returns), dL_dcolor without colors_precomp and dL_dcov3D without
- * cov3D_precomp may be NULL: they are then not written (saves their HBM traffic).
+ * cov3D_precomp may be NULL: they are then not written (saves their HBM traffic); non-NULL they
+ * receive what the reference's binding returns in them (the per-Gaussian colour gradient, the 3D
+ * covariance gradient).  The gradient array of every input in use must be there: dL_dmean2D,
+ * dL_dopacity, dL_dmean3D always; dL_dsh with shs, dL_dcolor with colors_precomp, dL_dscale and
+ * dL_drot with scales / rotations, dL_dcov3D with cov3D_precomp (GRPG_ERR_INVALID_ARGUMENT otherwise).
  * Returns GRPG_OK or a negative GRPG_ERR_*.
  */
 GRPG_API int grpg_backward(int P, int D, int M, int R, int S,

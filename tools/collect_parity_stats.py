@@ -1,0 +1,31 @@
+"""Turn the parity statistics a GPU test run leaves in gpurun_out/parity_stats_<pid>.json (tests/conftest.py)
+into the tracked profiles/<tag>_parity_stats.json: every compared plane, plus a summary of what the
+fragile-pixel / fragile-Gaussian exemptions hide.   usage: python tools/collect_parity_stats.py <tag> <file>..."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, files = sys.argv[1], sys.argv[2:]
+recs = []
+for f in files:
+    recs += json.load(open(f))
+img = [r for r in recs if "frac_beyond_1e4" in r]
+grd = [r for r in recs if "nonexempt_elements" in r]
+summary = {
+    "image_planes_compared": len(img),
+    "image_values_compared": sum(r["pixels"] for r in img),
+    "image_values_beyond_1e-4 (fragile pixels INCLUDED)": sum(r["beyond_1e4"] for r in img),
+    "worst_plane_share_beyond_1e-4": max((r["frac_beyond_1e4"] for r in img), default=0.0),
+    "worst_relative_error_any_pixel": max((r["max_rel_err"] for r in img), default=0.0),
+    "fragile_pixel_share_min_max": [min((r["fragile_frac"] for r in img if r["fragile_frac"] is not None), default=None),
+                                    max((r["fragile_frac"] for r in img if r["fragile_frac"] is not None), default=None)],
+    "gradient_arrays_compared": len(grd),
+    "gradient_rel_l2_max": max((r["rel_l2"] for r in grd), default=0.0),
+    "gradient_elements_of_non_exempt_gaussians": sum(r["nonexempt_elements"] for r in grd),
+    "of_which_beyond_rtol1e-3_atol1e-5": sum(r["nonexempt_beyond_strict"] for r in grd),
+    "worst_array_share_beyond (non-exempt)": max((r["nonexempt_beyond_strict"] / max(r["nonexempt_elements"], 1) for r in grd), default=0.0),
+    "worst_non_exempt_element_over_bar": max((r.get("nonexempt_worst_over_bar", 0.0) for r in grd), default=0.0),
+    "exempt_gaussian_share_min_max": [min((r["exempt_gaussians_frac"] for r in grd), default=None),
+                                      max((r["exempt_gaussians_frac"] for r in grd), default=None)],
+}
+out = os.path.join(ROOT, "profiles", "%s_parity_stats.json" % tag)
+json.dump({"summary": summary, "records": recs}, open(out, "w"), indent=1)
+print(json.dumps(summary, indent=1))

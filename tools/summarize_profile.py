@@ -32,6 +32,21 @@ for r in rows:
     lines.append("%10.1f %8.1f %10.1f  %s" % (per, int(r["Calls"]) / nf, float(r["AverageNs"]) / 1000,
                                              r["Name"].split("(")[0][-70:]))
 lines.append("%10.1f  total GPU-busy us per frame" % tot)
+# the default command runs priming + warm-up + timed frames over three streams (kernels of several
+# frames share the chip: a launch's wall time is not its own speed) and then single-stream passes
+# (statistics, stage timing, latency): the render kernel's duration distribution separates the two
+try:
+    tr = [r for r in csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_trace.csv")))
+          if "render_forward_kernel<false" in r["Kernel_Name"]]
+    d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr)
+    q = lambda f: d[min(len(d) - 1, int(f * len(d)))]   # noqa: E731
+    solo = [x for x in d if x <= 1.08 * q(0.5)]
+    lines += ["", "# render_forward_kernel<false,...> launch durations (us), %d launches: min %.1f  p25 %.1f  median %.1f  "
+              "p75 %.1f  p90 %.1f  max %.1f" % (len(d), d[0], q(0.25), q(0.5), q(0.75), q(0.9), d[-1]),
+              "# launches with one frame in flight (within 8 %% of the median): %d, mean %.1f us;"
+              " the others ran inside the three-stream region" % (len(solo), sum(solo) / len(solo))]
+except Exception as exc:
+    lines.append("# (no kernel trace: %r)" % (exc,))
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(OUT, "prof_pmc*", "pmc_counter_collection.csv"))):
