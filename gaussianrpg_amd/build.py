@@ -134,6 +134,9 @@ EXPERIMENT_VARIANTS = {
     # per-wave trace of the render (GRPG_RENDER_TRACE=<file>, tools/trace_render.py) and the loop
     # counters / ablation switches of the blend backward (GRPG_BWD_STATS, GRPG_BWD_ABLATE)
     "trace": {"render_fwd.hip": ["-DGRPG_TRACE"], "render_bwd.hip": ["-DGRPG_TRACE"]},
+    # render capped at 3 / 2 workgroups per CU by unused LDS (does a second stream's kernel co-reside?)
+    "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
+    "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }
 
 

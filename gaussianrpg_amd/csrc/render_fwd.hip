@@ -951,6 +951,11 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
   __shared__ PCCtrl s_ctl[2];
+#ifdef GRPG_RENDER_LDS_PAD   // experiment build: unused LDS that caps the workgroups per CU
+  __shared__ uint32_t s_pad[GRPG_RENDER_LDS_PAD / 4];
+  if (W < 0) s_pad[threadIdx.x] = (uint32_t)H;   // never true: keeps the array allocated
+  if (W < -1) out_color[0] = (float)s_pad[0];
+#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WaveTrace tr = {0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
   const uint64_t t_start = TRACE ? wall_clock64() : 0;
