@@ -157,11 +157,18 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   uint32_t* __restrict__ ds_table0 /* [chunk][DS_RADIX] pass-0 counts of the fat depth sort, or NULL */,
                   uint4* __restrict__ pre_counts /* [workgroups] (instances, coarse pairs, min key, max key) */,
                   const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
+  // The 64-byte records leave through LDS: every thread stages its record, then the workgroup
+  // stores the 16 KB slab with consecutive lanes on consecutive 16-byte pieces (whole sectors, fully
+  // coalesced; a lane-per-record store would touch 64 sectors per instruction).  Culled Gaussians
+  // get an all-zero record (radius 0, opacity 0): nothing ever gathers it.
+  __shared__ float4 s_out[256 * REC_STRIDE];
   // means3D / scales arrive as [P,3] fp32: a lane-per-Gaussian read is three stride-12-byte dword
   // loads.  Stage the workgroup's 256 x 12 B = 3 KB per array through LDS with 16-byte loads
-  // instead (the slab of workgroup b starts at byte 3072*b, so it is 16-byte aligned).
-  __shared__ float s_mean[256 * 3];
-  __shared__ float s_scale[256 * 3];
+  // instead (the slab of workgroup b starts at byte 3072*b, so it is 16-byte aligned).  The staging
+  // area lives in the record slab's space (dead until the records are staged, a barrier in between):
+  // 18.5 KB of LDS per workgroup = 8 workgroups per CU instead of 6.
+  float* const s_mean = reinterpret_cast<float*>(s_out);
+  float* const s_scale = s_mean + 256 * 3;
   const int base = blockIdx.x * 256;
   const int nval = min(256, P - base) * 3;   // floats in this workgroup's slab
   {
@@ -180,11 +187,6 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
     }
   }
   __syncthreads();
-  // The 64-byte records leave through LDS as well: every thread stages its record, then the
-  // workgroup stores the 16 KB slab with consecutive lanes on consecutive 16-byte pieces (whole
-  // sectors, fully coalesced; a lane-per-record store would touch 64 sectors per instruction).
-  // Culled Gaussians get an all-zero record (radius 0, opacity 0): nothing ever gathers it.
-  __shared__ float4 s_out[256 * REC_STRIDE];
   // Pass-0 digit histogram of the depth sort (sort.hip, fat passes): the low DS_BITS bits of the
   // depth key of every VISIBLE Gaussian, aggregated per workgroup in LDS; the 256 Gaussians of a
   // workgroup lie in one 8192-key chunk, so it costs one global atomic per non-empty digit.
@@ -194,17 +196,31 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   const int idx = base + threadIdx.x;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   uint32_t my_key = CULLED_KEY, my_tiles = 0u, my_st = 0u;
+  float mx = 0.f, my = 0.f, mz = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (idx < P) {
-    const float mx = s_mean[3 * threadIdx.x], my = s_mean[3 * threadIdx.x + 1],
-                mz = s_mean[3 * threadIdx.x + 2];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    mx = s_mean[3 * threadIdx.x]; my = s_mean[3 * threadIdx.x + 1]; mz = s_mean[3 * threadIdx.x + 2];
     if (scales != nullptr) {
       s0 = s_scale[3 * threadIdx.x]; s1 = s_scale[3 * threadIdx.x + 1]; s2 = s_scale[3 * threadIdx.x + 2];
     }
+  }
+  __syncthreads();   // every thread holds its inputs: the staging area may become the record slab
+  if (idx < P) {
+    // degree <= 1 (every shipped config): the 48 B of SH coefficients as three 16-byte loads, issued
+    // BEFORE the projection arithmetic so that their latency hides behind it (a culled Gaussian's
+    // coefficients are then loaded for nothing: + 7 % of the kernel's bytes)
+    const bool sh_fast = colors_precomp == nullptr && M == 4 && vec_ok;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (sh_fast) {
+      const float4* sp = reinterpret_cast<const float4*>(shs + (size_t)idx * 12);
+      q0 = sp[0]; q1 = sp[1]; q2 = sp[2];
+    }
+    const float opac = opacities[idx];
+    const bool q_early = cov3D_precomp == nullptr;   // the quaternion too: one 16-byte load in flight early
+    const float4 quat = q_early ? load_quat(rotations, idx) : make_float4(1.f, 0.f, 0.f, 0.f);
     Projected o;
     const bool vis = project_and_bound(idx, mx, my, mz, s0, s1, s2, scale_modifier, rotations,
                                        cov3D_precomp, view, proj, W, H, gx, gy, tan_fovx, tan_fovy,
-                                       focal_x, focal_y, o);
+                                       focal_x, focal_y, o, q_early, quat);
     if (!vis) {
       radii[idx] = 0;
       tiles[idx] = 0;
@@ -216,9 +232,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
         const float dx = mx - campos[0];
         const float dy = my - campos[1];
         const float dz = mz - campos[2];
-        if (M == 4 && vec_ok) {   // degree <= 1, every shipped config: 48 B per Gaussian as three 16-byte loads
-          const float4* sp = reinterpret_cast<const float4*>(shs + (size_t)idx * 12);
-          const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+        if (sh_fast) {
           const float sh12[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
           sh_to_rgb(D > 1 ? 1 : D, sh12, dx, dy, dz, rgb, clamped);
         } else {
@@ -240,7 +254,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
       }
       depth_key[idx] = __float_as_uint(o.depth);
       my_key = __float_as_uint(o.depth);
-      r0 = make_float4(o.px, o.py, opacities[idx], __int_as_float(o.radius));
+      r0 = make_float4(o.px, o.py, opac, __int_as_float(o.radius));
       r1 = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
       r2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
     }
