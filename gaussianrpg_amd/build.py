@@ -135,6 +135,10 @@ EXPERIMENT_VARIANTS = {
     # counters / ablation switches of the blend backward (GRPG_BWD_STATS, GRPG_BWD_ABLATE)
     "trace": {"render_fwd.hip": ["-DGRPG_TRACE"], "render_bwd.hip": ["-DGRPG_TRACE"]},
     # render capped at 3 / 2 workgroups per CU by unused LDS (does a second stream's kernel co-reside?)
+    # num_rendered published by a launch of its own right behind preprocess instead of by the sort's first pass
+    "pubearly": {"api.hip": ["-DGRPG_PUBLISH_EARLY"]},
+    # the classic (256-thread, 21 KB of LDS) depth-sort passes for every P: does a small footprint overlap better?
+    "classicsort": {"api.hip": ["-DGRPG_FORCE_CLASSIC_SORT"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

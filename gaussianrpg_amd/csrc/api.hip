@@ -639,7 +639,11 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // With the fat depth sort the sum rides in its first pass (one launch fewer; the count arrives
     // ~35 us later, still long before the host has enqueued the frame); the classic sort of very
     // large P: the separate one-workgroup launch right here.
+#ifdef GRPG_PUBLISH_EARLY   // experiment build: the count by its own launch right behind preprocess
+    const bool fold_publish = false;
+#else
     const bool fold_publish = fat_sort;
+#endif
     if (!fold_publish) {
       launch_publish_counts(stream, pre_counts, (uint32_t)((P + 255) / 256), pub_ptr, &gh->R_pre);
       HIP_TRY(hipEventRecord(pub_ev, stream));
@@ -661,13 +665,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
         depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, key_c, val_c, ds_table,
                        GL.nchunks_ds, &gh->V, &gh->key_base, with_pass3,
                        rects, (uint32_t*)rect_sorted, offsets,
-                       (uint32_t*)(geom + GL.aux_c), rect_sorted, tiles_sorted, pre_counts, pnb, true,
+                       (uint32_t*)(geom + GL.aux_c), rect_sorted, tiles_sorted, pre_counts, pnb, fold_publish,
                        pub_ptr, &gh->R_pre, pub_ev);
       else
         depth_sort_fat(stream, (uint32_t)P, key_a, val_a, key_b, val_b, key_c, val_c, ds_table,
                        GL.nchunks_ds, &gh->V, &gh->key_base, with_pass3,
                        nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, pre_counts, pnb, true, pub_ptr, &gh->R_pre, pub_ev);
+                       nullptr, pre_counts, pnb, fold_publish, pub_ptr, &gh->R_pre, pub_ev);
       sorted_gid = val_a;
     } else {          // culled keys sort last (tile count 0); V stays P
       const bool in_b = radix_sort_pairs(stream, (uint32_t)P, nullptr, key_a, val_a, key_b, val_b, true,

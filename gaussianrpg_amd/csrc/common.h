@@ -144,7 +144,11 @@ constexpr int DS_WAVES = DS_THREADS / WAVE;       // 16
 constexpr int DS_BITS = 9;                        // three 9-bit passes over key - key_base (+ a fourth
 constexpr int DS_RADIX = 1 << DS_BITS;            // over the last 5 bits when the depth range needs it)
 constexpr int DS_PASSES = 4;
+#ifdef GRPG_FORCE_CLASSIC_SORT   // experiment build: the small-footprint classic passes for every P
+constexpr uint32_t DS_MAX_CHUNKS = 0;
+#else
 constexpr uint32_t DS_MAX_CHUNKS = 512;           // beyond (P > 4 M) the table sweep per workgroup grows
+#endif
                                                   // quadratically: classic three-kernel passes instead
 
 // One model of a composed scene as the kernels see it (device copy of grpg_model_segment).

@@ -29,7 +29,10 @@ def dev():
 # Share of the NON-exempt elements that may still miss the strict element-wise bar.  The reference
 # itself does not meet rtol 1e-3 on every element from run to run: its float atomics sum in an
 # unspecified order, and an element whose terms cancel (|sum| << sum of |terms|) carries the rounding
-# of the large terms; T is recovered by a chain of divisions whose error grows with the list length.
+# of the large terms; and its walk starts from T_final = 1 - alphas[pix] (backward.cu:468) with alphas
+# the float32 sum of the weights, which on nearly opaque pixels (dense scenes, long lists) is 1e-3 ..
+# 1e-2 off in relative terms -- the HIP forward writes alpha = 1 - T and does not share that error
+# (helpers.float64_truth_gradients; the sweep's contested arrays are settled against float64 autograd).
 # Measured on the MI355X over the whole suite (profiles/round4_parity_stats.json): 0 .. 8e-4 of the
 # non-exempt elements, up to 6.3e-3 on the scenes with 10-18 k-entry tile lists.
 STRICT_MISS_FRAC = 1.5e-3
@@ -37,12 +40,18 @@ STRICT_MISS_FRAC_LONG_LISTS = 1e-2
 
 
 def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995, exempt=None,
-                miss_frac=STRICT_MISS_FRAC):
+                miss_frac=STRICT_MISS_FRAC, truth=None):
     """Array-level bars for every element: relative L2 <= 1e-3 and >= 99.5 % within 2e-3 max|ref|.
     SURVEY §8(d) config 5's element-wise bar -- rtol 1e-3 / atol 1e-5 (relative to the array's
     largest element: the test losses are random planes, not unit-scale) -- for every element of
     every Gaussian that no threshold-fragile pixel feeds (`exempt`: bool[P], see
-    helpers.gaussians_fed_by_fragile_pixels); the exempted share is recorded."""
+    helpers.gaussians_fed_by_fragile_pixels); the exempted share is recorded.
+
+    `truth` (optional: the same array by float64 autograd, helpers.float64_truth_gradients) settles
+    a disagreement beyond those bars: the oracle restates the reference's T_final = 1 - alphas[pix]
+    and is itself off the exact gradient by more than the bar on dense draws, so an array also passes
+    when the HIP result is at least as close to the truth as the oracle's is (relative L2 and the
+    element-wise miss count, 20 % + 3 elements of slack) -- and stays within 5e-3 of the oracle."""
     import os
     from helpers import PARITY_STATS
     got = np.asarray(got, np.float64).reshape(ref.shape)
@@ -69,13 +78,30 @@ def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995, exempt=N
                              exempt_gaussians_frac=float(np.mean(exempt)),
                              nonexempt_elements=n_keep, nonexempt_beyond_strict=miss,
                              nonexempt_worst_over_bar=worst))
+    if truth is not None and not (l2 <= rel_l2 and ok >= frac and miss <= miss_frac * n_keep + 3):
+        tr = np.asarray(truth, np.float64).reshape(ref.shape)
+        tscale = np.abs(tr).max() + 1e-30
+        tnorm = np.linalg.norm(tr) + 1e-30
+
+        def against_truth(a):
+            beyond = (np.abs(a - tr) > 1e-5 * tscale + 1e-3 * np.abs(tr)).reshape(ref.shape[0], -1)
+            return np.linalg.norm(a - tr) / tnorm, int(beyond[keep].sum())
+        (l2_h, miss_h), (l2_o, miss_o) = against_truth(got), against_truth(ref)
+        PARITY_STATS[-1].update(truth_rel_l2_hip=float(l2_h), truth_rel_l2_oracle=float(l2_o),
+                                truth_miss_hip=miss_h, truth_miss_oracle=miss_o)
+        assert l2 <= 5e-3, "%s: relL2 %.3e against the oracle" % (name, l2)
+        assert l2_h <= 1.2 * l2_o + 1e-6 and miss_h <= 1.2 * miss_o + 3, (
+            "%s: HIP is further from the float64 gradient than the oracle: relL2 %.3e vs %.3e, elements beyond "
+            "the bar %d vs %d of %d" % (name, l2_h, l2_o, miss_h, miss_o, n_keep))
+        return
     assert l2 <= rel_l2 and ok >= frac, "%s: relL2 %.3e, within-tol fraction %.5f" % (name, l2, ok)
     assert miss <= miss_frac * n_keep + 3, (
         "%s: %d of %d elements of Gaussians no fragile pixel feeds miss rtol 1e-3 / atol 1e-5 max|ref| "
         "(%.2e; exempt Gaussians: %.3f)" % (name, miss, n_keep, miss / max(n_keep, 1), float(np.mean(exempt))))
 
 
-def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_frac=STRICT_MISS_FRAC):
+def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_frac=STRICT_MISS_FRAC,
+         with_truth=False):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     g = torch.Generator().manual_seed(100 + seed)
     P = sc.means3D.shape[0]
@@ -98,6 +124,10 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_fr
                        semantics=sem, **okw)
     ref = oracle.backward(o, gc, gd, ga, gs)
     fed = gaussians_fed_by_fragile_pixels(o)
+    tr = {}
+    if with_truth:      # small draws only: float64 autograd through the pure-PyTorch splat
+        from helpers import float64_truth_gradients
+        tr = float64_truth_gradients(sc, okw, gc, gd, ga, gs, semantics=sem, colors=colors, cov=cov)
 
     camd = hz.CameraTensors(H, W, cam.tanfovx, cam.tanfovy, cam.viewmatrix.to(dev),
                             cam.projmatrix.to(dev), cam.campos.to(dev))
@@ -120,22 +150,23 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_fr
         loss = loss + (semantic * gs.to(dev)).sum()
     loss.backward()
     torch.cuda.synchronize()
-    _grad_close("dL_dmeans3D", means.grad.cpu(), ref["dL_dmeans3D"], exempt=fed, miss_frac=miss_frac)
-    _grad_close("dL_dmeans2D", means2D.grad.cpu(), ref["dL_dmeans2D"], exempt=fed, miss_frac=miss_frac)
-    _grad_close("dL_dopacity", opac.grad.cpu(), ref["dL_dopacity"], exempt=fed, miss_frac=miss_frac)
+    bars = dict(exempt=fed, miss_frac=miss_frac)
+    _grad_close("dL_dmeans3D", means.grad.cpu(), ref["dL_dmeans3D"], **bars, truth=tr.get("dL_dmeans3D"))
+    _grad_close("dL_dmeans2D", means2D.grad.cpu(), ref["dL_dmeans2D"], **bars)
+    _grad_close("dL_dopacity", opac.grad.cpu(), ref["dL_dopacity"], **bars, truth=tr.get("dL_dopacity"))
     if use_colors:
-        _grad_close("dL_dcolors", col.grad.cpu(), ref["dL_dcolors"], exempt=fed, miss_frac=miss_frac)
+        _grad_close("dL_dcolors", col.grad.cpu(), ref["dL_dcolors"], **bars, truth=tr.get("dL_dcolors"))
     else:
-        _grad_close("dL_dsh", shs.grad.cpu(), ref["dL_dsh"], exempt=fed, miss_frac=miss_frac)
+        _grad_close("dL_dsh", shs.grad.cpu(), ref["dL_dsh"], **bars, truth=tr.get("dL_dsh"))
         nact = (sc.sh_degree + 1) ** 2
         assert float(shs.grad[:, nact:].abs().max() if shs.shape[1] > nact else 0.0) == 0.0
     if use_cov:
-        _grad_close("dL_dcov3D", covd.grad.cpu(), ref["dL_dcov3D"], exempt=fed, miss_frac=miss_frac)
+        _grad_close("dL_dcov3D", covd.grad.cpu(), ref["dL_dcov3D"], **bars, truth=tr.get("dL_dcov3D"))
     else:
-        _grad_close("dL_dscales", scales.grad.cpu(), ref["dL_dscales"], exempt=fed, miss_frac=miss_frac)
-        _grad_close("dL_drotations", rots.grad.cpu(), ref["dL_drotations"], exempt=fed, miss_frac=miss_frac)
+        _grad_close("dL_dscales", scales.grad.cpu(), ref["dL_dscales"], **bars, truth=tr.get("dL_dscales"))
+        _grad_close("dL_drotations", rots.grad.cpu(), ref["dL_drotations"], **bars, truth=tr.get("dL_drotations"))
     if S:
-        _grad_close("dL_dsemantic", semd.grad.cpu(), ref["dL_dsemantic"], exempt=fed, miss_frac=miss_frac)
+        _grad_close("dL_dsemantic", semd.grad.cpu(), ref["dL_dsemantic"], **bars, truth=tr.get("dL_dsemantic"))
     # densification statistic: z = sum |dx|+|dy| must be >= |x|,|y| sums (backward.cu:627-628)
     m2 = means2D.grad
     assert bool((m2[:, 2] + 1e-6 >= m2[:, 0].abs()).all())
