@@ -135,7 +135,11 @@ def float64_truth_gradients(sc, okw, gc, gd, ga, gs=None, semantics=None, colors
     loss = (out["color"] * gc.double()).sum() + (out["depth"] * gd.double()).sum() + (out["alpha"] * ga.double()).sum()
     if semantics is not None:
         loss = loss + (out["semantic"] * gs.double()).sum()
+    m2 = out["pre"]["means2D"]          # pixel coordinates; the op reports d/d(NDC): x 0.5 W, 0.5 H
+    m2.retain_grad()
     loss.backward()
     g = lambda k: None if lv[k] is None else lv[k].grad.numpy()   # noqa: E731
-    return dict(dL_dmeans3D=g("means3D"), dL_dopacity=g("opacity"), dL_dsh=g("shs"), dL_dcolors=g("colors"),
+    half = np.array([0.5 * int(okw["image_width"]), 0.5 * int(okw["image_height"])])
+    return dict(dL_dmeans2D_xy=m2.grad.numpy()[:, :2] * half[None, :],
+                dL_dmeans3D=g("means3D"), dL_dopacity=g("opacity"), dL_dsh=g("shs"), dL_dcolors=g("colors"),
                 dL_dscales=g("scales"), dL_drotations=g("rotations"), dL_dcov3D=g("cov"), dL_dsemantic=g("sem"))

@@ -152,7 +152,13 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_fr
     torch.cuda.synchronize()
     bars = dict(exempt=fed, miss_frac=miss_frac)
     _grad_close("dL_dmeans3D", means.grad.cpu(), ref["dL_dmeans3D"], **bars, truth=tr.get("dL_dmeans3D"))
-    _grad_close("dL_dmeans2D", means2D.grad.cpu(), ref["dL_dmeans2D"], **bars)
+    if with_truth:   # x, y can be arbitrated; the |.| statistic of column 2 has no autograd counterpart
+        _grad_close("dL_dmeans2D", means2D.grad[:, :2].cpu(), np.asarray(ref["dL_dmeans2D"])[:, :2], **bars,
+                    truth=tr.get("dL_dmeans2D_xy"))
+        _grad_close("dL_dmeans2D_abs", means2D.grad[:, 2:].cpu(), np.asarray(ref["dL_dmeans2D"])[:, 2:],
+                    exempt=fed, miss_frac=2 * miss_frac)
+    else:
+        _grad_close("dL_dmeans2D", means2D.grad.cpu(), ref["dL_dmeans2D"], **bars)
     _grad_close("dL_dopacity", opac.grad.cpu(), ref["dL_dopacity"], **bars, truth=tr.get("dL_dopacity"))
     if use_colors:
         _grad_close("dL_dcolors", col.grad.cpu(), ref["dL_dcolors"], **bars, truth=tr.get("dL_dcolors"))

@@ -12,6 +12,8 @@ combinations nobody picked (tile-list lengths around the 256 / 2048 / 8192 class
 csrc/common.h arise from the draws with small frames and dense clouds).  The draws are a pure
 function of the seed: a failure reproduces with `-k "sweep and <seed>"`.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -75,7 +77,12 @@ def draw(seed, max_P, max_side):
                 S=int(r.choice([0, 0, 1, 7, 16, 17])), kind=kind)
 
 
-@pytest.mark.parametrize("seed", range(24))
+# more draws for a bug hunt: GRPG_SWEEP_FORWARD=300 GRPG_SWEEP_BACKWARD=100 python -m pytest tests/test_gpu_sweep.py
+N_FORWARD = int(os.environ.get("GRPG_SWEEP_FORWARD", "40"))
+N_BACKWARD = int(os.environ.get("GRPG_SWEEP_BACKWARD", "16"))
+
+
+@pytest.mark.parametrize("seed", range(N_FORWARD))
 def test_forward_sweep(dev, seed):
     d = draw(seed, max_P=60000, max_side=420)
     sc, cam = d["sc"], d["cam"]
@@ -90,7 +97,7 @@ def test_forward_sweep(dev, seed):
     _check(got, o, max_fragile_frac=0.25)
 
 
-@pytest.mark.parametrize("seed", range(100, 110))
+@pytest.mark.parametrize("seed", range(1000, 1000 + N_BACKWARD))
 def test_backward_sweep(dev, seed):
     d = draw(seed, max_P=12000, max_side=200)
     r = np.random.RandomState(seed)
