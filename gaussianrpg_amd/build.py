@@ -139,6 +139,8 @@ EXPERIMENT_VARIANTS = {
     "pubearly": {"api.hip": ["-DGRPG_PUBLISH_EARLY"]},
     # the classic (256-thread, 21 KB of LDS) depth-sort passes for every P: does a small footprint overlap better?
     "classicsort": {"api.hip": ["-DGRPG_FORCE_CLASSIC_SORT"]},
+    # 96 registers / 101 KB of LDS per sort workgroup: room for another stream's workgroup on the same CU
+    "sortlean": {"sort.hip": ["-DGRPG_SORT_LEAN"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

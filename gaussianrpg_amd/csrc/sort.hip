@@ -418,8 +418,23 @@ __device__ unsigned long long g_ds_trace[4][4][10];   // [pass][probe workgroup]
 #define DS_TRACE(PH) do {} while (0)
 #endif
 
+// GRPG_SORT_LEAN (experiment build): 96 instead of 126 registers and 101 instead of 133 KB of LDS per
+// workgroup, so that one workgroup of another stream's render / preprocess fits beside a sort
+// workgroup on its CU.  The staging area becomes dynamic LDS (the compiler honours a register cap only
+// when it cannot see that the LDS allows one workgroup per CU anyway), the per-wave digit counters
+// move into the payload plane, which is dead until the staging, and the table sweep keeps 4 instead
+// of 8 rows in flight per wave.
+#ifdef GRPG_SORT_LEAN
+#define DS_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+constexpr bool DS_LEAN = true;
+#else
+#define DS_KERNEL_ATTR
+constexpr bool DS_LEAN = false;
+#endif
+constexpr size_t DS_DYN_LDS = DS_LEAN ? 3 * DS_CHUNK * sizeof(uint32_t) : 0;
+
 template <int PASS, bool RECT>
-__global__ void __launch_bounds__(DS_THREADS)
+DS_KERNEL_ATTR __global__ void __launch_bounds__(DS_THREADS)
 depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      const PassOut out_near, const PassOut out_far,
                      const uint32_t P, const uint32_t* __restrict__ table /* [nchunks][DS_RADIX] */,
@@ -428,8 +443,14 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                      const RectPayload rp, const CountPublish pub) {
   // keys | values | payload staged for the coalesced run writes; the per-wave partial column sums
   // of the table sweep live in the first two thirds until the keys are staged
+#ifdef GRPG_SORT_LEAN
+  extern __shared__ uint32_t s_dyn[];
+  uint32_t* const s_buf = s_dyn;
+  uint32_t* const s_cnt = s_dyn + 2 * DS_CHUNK;     // RECT: the payload plane, staged into only after the last s_cnt read
+#else
   __shared__ uint32_t s_buf[(RECT ? 3 : 2) * DS_CHUNK];
   __shared__ uint32_t s_cnt[DS_WAVES * DS_RADIX];   // [wave][digit]: bank-conflict-free ranking
+#endif
   __shared__ uint32_t s_gbase[DS_RADIX];
   __shared__ uint32_t s_w[2 * (DS_RADIX / 64)];
   uint32_t* const s_keys = s_buf;
@@ -487,7 +508,7 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   {
     const uint4* t4 = reinterpret_cast<const uint4*>(table);
     uint4 exa = make_uint4(0u, 0u, 0u, 0u), exb = exa, tota = exa, totb = exa;
-    constexpr int SW = 8;
+    constexpr int SW = DS_LEAN ? 4 : 8;
     for (uint32_t r0 = wave; r0 < nrows; r0 += DS_WAVES * SW) {
       uint4 va[SW], vb[SW];
 #pragma unroll
@@ -587,11 +608,19 @@ depth_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     s_gbase[tid] -= dstart;   // wraps mod 2^32; only used as base + local slot
   }
   __syncthreads();
+  if (DS_LEAN) {   // the counters share LDS with the payload plane: every slot is read before anything is staged
+#pragma unroll
+    for (int i = 0; i < DS_ITEMS; i++) {
+      if (rnk[i] != 0xFFFFFFFFu)
+        rnk[i] += s_cnt[wave * DS_RADIX + (ds_digit<PASS>(key[i], kb) & (DS_RADIX - 1))];
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < DS_ITEMS; i++) {
     if (rnk[i] != 0xFFFFFFFFu) {
       const uint32_t d = ds_digit<PASS>(key[i], kb) & (DS_RADIX - 1);
-      const uint32_t slot = s_cnt[wave * DS_RADIX + d] + rnk[i];
+      const uint32_t slot = DS_LEAN ? rnk[i] : s_cnt[wave * DS_RADIX + d] + rnk[i];
       s_keys[slot] = key[i];
       s_vals[slot] = val[i];
       if (RECT) s_aux[slot] = PASS == 0 ? rect_pack(rraw[i]) : aux[i];
@@ -645,6 +674,18 @@ void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a,
                     const uint4* pre_counts, uint32_t pre_nblocks, bool publish_here,
                     uint32_t* count_host_word, uint32_t* count_header_words, hipEvent_t count_event) {
   if (P == 0) return;
+#ifdef GRPG_SORT_LEAN
+  static const bool lds_ok = [] {   // more than 64 KB of dynamic LDS has to be asked for, once per kernel
+    auto ask = [](const void* f) {
+      return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DS_DYN_LDS) == hipSuccess;
+    };
+    return ask((const void*)depth_scatter_kernel<0, true>) & ask((const void*)depth_scatter_kernel<1, true>) &
+           ask((const void*)depth_scatter_kernel<2, true>) & ask((const void*)depth_scatter_kernel<3, true>) &
+           ask((const void*)depth_scatter_kernel<0, false>) & ask((const void*)depth_scatter_kernel<1, false>) &
+           ask((const void*)depth_scatter_kernel<2, false>) & ask((const void*)depth_scatter_kernel<3, false>);
+  }();
+  (void)lds_ok;
+#endif
   const size_t tsz = (size_t)nchunks * DS_RADIX;
   const bool rect = rects_by_id != nullptr;
   const int allow_far = with_pass3 ? 1 : 0;
@@ -655,10 +696,10 @@ void depth_sort_fat(hipStream_t s, uint32_t P, uint32_t* key_a, uint32_t* val_a,
                               count_host_word, count_header_words};                              \
     const PassOut on = {KN, VN}, of = {KF, VF};                                                  \
     if (rect)                                                                                    \
-      depth_scatter_kernel<PASS, true><<<nchunks, DS_THREADS, 0, s>>>(                           \
+      depth_scatter_kernel<PASS, true><<<nchunks, DS_THREADS, DS_DYN_LDS, s>>>(                  \
           KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, allow_far, rp, pub);  \
     else                                                                                         \
-      depth_scatter_kernel<PASS, false><<<nchunks, DS_THREADS, 0, s>>>(                          \
+      depth_scatter_kernel<PASS, false><<<nchunks, DS_THREADS, DS_DYN_LDS, s>>>(                 \
           KI, VI, on, of, P, ds_table + PASS * tsz, nchunks, V_out, range, allow_far, rp, pub);  \
   } while (0)
 #define DS_HIST(PASS, K)                                                                         \
