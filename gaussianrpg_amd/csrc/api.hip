@@ -41,7 +41,16 @@ struct HostWord {
   uint32_t* dev_ptr = nullptr;    // the same memory as the device addresses it
   hipEvent_t ev = nullptr;
 };
-thread_local std::vector<HostWord> g_host_words;
+// released when the owning thread exits (as the deferred-frame ring below)
+struct HostWords : std::vector<HostWord> {
+  ~HostWords() {
+    for (auto& h : *this) {
+      if (h.host_ptr) (void)hipHostFree(h.host_ptr);
+      if (h.ev) (void)hipEventDestroy(h.ev);
+    }
+  }
+};
+thread_local HostWords g_host_words;
 
 HostWord* host_word() {
   int dev = 0;
@@ -51,8 +60,11 @@ HostWord* host_word() {
   HostWord h;
   h.dev = dev;
   if (hipHostMalloc((void**)&h.host_ptr, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-  if (hipHostGetDevicePointer((void**)&h.dev_ptr, h.host_ptr, 0) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipHostGetDevicePointer((void**)&h.dev_ptr, h.host_ptr, 0) != hipSuccess ||
+      hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipHostFree(h.host_ptr);
+    return nullptr;
+  }
   h.host_ptr[0] = 0u; h.host_ptr[1] = 0u; h.host_ptr[2] = 0u; h.host_ptr[3] = 0u;
   g_host_words.push_back(h);
   return &g_host_words.back();
