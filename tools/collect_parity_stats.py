@@ -26,6 +26,18 @@ summary = {
     "exempt_gaussian_share_min_max": [min((r["exempt_gaussians_frac"] for r in grd), default=None),
                                       max((r["exempt_gaussians_frac"] for r in grd), default=None)],
 }
+# arrays that missed the HIP-vs-oracle bars and were settled against float64 autograd (tests/test_gpu_sweep.py)
+tru = [r for r in grd if "truth_rel_l2_hip" in r]
+summary["gradient_arrays_settled_against_float64_autograd"] = {
+    "arrays": len(tru),
+    "rel_l2_vs_float64_hip_min_max": [min((r["truth_rel_l2_hip"] for r in tru), default=None),
+                                      max((r["truth_rel_l2_hip"] for r in tru), default=None)],
+    "rel_l2_vs_float64_oracle_min_max": [min((r["truth_rel_l2_oracle"] for r in tru), default=None),
+                                         max((r["truth_rel_l2_oracle"] for r in tru), default=None)],
+    "elements_beyond_bar_vs_float64_hip": sum(r["truth_miss_hip"] for r in tru),
+    "elements_beyond_bar_vs_float64_oracle": sum(r["truth_miss_oracle"] for r in tru),
+    "non_exempt_elements_in_those_arrays": sum(r["nonexempt_elements"] for r in tru),
+}
 out = os.path.join(ROOT, "profiles", "%s_parity_stats.json" % tag)
 json.dump({"summary": summary, "records": recs}, open(out, "w"), indent=1)
 print(json.dumps(summary, indent=1))
