@@ -200,6 +200,52 @@ def part_a_sh_bwd():
     np.savez(os.path.join(HERE, "ref_sh_bwd.npz"), **out)
 
 
+def part_a_cov3d():
+    """The reference's PYTHON route to the 3D covariance -> ref_cov3d.npz: `get_covariance`
+    (lib/models/gaussian_model.py:253) = build_covariance_from_scaling_rotation (:208-212) over
+    build_scaling_rotation / quaternion_to_matrix / strip_symmetric (lib/utils/general_utils.py:278-287,
+    :125-146, :88-100) -- what the renderer hands to the op as cov3D_precomp when
+    `compute_cov3D_python` is set (gaussian_renderer.py:74-75), i.e. the reference's own statement of
+    what computeCov3D (CR/forward.cu:118-152) computes from (scale, modifier, rotation), element
+    order included.  The functions are cut out with ast and run here; their `device="cuda"` /
+    `device='cuda'` keywords of torch.zeros are dropped (no CUDA in this container), the arithmetic
+    is untouched."""
+    import ast
+
+    class TorchNoDevice:                      # torch, with torch.zeros(..., device=...) placed on the CPU
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def zeros(*a, **kw):
+            kw.pop("device", None)
+            return torch.zeros(*a, **kw)
+    ns = {"torch": TorchNoDevice(), "np": np}
+    gu = ast.parse(open(os.path.join(REF, "lib/utils/general_utils.py")).read())
+    names = ["quaternion_to_matrix", "build_scaling_rotation", "strip_lowerdiag", "strip_symmetric"]
+    fns = [n for n in gu.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names)
+    exec(compile(ast.Module(fns, []), "general_utils.py", "exec"), ns)
+    gm = ast.parse(open(os.path.join(REF, "lib/models/gaussian_model.py")).read())
+    nested = [n for n in ast.walk(gm) if isinstance(n, ast.FunctionDef)
+              and n.name == "build_covariance_from_scaling_rotation"]
+    assert len(nested) == 1
+    exec(compile(ast.Module(nested, []), "gaussian_model.py", "exec"), ns)
+    cov_fn = ns["build_covariance_from_scaling_rotation"]
+    g = torch.Generator().manual_seed(777)
+    N = 96
+    scales = torch.exp(-2.0 + 1.2 * torch.randn(N, 3, generator=g))
+    scales[:8] *= torch.tensor([10.0, 0.1, 1.0])            # needles / pancakes
+    q = torch.randn(N, 4, generator=g)
+    q[0] = torch.tensor([1.0, 0, 0, 0])
+    q[1] = torch.tensor([0.0, 0, 0, 1.0])
+    rot = torch.nn.functional.normalize(q)                  # get_rotation (gaussian_model.py:229-230)
+    out = dict(scales=scales.numpy(), rotations=rot.numpy())
+    for name, mod in (("mod1", 1.0), ("mod06", 0.6)):
+        out["cov_" + name] = cov_fn(scales, mod, rot).numpy()
+    np.savez(os.path.join(HERE, "ref_cov3d.npz"), **out)
+
+
 def scenes():
     """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
     from gaussianrpg_amd import harness as hz
@@ -262,6 +308,7 @@ if __name__ == "__main__":
         part_a_sky()
         part_a_quat()
         part_a_sh_bwd()
+        part_a_cov3d()
     else:
         print("no /root/reference here: skipping part A (reference-derived vectors)")
     part_b()

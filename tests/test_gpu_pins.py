@@ -10,6 +10,8 @@ the drop-in Python API / the _C binding:
                   dL_dsh (per-Gaussian basis: dL_dsh / dL_dcolor), through _C.rasterize_gaussians_backward
 * ref_quat.npz    quaternion_to_matrix_numpy (R/lib/utils/general_utils.py:103-122) -> the (r,x,y,z)
                   convention of computeCov3D as seen in the conic the kernel stores
+* ref_cov3d.npz   build_covariance_from_scaling_rotation (R/lib/models/gaussian_model.py:208-212) -> the
+                  op's internal computeCov3D (scale modifier, entry order) as seen in radii and conics
 * ref_camera.npz  getWorld2View2 / getProjectionMatrixK (R/lib/utils/graphics_utils.py:38-94) ->
                   means2D / depths of preprocess for matrices built exactly like the reference's Camera
 """
@@ -158,6 +160,54 @@ def test_hip_conic_uses_reference_quaternion_convention(dev):
     np.testing.assert_allclose(dbg["conic_opacity"][:, :3], ref, rtol=2e-4, atol=1e-7)
     wrong = conic(np.transpose(z["R"], (0, 2, 1)))
     assert (np.abs(wrong - ref).max(axis=1) > 1e-3 * np.abs(ref).max(axis=1)).mean() > 0.5
+
+
+@pytest.mark.parametrize("mod,key", [(1.0, "cov_mod1"), (0.6, "cov_mod06")])
+def test_hip_covariance_matches_reference_python_covariance(dev, mod, key):
+    """ref_cov3d.npz: what preprocess derives from (scales, scale_modifier, rotations) == what it derives
+    from cov3D_precomp = the reference's OWN Python covariance of the same Gaussians
+    (get_covariance, gaussian_model.py:208-212,253; the `compute_cov3D_python` route of
+    gaussian_renderer.py:74-75): same radii, same conics (float32 rounding of two routes to the same
+    matrix), so the op's internal computeCov3D and the order of the six entries are the reference's."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    from gaussianrpg_amd.rasterizer import _C, debug_export
+    z = np.load(os.path.join(GOLDEN, "ref_cov3d.npz"))
+    scales, rots, cov = z["scales"], z["rotations"], z[key]
+    n = scales.shape[0]
+    rng = np.random.RandomState(8)
+    means = np.c_[rng.uniform(-1, 1, n), rng.uniform(-0.6, 0.6, n), rng.uniform(6, 9, n)].astype(np.float32)
+    cam = hz.make_camera(np.eye(3), np.zeros(3), W=512, H=384, fx=200.0, fy=200.0, cx=256, cy=192)
+    camd = hz.CameraTensors(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy,
+                            cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.campos.to(dev))
+    rs = GaussianRasterizationSettings(**hz.settings_kwargs(camd, 0, bg=torch.zeros(3, device=dev),
+                                                            scale_modifier=mod))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)   # noqa: E731
+    e = torch.Tensor([])
+
+    def run(use_cov):
+        args = (rs.bg, t(means), t(np.ones((n, 3), np.float32)), torch.zeros(n, 0, device=dev),
+                t(np.full((n, 1), 0.5, np.float32)), e if use_cov else t(scales), e if use_cov else t(rots),
+                rs.scale_modifier, t(cov) if use_cov else e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                rs.tanfovy, rs.image_height, rs.image_width, e, 0, rs.campos, False, False)
+        out = _C.rasterize_gaussians(*args)
+        dbg = debug_export(out[6], out[7], out[8], n, out[0], rs.image_height, rs.image_width)
+        torch.cuda.synchronize()
+        return out[5].cpu().numpy(), dbg["conic_opacity"].cpu().numpy()
+    radii_sr, conic_sr = run(False)
+    radii_cov, conic_cov = run(True)
+    assert (radii_sr > 0).all() and (radii_cov > 0).all()
+    # the radius is ceil(3 sqrt(lambda_max)): one unit of slack where the two roundings straddle an integer
+    assert np.abs(radii_sr - radii_cov).max() <= 1 and (radii_sr == radii_cov).mean() >= 0.95
+    np.testing.assert_allclose(conic_sr, conic_cov, rtol=2e-4, atol=1e-7)
+    # and the entry order matters: cov3D with xy / xz swapped gives other conics
+    cov_swapped = cov[:, [0, 2, 1, 3, 4, 5]]
+    args = (rs.bg, t(means), t(np.ones((n, 3), np.float32)), torch.zeros(n, 0, device=dev),
+            t(np.full((n, 1), 0.5, np.float32)), e, e, rs.scale_modifier, t(cov_swapped), rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, e, 0, rs.campos, False, False)
+    out = _C.rasterize_gaussians(*args)
+    wrong = debug_export(out[6], out[7], out[8], n, out[0], rs.image_height, rs.image_width)["conic_opacity"].cpu().numpy()
+    vis = out[5].cpu().numpy() > 0
+    assert (np.abs(wrong[vis, :3] - conic_sr[vis, :3]).max(axis=1) > 1e-3 * np.abs(conic_sr[vis, :3]).max(axis=1)).mean() > 0.5
 
 
 def test_hip_projection_uses_reference_matrices(dev):

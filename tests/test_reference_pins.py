@@ -8,6 +8,9 @@ The fixtures were generated in the build container by executing the reference's 
 * ref_sh_bwd.npz -- torch.autograd through eval_sh (R/lib/utils/sh_utils.py:57-112) + the caller's
                     direction normalisation: the first reference-derived pin of the backward.
 
+* ref_cov3d.npz  -- (round 4) build_covariance_from_scaling_rotation (R/lib/models/gaussian_model.py:
+                    208-212) over build_scaling_rotation / quaternion_to_matrix / strip_symmetric.
+
 They pin: gs_oracle.c's quat_to_R_glm / computeCov3D convention (CR/forward.cu:118-152),
 oracle/compose_torch.py's quaternion_to_matrix and quaternion_raw_multiply, and gs_oracle.c's
 computeColorFromSH_bwd (CR/backward.cu:20-139: dL_dsh and the direction part of dL_dmeans3D).
@@ -66,6 +69,29 @@ def test_cov3d_uses_reference_quaternion_convention():
     # the convention is observable: the transposed matrix gives a different covariance
     wrong = cov3d_from_reference_R(np.transpose(fx["R"], (0, 2, 1)), scales)
     assert np.abs(wrong - ref).max() > 1e-3
+
+
+@pytest.mark.parametrize("mod,key", [(1.0, "cov_mod1"), (0.6, "cov_mod06")])
+def test_cov3d_matches_reference_python_covariance(mod, key):
+    """ref_cov3d.npz (round 4): the reference's own Python statement of computeCov3D --
+    build_covariance_from_scaling_rotation(scaling, modifier, rotation) (gaussian_model.py:208-212,
+    the cov3D_precomp route of gaussian_renderer.py:74-75), element order of strip_symmetric -- against
+    gs_oracle.c's computeCov3D (CR/forward.cu:118-152) on the same scales, rotations and modifier."""
+    z = np.load(os.path.join(GOLDEN, "ref_cov3d.npz"))
+    scales, rots = z["scales"], z["rotations"]
+    n = scales.shape[0]
+    rng = np.random.RandomState(8)
+    means = np.c_[rng.uniform(-1, 1, n), rng.uniform(-0.6, 0.6, n), rng.uniform(6, 9, n)].astype(np.float32)
+    cam = hz.make_camera(np.eye(3), np.zeros(3), W=512, H=384, fx=200.0, fy=200.0, cx=256, cy=192)
+    o = oracle.forward(means, np.full((n, 1), 0.5, np.float32), colors_precomp=np.ones((n, 3), np.float32),
+                       scales=scales, rotations=rots, render=False,
+                       **oracle_kwargs(cam, 0, scale_modifier=mod))
+    assert (o["radii"] > 0).all()
+    scale = np.abs(z[key]).max(axis=1, keepdims=True)       # per Gaussian: entries span many decades
+    np.testing.assert_allclose(o["cov3D"] / scale, z[key] / scale, rtol=0, atol=3e-6)
+    # the order of the six entries is observable (xy <-> xz swapped is another matrix)
+    swapped = z[key][:, [0, 2, 1, 3, 4, 5]]
+    assert np.abs(swapped / scale - o["cov3D"] / scale).max() > 1e-2
 
 
 def test_compose_restatement_quaternions_match_reference():
