@@ -246,6 +246,38 @@ def part_a_cov3d():
     np.savez(os.path.join(HERE, "ref_cov3d.npz"), **out)
 
 
+def part_a_ply_layout():
+    """The trained-model file layouts, from the reference's own writer -> ref_ply_layout.npz:
+    GaussianModel.make_ply / construct_list_of_attributes (lib/models/gaussian_model.py:80-96, 327-341)
+    and GaussianModel.state_dict(is_final=True) (:182-205), cut out of the class with ast and run on a
+    stand-in `self` that carries only the seven parameter tensors.  The fixture holds the tensors, the
+    property names in file order and the element table make_ply returns; gaussianrpg_amd/checkpoint.py
+    must turn that table back into the tensors (tests/test_model_checkpoint_loader.py)."""
+    import ast
+    import types
+    cls = [n for n in ast.parse(open(os.path.join(REF, "lib/models/gaussian_model.py")).read()).body
+           if isinstance(n, ast.ClassDef) and n.name == "GaussianModel"][0]
+    names = ["make_ply", "construct_list_of_attributes", "state_dict"]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names)
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(fns, []), "gaussian_model.py", "exec"), ns)
+    g = torch.Generator().manual_seed(2024)
+    N, S = 24, 3
+    me = types.SimpleNamespace(
+        _xyz=torch.randn(N, 3, generator=g) * 4, _features_dc=torch.randn(N, 1, 3, generator=g),
+        _features_rest=torch.randn(N, 15, 3, generator=g) * 0.3, _scaling=torch.randn(N, 3, generator=g) - 2,
+        _rotation=torch.randn(N, 4, generator=g), _opacity=torch.randn(N, 1, generator=g),
+        _semantic=torch.rand(N, S, generator=g))
+    me.construct_list_of_attributes = types.MethodType(ns["construct_list_of_attributes"], me)
+    el = ns["make_ply"](me)
+    sd = ns["state_dict"](me, True)
+    np.savez(os.path.join(HERE, "ref_ply_layout.npz"),
+             property_names=np.array(el.dtype.names), table=np.stack([el[k] for k in el.dtype.names], axis=1),
+             state_dict_keys=np.array(list(sd.keys())),
+             **{"sd_" + k: v.numpy() for k, v in sd.items()})
+
+
 def scenes():
     """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
     from gaussianrpg_amd import harness as hz
@@ -309,6 +341,7 @@ if __name__ == "__main__":
         part_a_quat()
         part_a_sh_bwd()
         part_a_cov3d()
+        part_a_ply_layout()
     else:
         print("no /root/reference here: skipping part A (reference-derived vectors)")
     part_b()

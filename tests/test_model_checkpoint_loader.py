@@ -117,3 +117,47 @@ def test_activated_scene_is_what_the_references_getters_return(tmp_path, models)
     ms, ps = ckpt.scene_models(loaded, "cpu", poses={"obj_012": ActorPose([1, 0, 0, 0], [2, 0, 5], 0.3)})
     assert len(ms) == 2 and ps[0] is None and ps[1].obj_trans == [2, 0, 5]
     assert torch.equal(ms[1].xyz, models["obj_012"].xyz)
+
+
+def _write_ply_table(path, element, names, table):
+    """A PLY container around an element table, independent of checkpoint.write_ply."""
+    hdr = ["ply", "format binary_little_endian 1.0", "element %s %d" % (element, table.shape[0])]
+    hdr += ["property float %s" % n for n in names] + ["end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(hdr) + "\n").encode("ascii"))
+        f.write(np.ascontiguousarray(table, dtype="<f4").tobytes())
+
+
+def test_loader_inverts_the_references_own_writer(tmp_path):
+    """ref_ply_layout.npz (tests/golden/make_golden.py part_a_ply_layout): the element table and the
+    property names GaussianModel.make_ply produced IN the reference's code for seven known tensors, and
+    the keys of its state_dict(is_final=True).  The loader must give those tensors back -- bit for bit,
+    feature planes in the [N, K, 3] layout of the state dict (make_ply stores them channel-major)."""
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "ref_ply_layout.npz"))
+    names = [str(n) for n in z["property_names"]]
+    want = {k: z["sd_" + k] for k in (str(s) for s in z["state_dict_keys"])}
+    assert list(want) == ["xyz", "feature_dc", "feature_rest", "scaling", "rotation", "opacity", "semantic"]
+    # PLY: one element of a street scene (save_ply names it vertex_<model>, street_gaussian_model.py:94-105)
+    ply = str(tmp_path / "point_cloud.ply")
+    _write_ply_table(ply, "vertex_background", names, z["table"])
+    got = ckpt.load_checkpoint(ply)
+    assert got.names() == ["background"] and got.sh_degree("background") == 3
+    for k, v in want.items():
+        assert np.array_equal(got.models["background"][k].numpy(), v), k
+    # .pth: the state dict under the reference's keys, as save_state_dict nests it per model
+    pth = str(tmp_path / "iteration_7000.pth")
+    torch.save({"background": {k: torch.tensor(v) for k, v in want.items()}}, pth)
+    got = ckpt.load_checkpoint(pth)
+    for k, v in want.items():
+        assert np.array_equal(got.models["background"][k].numpy(), v), k
+    # and the writer of this package produces the reference's table and property order
+    out = str(tmp_path / "rewritten.ply")
+    m = got.params("background")
+    ckpt.write_ply(out, {"background": m}, semantic_classes=want["semantic"].shape[1])
+    el = ckpt.read_ply(out)["vertex_background"]
+    assert list(el.dtype.names) == names
+    sem_cols = [i for i, n in enumerate(names) if n.startswith("semantic_")]
+    keep = [i for i in range(len(names)) if i not in sem_cols]     # write_ply has no semantic values to write
+    table = np.stack([el[n] for n in names], axis=1)
+    assert np.array_equal(table[:, keep], z["table"][:, keep])
