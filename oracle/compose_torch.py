@@ -9,12 +9,14 @@ Follows, line by line, what ``StreetGaussianModel``'s properties compute for one
   get_features  street_gaussian_model.py:367-383, gaussian_model.py:236-240,
                 gaussian_model_actor.py:73-82 (get_features_fourier), sh_utils.py:120-130 (IDFT)
   get_opacity   street_gaussian_model.py:437-453             + gaussian_model.py:248-250 (sigmoid)
-with the optional per-Gaussian flip mask of training (flip_prob) and no pose correction.  PARITY UNPINNED for the composition as a
-whole: lib/models cannot be imported here (plyfile, roma, simple_knn, nvdiffrast missing and
-lib.config parses sys.argv); only IDFT is reference-pinned (tests/golden/ref_idft.npz, generated by
-importing lib/utils/sh_utils.py); round 3 adds quaternion_to_matrix and quaternion_raw_multiply
-(tests/golden/ref_quat.npz, produced by executing the reference's own general_utils.py functions;
-tests/test_reference_pins.py, and tests/test_compose.py for grpg_compose on the GPU).
+with the optional per-Gaussian flip mask of training (flip_prob) and no pose correction.  PINNED since round 4:
+lib/models cannot be imported here (plyfile, roma, simple_knn, nvdiffrast missing and lib.config parses
+sys.argv), but tests/golden/make_golden.py part_a_compose cuts the getters above out of their classes with
+ast and runs them, in the reference's code, on stand-in objects holding a background model and two posed,
+partly flipped actors -> tests/golden/ref_compose.npz; this file reproduces that output within 2e-6
+(tests/test_reference_pins.py), and so does grpg_compose on the GPU (tests/test_compose.py).  Piecewise
+pins from earlier rounds: IDFT (ref_idft.npz), quaternion_to_matrix and quaternion_raw_multiply
+(ref_quat.npz).
 """
 import torch
 

@@ -143,3 +143,27 @@ def float64_truth_gradients(sc, okw, gc, gd, ga, gs=None, semantics=None, colors
     return dict(dL_dmeans2D_xy=m2.grad.numpy()[:, :2] * half[None, :],
                 dL_dmeans3D=g("means3D"), dL_dopacity=g("opacity"), dL_dsh=g("shs"), dL_dcolors=g("colors"),
                 dL_dscales=g("scales"), dL_drotations=g("rotations"), dL_dcov3D=g("cov"), dL_dsemantic=g("sem"))
+
+
+def reference_composition_fixture():
+    """tests/golden/ref_compose.npz (make_golden.py part_a_compose): raw parameters of a background model
+    and two actors, their poses / frames / flip masks, and what the reference's OWN getters
+    (StreetGaussianModel.get_xyz / get_rotation / get_scaling / get_opacity / get_features) returned
+    for them.  -> (models [ModelParams], poses [None | ActorPose], expected dict)."""
+    import torch
+    from gaussianrpg_amd.composed import ActorPose, ModelParams
+    z = np.load(os.path.join(GOLDEN, "ref_compose.npz"))
+    t = lambda k: torch.tensor(z[k])          # noqa: E731
+    models, poses = [], []
+    for name in ("background", "obj_003", "obj_011"):
+        flip = t(name + ".flip") if name != "background" else None
+        models.append(ModelParams(*(t("%s.%s" % (name, f)) for f in ModelParams._fields[:6]), flip))
+        if name == "background":
+            poses.append(None)
+        else:
+            start, end, scale = (float(v) for v in z[name + ".frames"])
+            # gaussian_model_actor.py:74-75
+            poses.append(ActorPose(t(name + ".obj_rot"), t(name + ".obj_trans"),
+                                   scale * (float(z["frame"]) - start) / (end - start)))
+    want = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    return models, poses, want

@@ -277,3 +277,18 @@ def test_fused_training_gradients_match_autograd_through_the_restatement(sh_degr
     with torch.no_grad():
         c3, r3, d3, a3 = ComposedRasterizer(rs)(ms, ps)
     assert not c3.requires_grad and torch.equal(c3, color.detach()) and torch.equal(r3, radii)
+
+
+@pytest.mark.gpu
+def test_compose_matches_the_references_own_getters():
+    """grpg_compose (the HIP code the fused rasterizer runs) against tests/golden/ref_compose.npz: what
+    StreetGaussianModel.get_xyz / get_rotation / get_scaling / get_opacity / get_features returned IN the
+    reference's code for a background model and two posed, partly flipped actors
+    (street_gaussian_model.py:296-453, gaussian_model_actor.py:73-82; make_golden.py part_a_compose)."""
+    from gaussianrpg_amd.composed import compose
+    from helpers import reference_composition_fixture
+    models, poses, want = reference_composition_fixture()
+    dev = torch.device("cuda:0")
+    got = compose([_to(m, dev) for m in models], poses)
+    for name, t in zip(("xyz", "scaling", "rotation", "opacity", "features"), got):
+        np.testing.assert_allclose(t.cpu().numpy(), want[name], rtol=3e-6, atol=3e-6, err_msg=name)
