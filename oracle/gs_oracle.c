@@ -29,7 +29,12 @@
  *     - computeColorFromSH_bwd: dL_dsh and the direction part of dL_dmeans3D
  *       (torch.autograd through the reference's eval_sh; ref_sh_bwd.npz,
  *       tests/test_reference_pins.py) -- round 3, the first reference-derived
- *       pin of anything in the backward.
+ *       pin of anything in the backward;
+ *     - computeCov3D as a whole -- scale-modifier placement, (S R)^T (S R),
+ *       order of the six entries -- against the reference's own Python route
+ *       (get_covariance = build_covariance_from_scaling_rotation,
+ *       lib/models/gaussian_model.py:208-212; ref_cov3d.npz,
+ *       tests/test_reference_pins.py) -- round 4.
  *   Everything else (EWA projection, tile binning, blend, the rest of the
  *   backward) is pinned only by agreement of three independent
  *   implementations: this file, oracle/torch_splat.py (+ fp64 autograd) and
