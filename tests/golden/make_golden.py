@@ -381,6 +381,32 @@ def part_a_compose():
     np.savez(os.path.join(HERE, "ref_compose.npz"), **save)
 
 
+def part_a_binding_trace():
+    """The Python -> _C boundary of the operator, traced under the reference's own wrapper ->
+    ref_binding_trace.json: submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py
+    is imported with a RECORDING stand-in for its compiled `_C` (tests/helpers.py BindingRecorder) and
+    driven through a training forward + backward (SH + scales/rotations, and colors_precomp +
+    cov3D_precomp), markVisible and visible_filter.  The fixture holds, per `_C` call, the entry point's
+    name and which caller-side object or plain value sits in every argument position, what the wrapper
+    returns in which order, and which of `_C`'s nine gradients reaches which input."""
+    import json
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import BindingRecorder, binding_trace
+    rec = BindingRecorder()
+    pkg = types.ModuleType("ref_dgr")
+    pkg.__path__ = []
+    pkg._C = rec
+    sys.modules["ref_dgr"] = pkg
+    sys.modules["ref_dgr._C"] = rec
+    path = os.path.join(REF, "submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py")
+    mod = types.ModuleType("ref_dgr.wrapper")
+    mod.__package__ = "ref_dgr"
+    exec(compile(open(path).read(), path, "exec"), mod.__dict__)
+    trace = binding_trace(mod, rec)
+    json.dump(trace, open(os.path.join(HERE, "ref_binding_trace.json"), "w"), indent=1)
+
+
 def scenes():
     """(name, scene, camera, extra kwargs) of the oracle-generated regression fixtures."""
     from gaussianrpg_amd import harness as hz
@@ -446,6 +472,7 @@ if __name__ == "__main__":
         part_a_cov3d()
         part_a_ply_layout()
         part_a_compose()
+        part_a_binding_trace()
     else:
         print("no /root/reference here: skipping part A (reference-derived vectors)")
     part_b()

@@ -167,3 +167,108 @@ def reference_composition_fixture():
                                    scale * (float(z["frame"]) - start) / (end - start)))
     want = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
     return models, poses, want
+
+
+# ---- the Python -> _C boundary, traced (tests/golden/ref_binding_trace.json) -------------------
+class BindingRecorder:
+    """A stand-in for the compiled `_C` module that records how a Python wrapper calls it: for every
+    call the entry point's name and, per positional argument, WHICH caller-side object it is (tensors are
+    recognised by storage address; the empty placeholders by their shape) or its plain value.  Its
+    return values are labelled tensors too, so that what a wrapper hands on to the next call, back to the
+    caller, or to autograd can be followed.  Used twice: in tests/golden/make_golden.py under the
+    reference's own diff_gaussian_rasterization/__init__.py (-> the fixture) and in
+    tests/test_binding_trace.py under gaussianrpg_amd/rasterizer.py."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.calls = []
+        self.names = {}
+
+    def tensor(self, label, *shape, fill=None):
+        t = self.torch.full(shape, float(len(self.names) + 1) if fill is None else fill)
+        self.names[(t.data_ptr(), tuple(t.shape))] = label
+        return t
+
+    def describe(self, a):
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            if a.numel() == 0:
+                return "empty%s" % (list(a.shape),)
+            return self.names.get((a.data_ptr(), tuple(a.shape)), "unknown%s" % (list(a.shape),))
+        if isinstance(a, bool):
+            return "bool:%s" % a
+        if isinstance(a, int):
+            return "int:%d" % a
+        if isinstance(a, float):
+            return "float:%r" % a
+        return type(a).__name__
+
+    def _record(self, name, args):
+        self.calls.append([name, [self.describe(a) for a in args]])
+
+    # the entry points of rasterize_points.h / ext.cpp
+    def rasterize_gaussians(self, *args):
+        self._record("rasterize_gaussians", args)
+        P = args[1].shape[0]
+        H, W = args[13], args[14]
+        S = args[3].shape[1]
+        return (4321, self.tensor("out.color", 3, H, W), self.tensor("out.depth", 1, H, W),
+                self.tensor("out.alpha", 1, H, W), self.tensor("out.semantic", S, H, W),
+                self.tensor("out.radii", P), self.tensor("out.geomBuffer", 16), self.tensor("out.binningBuffer", 16),
+                self.tensor("out.imgBuffer", 16))
+
+    def rasterize_gaussians_backward(self, *args):
+        self._record("rasterize_gaussians_backward", args)
+        P = args[1].shape[0]
+        M = max(args[16].shape[1] if args[16].dim() == 3 else 0, 1)
+        S = args[24].shape[1]
+        shapes = [("means2D", (P, 3)), ("colors_precomp", (P, 3)), ("opacities", (P, 1)), ("means3D", (P, 3)),
+                  ("cov3Ds_precomp", (P, 6)), ("sh", (P, M, 3)), ("scales", (P, 3)), ("rotations", (P, 4)),
+                  ("semantics", (P, S))]
+        return tuple(self.tensor("grad." + n, *shp) for n, shp in shapes)
+
+    def mark_visible(self, *args):
+        self._record("mark_visible", args)
+        return self.tensor("out.visible", args[0].shape[0])
+
+    def rasterize_gaussians_filter(self, *args):
+        self._record("rasterize_gaussians_filter", args)
+        P = args[0].shape[0]
+        return self.tensor("out.filter_radii", P), self.tensor("out.filter_means2D", P, 2)
+
+
+def binding_trace(wrapper_module, rec, backward_alias=None):
+    """Drive a wrapper module (the reference's __init__.py or gaussianrpg_amd/rasterizer.py, its `_C`
+    already replaced by `rec`) through the calls the reference's callers make; returns the trace."""
+    import torch
+    P, H, W, S = 5, 4, 6, 2
+    out = {}
+    for scenario in ("sh_scales_rotations", "colors_cov3d"):
+        rec.calls.clear()
+        leaf = lambda label, *shape: rec.tensor("in." + label, *shape).requires_grad_(True)   # noqa: E731
+        rs = wrapper_module.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=0.5, tanfovy=0.25, bg=rec.tensor("rs.bg", 3),
+            scale_modifier=0.75, viewmatrix=rec.tensor("rs.viewmatrix", 4, 4),
+            projmatrix=rec.tensor("rs.projmatrix", 4, 4), sh_degree=1, campos=rec.tensor("rs.campos", 3),
+            prefiltered=False, debug=False)
+        ins = dict(means3D=leaf("means3D", P, 3), means2D=leaf("means2D", P, 3), opacities=leaf("opacities", P, 1),
+                   semantics=leaf("semantics", P, S))
+        if scenario == "sh_scales_rotations":
+            ins.update(shs=leaf("sh", P, 4, 3), scales=leaf("scales", P, 3), rotations=leaf("rotations", P, 4))
+        else:
+            ins.update(colors_precomp=leaf("colors_precomp", P, 3), cov3D_precomp=leaf("cov3Ds_precomp", P, 6))
+        rast = wrapper_module.GaussianRasterizer(rs)
+        outs = rast(**ins)
+        returned = [rec.describe(o) for o in outs]
+        gouts = [rec.tensor("gin." + n, *o.shape) for n, o in zip(("color", "radii", "depth", "alpha", "semantic"), outs)]
+        diff = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad]
+        torch.autograd.backward([o for o, _ in diff], [g for _, g in diff])
+        grads = {k: (rec.describe(v.grad) if v.grad is not None else None) for k, v in ins.items()}
+        vis = rast.markVisible(rec.tensor("in.positions", P, 3))
+        filt = rast.visible_filter(rec.tensor("in.filter_means3D", P, 3), scales=rec.tensor("in.filter_scales", P, 3),
+                                   rotations=rec.tensor("in.filter_rotations", P, 4))
+        calls = [[(backward_alias or {}).get(n, n), a] for n, a in rec.calls]
+        out[scenario] = dict(calls=calls, returned=returned, input_grads=grads,
+                             mark_visible_returns=rec.describe(vis), filter_returns=[rec.describe(t) for t in filt])
+    return out
