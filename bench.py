@@ -495,6 +495,11 @@ def main():
         if world > 1:
             tiny = torch.zeros(1, device=cdev)
             dist.all_reduce(tiny)          # warm the communicator outside the timed region
+            # ... and the gather's point-to-point channels, which RCCL sets up on first use (the
+            # warm-up frames above are not gathered): one frame travels now, twice
+            for _ in range(2):
+                dist.gather(local[:1] if backend == "nccl" else local[:1].cpu(),
+                            gather_list=[g[:1] for g in gather_bufs] if rank == 0 else None, dst=0)
         torch.cuda.synchronize()
 
         stage_timing = not args.no_stage_timing
