@@ -188,3 +188,42 @@ def test_backward_refuses_an_evaluation_forwards_blob(dev, lib):
     fr2 = Frame(lib, dev, sc, cam)
     rc, err = fr2.backward(poisoned(dev, fr2.P, fr2.M, ("mean2D", "opacity", "mean3D", "sh", "scale", "rot")))
     assert rc == 0, err
+
+
+def test_allocation_failures_are_reported_and_leave_the_library_usable(dev, lib):
+    """A grpg_alloc_fn that returns NULL -- for the geometry blob, the image blob or the binning blob
+    (the last one is asked for in the middle of the frame, behind launches that are already enqueued) --
+    makes grpg_forward return GRPG_ERR_ALLOC with a message, never a crash; the next call with a working
+    allocator renders the same frame as if nothing had happened."""
+    GRPG_ERR_ALLOC = -4
+    sc, cam = hz.toy_scene(2500, seed=17, sh_degree=1), hz.trajectory_camera(0, W=160, H=112)
+    good = Frame(lib, dev, sc, cam)
+    want = good.color.clone()
+    d = sc.to(dev)
+    P, H, W = d.means3D.shape[0], cam.image_height, cam.image_width
+    view, proj, campos = cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.campos.to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    for fail_at in (1, 2, 3):
+        blobs, calls = [], [0]
+
+        def alloc(nbytes, _user):
+            calls[0] += 1
+            if calls[0] == fail_at:
+                return 0
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            blobs.append(t)
+            return t.data_ptr()
+        cb = ALLOC(alloc)
+        color = torch.empty(3, H, W, device=dev)
+        depth, alpha = torch.empty(1, H, W, device=dev), torch.empty(1, H, W, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        rc = lib.grpg_forward(cb, None, cb, None, cb, None, P, sc.sh_degree, d.shs.shape[1], 0, p(bg), W, H,
+                              p(d.means3D), p(d.shs), None, None, p(d.opacity), p(d.scales), ctypes.c_float(1.0),
+                              p(d.rotations), None, p(view), p(proj), p(campos), ctypes.c_float(cam.tanfovx),
+                              ctypes.c_float(cam.tanfovy), 0, p(color), p(depth), p(alpha), None, p(radii), 0,
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert rc == GRPG_ERR_ALLOC, (fail_at, rc, lib.grpg_last_error())
+        assert b"allocation failed" in lib.grpg_last_error()
+        again = Frame(lib, dev, sc, cam)
+        assert again.R == good.R and torch.equal(again.color, want)
