@@ -517,3 +517,56 @@ def test_alternative_code_paths(dev, restore_policy, path):
             _C.set_capacity_hint(sc.means3D.shape[0], cam.image_width, cam.image_height, *cfg["hint"])
         got = _rasterize(dev, sc, cam, bg=bg)
         _check(got, o, max_fragile_frac=0.2 if case == "smoke_overdraw" else 0.05)
+
+
+def test_non_finite_inputs_do_not_take_the_library_down(dev):
+    """A diverged training run hands NaN / Inf parameters to the op.  The reference's behaviour there is
+    undefined (float -> int conversions of NaN in getRect, auxiliary.h:46-57), so there is nothing to be
+    equal to; what must hold: forward and backward return, no hand-over times out, nothing is written
+    outside the blobs (the next clean frame is bit-identical to the same frame rendered before), and the
+    Gaussians that are fine AND culled still get exactly zero gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = hz.toy_scene(3000, seed=23, sh_degree=1).to(dev)
+    cam = hz.trajectory_camera(0, W=208, H=144, device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1, bg=torch.zeros(3, device=dev))))
+    kw = dict(means3D=sc.means3D, opacities=sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    with torch.no_grad():
+        clean = [t.clone() for t in rast(means2D=None, **kw)[:4]]
+    nan, inf = float("nan"), float("inf")
+    bad = {k: v.clone() for k, v in kw.items()}
+    bad["means3D"][0] = nan
+    bad["means3D"][1, 2] = inf
+    bad["means3D"][2] = torch.tensor([inf, -inf, 5.0])
+    bad["scales"][3] = nan
+    bad["scales"][4] = 1e38
+    bad["scales"][5] = inf
+    bad["scales"][6] = -1.0
+    bad["rotations"][7] = 0.0
+    bad["rotations"][8] = nan
+    bad["rotations"][9] = inf
+    bad["opacities"][10] = nan
+    bad["opacities"][11] = inf
+    bad["opacities"][12] = -inf
+    bad["shs"][13] = nan
+    bad["shs"][14] = inf
+    with torch.no_grad():
+        out = rast(means2D=None, **bad)
+        torch.cuda.synchronize()
+        assert out[0].shape == clean[0].shape and out[1].shape == clean[1].shape
+    # training step on the same inputs
+    leaves = {k: v.clone().requires_grad_(True) for k, v in bad.items()}
+    m2 = torch.zeros(3000, 3, device=dev, requires_grad=True)
+    color, radii, depth, alpha, _ = rast(means2D=m2, **leaves)
+    (torch.nan_to_num(color).sum() + torch.nan_to_num(depth).sum() + torch.nan_to_num(alpha).sum()).backward()
+    torch.cuda.synchronize()
+    for k, v in leaves.items():
+        assert v.grad is not None and v.grad.shape == v.shape, k
+    culled_fine = (radii == 0)
+    culled_fine[:15] = False
+    assert float(leaves["means3D"].grad[culled_fine].abs().max()) == 0.0
+    # the library and the device are fine: the clean frame again, bit for bit
+    with torch.no_grad():
+        again = rast(means2D=None, **kw)[:4]
+        torch.cuda.synchronize()
+    for a, b in zip(again, clean):
+        assert torch.equal(a, b)
