@@ -80,9 +80,10 @@ def draw(seed, max_P, max_side):
 # more draws for a bug hunt: GRPG_SWEEP_FORWARD=300 GRPG_SWEEP_BACKWARD=100 python -m pytest tests/test_gpu_sweep.py
 N_FORWARD = int(os.environ.get("GRPG_SWEEP_FORWARD", "40"))
 N_BACKWARD = int(os.environ.get("GRPG_SWEEP_BACKWARD", "16"))
+OFFSET = int(os.environ.get("GRPG_SWEEP_OFFSET", "0"))      # other draws: GRPG_SWEEP_OFFSET=5000
 
 
-@pytest.mark.parametrize("seed", range(N_FORWARD))
+@pytest.mark.parametrize("seed", range(OFFSET, OFFSET + N_FORWARD))
 def test_forward_sweep(dev, seed):
     d = draw(seed, max_P=60000, max_side=420)
     sc, cam = d["sc"], d["cam"]
@@ -97,7 +98,7 @@ def test_forward_sweep(dev, seed):
     _check(got, o, max_fragile_frac=0.25)
 
 
-@pytest.mark.parametrize("seed", range(1000, 1000 + N_BACKWARD))
+@pytest.mark.parametrize("seed", range(OFFSET + 1000, OFFSET + 1000 + N_BACKWARD))
 def test_backward_sweep(dev, seed):
     d = draw(seed, max_P=12000, max_side=200)
     r = np.random.RandomState(seed)
