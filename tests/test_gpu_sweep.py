@@ -108,3 +108,35 @@ def test_backward_sweep(dev, seed):
          # the dense draws reach the list lengths of test_backward_long_lists: its bar; where the
          # oracle's own T_final cancellation exceeds it, float64 autograd arbitrates (_grad_close)
          miss_frac=STRICT_MISS_FRAC_LONG_LISTS, with_truth=True)
+
+
+ALT = {"sort_binning": dict(alg=0), "exact_mode": dict(mode=1), "overflow": dict(hint=True)}
+
+
+@pytest.mark.parametrize("seed", range(OFFSET + 2000, OFFSET + 2000 + max(N_FORWARD // 4, 1)))
+@pytest.mark.parametrize("path", list(ALT))
+def test_forward_sweep_alternative_schedules(dev, seed, path):
+    """The same draws through the schedules the defaults do not take (test_gpu_forward.ALT_PATHS): emit +
+    stable partition instead of the hierarchical binning, the reference-like mid-frame wait, and a frame
+    that overflows the capacity it was promised and re-runs its tail."""
+    from gaussianrpg_amd.rasterizer import _C
+    d = draw(seed, max_P=60000, max_side=420)
+    sc, cam = d["sc"], d["cam"]
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       **oracle_kwargs(cam, sc.sh_degree, bg=d["bg"], scale_modifier=d["scale_modifier"]))
+    alg = _C.get_binning_algorithm()
+    try:
+        cfg = ALT[path]
+        if "mode" in cfg:
+            _C.set_binning_mode(cfg["mode"])
+        if "alg" in cfg:
+            _C.set_binning_algorithm(cfg["alg"])
+        if "hint" in cfg:   # a third of what the frame needs (at least one granule is always carved)
+            R = max(int(o["num_rendered"]) // 3, 1)
+            _C.set_capacity_hint(sc.means3D.shape[0], cam.image_width, cam.image_height, R, R)
+        got = _rasterize(dev, sc, cam, bg=d["bg"], scale_modifier=d["scale_modifier"])
+        _check(got, o, max_fragile_frac=0.25)
+    finally:
+        _C.set_binning_mode(0)      # speculative: the default (test_gpu_forward.restore_policy)
+        _C.set_binning_algorithm(alg)
+        _C.reset_capacity_hints()
