@@ -306,7 +306,13 @@ inline ImgLayout img_layout(size_t T, size_t N) {
 //   shorter: one wave per tile (light).
 // A frame with semantic planes sends every non-empty tile down the heavy path (heavy_min = 1), whose
 // one-pixel-per-lane waves carry the extra accumulators.
-constexpr uint32_t RENDER_PC_MIN = 8192, RENDER_C1_MIN = 2048, RENDER_HEAVY_MIN = 256;
+#ifndef GRPG_RENDER_PC_MIN      // experiment builds override the class boundaries
+#define GRPG_RENDER_PC_MIN 8192
+#endif
+#ifndef GRPG_RENDER_C1_MIN
+#define GRPG_RENDER_C1_MIN 2048
+#endif
+constexpr uint32_t RENDER_PC_MIN = GRPG_RENDER_PC_MIN, RENDER_C1_MIN = GRPG_RENDER_C1_MIN, RENDER_HEAVY_MIN = 256;
 constexpr int RENDER_NSEM = 16;   // semantic channels fused into the main render launch
 static_assert(RENDER_HEAVY_MIN <= CK_LONG_MIN, "lists with blend checkpoints must take the heavy path");
 struct TileClasses { uint32_t c0_min, c1_min, heavy_min; };
