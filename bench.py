@@ -116,6 +116,9 @@ def parse():
                     help="0 speculative binning capacity + deferred num_rendered wait (default), "
                          "1 exact (reference-like mid-frame wait)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, count them with one all_reduce, print "
+                         "that and exit (no rendering: checks the launch path, also without a GPU)")
     return ap.parse_args()
 
 
@@ -356,6 +359,43 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
                                           "render_backward_kernel launch, DESIGN.md §7), not HBM-bound"}}
 
 
+def _self_launch(n):
+    """Re-run this very command line as n ranks of one node (the driver's N > 1 form, started by
+    bench.py itself when no launcher set WORLD_SIZE); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:           # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // n)))
+    print("bench.py: --gpus %d without a launcher, starting %d ranks: %s" % (n, n, " ".join(cmd[1:9])),
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def _rendezvous_only(world, rank):
+    """The launch path alone: process group over the job's backend, one all_reduce of ones."""
+    backend = os.environ.get("GRPG_BENCH_BACKEND", "nccl")
+    seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
+        ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        seen = int(ones.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks_seen": seen,
+                          "collective_backend": "rccl" if backend == "nccl" else backend}), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -367,9 +407,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per
+        # GPU under torch.distributed.run, rendezvous on 127.0.0.1) and hand their JSON line through
+        raise SystemExit(_self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d (or without a launcher: bench.py starts its own ranks)"
+                         % (args.gpus, world, args.gpus))
+    if args.rendezvous_only:
+        return _rendezvous_only(world, rank)
     assert torch.cuda.is_available(), "bench.py needs ROCm devices (no CPU fallback exists)"
     torch.set_num_threads(max(1, min(effective_cores() // max(world, 1), 16)))   # host-side scene synthesis
     # GRPG_BENCH_BACKEND=gloo is a single-GPU debugging aid only (all ranks share cuda:0, the
@@ -449,6 +496,7 @@ def main():
             st_.wait_stream(torch.cuda.current_stream())
 
         redone_frames = [0]
+        ranks_seen = [1]
 
         def frame_loop(n, first_frame=0, do_gather=False):
             """n frames alternating over the streams; returns the pending gather handles."""
@@ -495,6 +543,9 @@ def main():
         if world > 1:
             tiny = torch.zeros(1, device=cdev)
             dist.all_reduce(tiny)          # warm the communicator outside the timed region
+            ones = torch.ones(1, device=cdev)
+            dist.all_reduce(ones)          # every rank that really takes part adds one
+            ranks_seen[0] = int(ones.item())
             # ... and the gather's point-to-point channels, which RCCL sets up on first use (the
             # warm-up frames above are not gathered): one frame travels now, twice
             for _ in range(2):
@@ -813,6 +864,8 @@ def main():
                        "deferred_count": args.entry == "deferred", "frames_rendered_twice": redone_frames[0],
                        "gather_batch_frames": args.gather_batch if world > 1 else None,
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
+            "collective_backend": (("rccl" if backend == "nccl" else backend) if world > 1 else None),
+            "rccl_ranks_seen": ranks_seen[0],     # all_reduce of ones over the job's process group
             "roofline": roof,
             "roofline_overlapped": roof_overlapped,
             "roofline_valu": roof_valu,
