@@ -92,6 +92,9 @@ def parse():
                          "static models (background) are rendered along the synthetic drive "
                          "(gaussianrpg_amd/checkpoint.py).  Not the BASELINE workload: reported as data = "
                          "'checkpoint:<file>'")
+    ap.add_argument("--trust-checkpoint", action="store_true",
+                    help="allow the full unpickler for a .pth that weights_only=True cannot read "
+                         "(a non-final checkpoint; executes code from the file)")
     ap.add_argument("--checkpoint-models", default=None,
                     help="comma-separated model names to render (default: every static model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -443,7 +446,7 @@ def main():
 
     if args.checkpoint:
         from gaussianrpg_amd import checkpoint as ckpt
-        loaded = ckpt.load_checkpoint(args.checkpoint)
+        loaded = ckpt.load_checkpoint(args.checkpoint, allow_unsafe=args.trust_checkpoint)
         names = args.checkpoint_models.split(",") if args.checkpoint_models else None
         scene_cpu = ckpt.activated_scene(loaded, names)
         if rank == 0:

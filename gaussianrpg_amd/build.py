@@ -141,6 +141,13 @@ EXPERIMENT_VARIANTS = {
     "classicsort": {"api.hip": ["-DGRPG_FORCE_CLASSIC_SORT"]},
     # 96 registers / 101 KB of LDS per sort workgroup: room for another stream's workgroup on the same CU
     "sortlean": {"sort.hip": ["-DGRPG_SORT_LEAN"]},
+    # round 5: the producer / consumer PAIRS of round 2-4 for the class-0 tiles instead of the three-stage
+    # wave pipeline (A/B of the pipeline), and the pipeline from 4096 / 16384 entries
+    "pcpair": {"render_fwd.hip": ["-DGRPG_RENDER_PIPE=0"]},
+    "pipe4096": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=4096"], "api.hip": ["-DGRPG_RENDER_PC_MIN=4096"],
+                 "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=4096"]},
+    "pipe16384": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=16384"], "api.hip": ["-DGRPG_RENDER_PC_MIN=16384"],
+                  "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=16384"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

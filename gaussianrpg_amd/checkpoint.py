@@ -126,9 +126,14 @@ class LoadedScene:
 _MODEL_KEYS = ("xyz", "feature_dc", "feature_rest", "scaling", "rotation", "opacity")
 
 
-def load_checkpoint(path: str) -> LoadedScene:
+def load_checkpoint(path: str, allow_unsafe: bool = False) -> LoadedScene:
     """``.pth`` (StreetGaussianModel.save_state_dict, or a bare GaussianModel.state_dict) or ``.ply``
-    (one ``vertex_<model>`` element per model, or a single ``vertex`` element) -> LoadedScene."""
+    (one ``vertex_<model>`` element per model, or a single ``vertex`` element) -> LoadedScene.
+
+    A ``.pth`` is read with ``torch.load(weights_only=True)``.  A non-final checkpoint of the
+    reference (optimizer state, bidict objects) needs the full unpickler, which EXECUTES code found
+    in the file: that is only done when the caller says the file is trusted (``allow_unsafe=True``,
+    ``bench.py --trust-checkpoint``), never as a silent fallback."""
     ext = os.path.splitext(path)[1].lower()
     models = OrderedDict()
     if ext == ".ply":
@@ -139,7 +144,15 @@ def load_checkpoint(path: str) -> LoadedScene:
     else:
         try:
             sd = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception:      # optimizer state / bidict objects of a non-final checkpoint
+        except Exception as e:      # optimizer state / bidict objects of a non-final checkpoint
+            if not allow_unsafe:
+                raise ValueError(
+                    "%s cannot be read with torch.load(weights_only=True) (%s: %s).  If it is a non-final "
+                    "checkpoint of the reference and you TRUST the file, pass allow_unsafe=True "
+                    "(bench.py --trust-checkpoint): the full unpickler executes code from the file."
+                    % (path, type(e).__name__, str(e).splitlines()[0] if str(e) else "")) from e
+            import warnings
+            warnings.warn("loading %s with the full (unsafe) unpickler on the caller's request" % path)
             sd = torch.load(path, map_location="cpu", weights_only=False)
         if all(k in sd for k in _MODEL_KEYS):
             sd = {"background": sd}

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,8 +45,13 @@ struct HostWord {
   hipEvent_t ev = nullptr;
 };
 // released when the owning thread exits (as the deferred-frame ring below)
+// ... except on the MAIN thread: its thread_local destructors run during process exit, when the HIP
+// runtime may already be shutting down (Python finalisation with the torch extension loaded); calling
+// into it then is a known source of exit-time errors, and the OS reclaims the memory anyway.
+static bool on_main_thread() { return (long)syscall(SYS_gettid) == (long)getpid(); }
 struct HostWords : std::vector<HostWord> {
   ~HostWords() {
+    if (on_main_thread()) return;
     for (auto& h : *this) {
       if (h.host_ptr) (void)hipHostFree(h.host_ptr);
       if (h.ev) (void)hipEventDestroy(h.ev);
@@ -95,6 +103,7 @@ constexpr int DEFER_SLOTS = GRPG_MAX_DEFERRED_FRAMES;
 struct DeferRing {
   DeferSlot slot[DEFER_SLOTS];
   ~DeferRing() {
+    if (on_main_thread()) return;   // process exit: see HostWords
     for (auto& d : slot) {
       if (d.host_ptr) (void)hipHostFree(d.host_ptr);
       if (d.ev) (void)hipEventDestroy(d.ev);
@@ -109,7 +118,8 @@ struct CapHint {
   CapKey key{-1, 0, 0, 0};
   uint32_t high = 0;      // decaying high-water mark of num_rendered
   uint32_t high_c = 0;    // same for the coarse (Gaussian, super-tile) count of the hierarchical binning
-  bool far = true;        // the last frame's depth keys needed the fourth sort pass (sort.hip key_far)
+  bool far = true;        // a recent frame's depth keys needed the fourth sort pass (sort.hip key_far)
+  uint32_t far_hold = 0;  // near frames left before `far` is dropped again (sticky with decay, below)
   uint32_t once = 0, once_c = 0;   // grpg_set_capacity_hint: exact capacities for the next frame only
   bool seen = false;      // a frame of this shape has reported its counts (high / high_c / far are real)
   uint64_t stamp = 0;     // last use (LRU replacement)
@@ -176,7 +186,14 @@ void update_hint(const CapKey& k, uint32_t R, uint32_t Rc, bool far) {
   const uint32_t dc = slot->high_c - slot->high_c / 64;
   slot->high_c = Rc > dc ? Rc : dc;
   if (slot->high_c > slot->high) slot->high_c = slot->high;
-  slot->far = far;
+  // Sticky with decay: frames alternating between a near and a far depth range under one
+  // (device, P, W, H) -- two cameras, two scenes of one size -- would otherwise enqueue every far frame
+  // without its fourth pass and render it twice.  An enqueued-but-idle fourth pass costs two launch
+  // boundaries (~9 us of a single stream); it is dropped after FAR_HOLD consecutive near frames.
+  constexpr uint32_t FAR_HOLD = 32;
+  if (far) slot->far_hold = FAR_HOLD;
+  else if (slot->far_hold > 0u) slot->far_hold--;
+  slot->far = slot->far_hold > 0u;
   slot->seen = true;
   slot->stamp = ++g_hint_clock;
 }
@@ -339,12 +356,29 @@ void remember_geom(const void* ptr, int P, bool has_grad) {
   }
   slot->ptr = ptr; slot->P = P; slot->has_grad = has_grad; slot->stamp = ++g_geom_clock;
 }
-// false only when the blob is KNOWN to lack the gradient records
-bool geom_may_take_backward(const void* ptr, int P) {
-  std::lock_guard<std::mutex> lk(g_geom_mu);
-  for (auto& g : g_geom_seen)
-    if (g.ptr == ptr && g.P == P) return g.has_grad;
-  return true;
+// The table is ADVISORY: entries are never invalidated when a caller frees or copies a
+// blob, so only its "yes, the training forward of this P carved that address" answer is taken as is
+// (the training loop's case: no host round trip).  A "no" (possibly stale: a reloaded training blob
+// at an address an evaluation forward used) or an unknown address is settled by the geometry header
+// itself -- one 4-byte read behind the stream's work, off the hot path.
+// returns GRPG_OK, or the error the backward must return
+int geom_check_backward(const void* ptr, int P, hipStream_t stream) {
+  {
+    std::lock_guard<std::mutex> lk(g_geom_mu);
+    for (auto& g : g_geom_seen)
+      if (g.ptr == ptr && g.P == P && g.has_grad) return GRPG_OK;
+  }
+  BlobHeader h;
+  hipError_t e = hipMemcpyAsync(&h, ptr, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return fail(GRPG_ERR_HIP, std::string("reading the geometry header: ") + hipGetErrorString(e));
+  if (h.magic != GEOM_MAGIC || h.P != (uint32_t)P)
+    return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer does not hold a forward of this P (magic / P)");
+  if (h.has_grad_rec == 0u)
+    return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer was carved by an evaluation forward "
+                                     "(GRPG_FORWARD_NO_BACKWARD): it has no room for the backward's gradient records");
+  remember_geom(ptr, P, true);
+  return GRPG_OK;
 }
 
 CameraArgs make_camera(const float* view, const float* proj, const float* campos, int W, int H,
@@ -1110,9 +1144,7 @@ int grpg_backward_composed(const grpg_model_segment* segments, const grpg_model_
     return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M <= 16");
   if (!grads || !geom_buffer || !binning_buffer || !image_buffer)
     return fail(GRPG_ERR_BAD_BUFFER, "NULL gradient table / state buffer");
-  if (!geom_may_take_backward(geom_buffer, P))
-    return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer was carved by an evaluation forward "
-                                     "(GRPG_FORWARD_NO_BACKWARD): it has no room for the backward's gradient records");
+  if (int rc = geom_check_backward(geom_buffer, P, (hipStream_t)hip_stream)) return rc;
   for (auto& hw : g_host_words)
     if (int rc = check_async_error(&hw)) return rc;
   if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas || !dL_dmean2D || !dL_dposes || !radii ||
@@ -1236,9 +1268,7 @@ int grpg_backward(int P, int D, int M, int R, int S, const float* background, in
   if (P <= 0) return GRPG_OK;
   if (!geom_buffer || !binning_buffer || !image_buffer)
     return fail(GRPG_ERR_BAD_BUFFER, "NULL state buffer");
-  if (!geom_may_take_backward(geom_buffer, P))
-    return fail(GRPG_ERR_BAD_BUFFER, "the geometry buffer was carved by an evaluation forward "
-                                     "(GRPG_FORWARD_NO_BACKWARD): it has no room for the backward's gradient records");
+  if (int rc = geom_check_backward(geom_buffer, P, (hipStream_t)hip_stream)) return rc;
   for (auto& hw : g_host_words)
     if (int rc = check_async_error(&hw)) return rc;
   // dL_dconic / dL_ddepth (pure intermediates of the reference's binding) and dL_dcolor / dL_dcov3D

@@ -243,14 +243,10 @@ __device__ __forceinline__ void store_pair_half(float4* __restrict__ my, const i
   if (WITH_ID) f[22] = __uint_as_float(id);
 }
 
-// Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
-template <bool AUX = true, int NSEM = 0>
-__device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
-                                           const int j0, const float pxf, const float pyf,
-                                           SemAcc<NSEM>* sa = nullptr, const SemSrc sem = SemSrc{nullptr, 0}) {
-  const float4* blk = my + (j0 >> 1) * PAIR_F4;
-  float alpha[4];
-  uint64_t ok[4];
+// The accept half of a quad: alpha and the lanes that take the splat, for the four slots of blk
+// (two pair blocks).  One body for every caller, so that they all get the same bits.
+__device__ __forceinline__ void eval_quad(const float4* __restrict__ blk, const float pxf, const float pyf,
+                                          float (&alpha)[4], uint64_t (&ok)[4]) {
   const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -264,6 +260,30 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
     ok[2 * h + 0] = lanes(!(p.x > 0.0f)) & lanes(!(alpha[2 * h + 0] < ALPHA_MIN));
     ok[2 * h + 1] = lanes(!(p.y > 0.0f)) & lanes(!(alpha[2 * h + 1] < ALPHA_MIN));
   }
+}
+
+// The blend half of a quad, given alpha[i] and ok[i] of its four slots.
+template <bool AUX, int NSEM>
+__device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const float4* __restrict__ blk,
+                                                const float (&alpha)[4], const uint64_t (&ok)[4],
+                                                SemAcc<NSEM>* sa, const SemSrc sem);
+
+// Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
+template <bool AUX = true, int NSEM = 0>
+__device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
+                                           const int j0, const float pxf, const float pyf,
+                                           SemAcc<NSEM>* sa = nullptr, const SemSrc sem = SemSrc{nullptr, 0}) {
+  const float4* blk = my + (j0 >> 1) * PAIR_F4;
+  float alpha[4];
+  uint64_t ok[4];
+  eval_quad(blk, pxf, pyf, alpha, ok);
+  return blend_quad_tail<AUX, NSEM>(s, blk, alpha, ok, sa, sem);
+}
+
+template <bool AUX, int NSEM>
+__device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const float4* __restrict__ blk,
+                                                const float (&alpha)[4], const uint64_t (&ok)[4],
+                                                SemAcc<NSEM>* sa, const SemSrc sem) {
   const uint64_t live = ~s.done[0];
   if (((ok[0] | ok[1] | ok[2] | ok[3]) & live) == 0ull) return false;
   // The transmittance chain of the four splats first, with alpha = 0 in the lanes that reject a
@@ -927,6 +947,275 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Class 0, round 5: a THREE-STAGE WAVE PIPELINE per quarter (one quarter per workgroup).
+//
+// With the producer / consumer pairs the launch is as long as the consumer's walk of the ~100 longest
+// lists: ~80 cycles per surviving splat on a wave that issues one instruction per 5-6 cycles whatever
+// it does (a launch holding a quarter of the frame's work still takes 0.195 ms).
+// Cutting the LIST into segments re-does the expensive all-pixels-live head of the walk in every
+// segment (built twice in rounds 1-2: slower).  Cutting the WORK PER SPLAT keeps the walk sequential
+// and its arithmetic bit for bit: the accept half of a quad (power, exp2, alpha, the two tests -- 60 %
+// of the consumer's instructions, and independent of the pixel's state) moves to two EVALUATOR waves,
+// which leave alpha (0 where the lane rejects the splat) in LDS; the BLENDER wave runs only what
+// really is a chain -- the transmittance products, the colour accumulation, termination.
+//
+//   wave 1  PRODUCER   FILL / POP / cull / compaction as before, into PL_NB batch slots (s_rec)
+//   wave 2, 3  EVALUATORS  chunks of PL_CHUNK_Q quads, alternately: eval_quad -> alpha chunk k, ok-any masks
+//   wave 0  BLENDER    blend_quad_tail over the chunks in order; checkpoints, live box, stop, outputs
+//
+// Hand-over: single-writer, monotone words in LDS (workgroup-scope acquire / release, no barrier after
+// the start, nothing is ever reset -- no ABA):
+//   bseq[slot]   producer : ((n + 1) << 7) | cnt   batch n is in slot n % PL_NB (cnt 127: end of list)
+//   eprog[k]     evaluator k: batches it has passed;  bprog  blender: batches blended
+//                -> the producer refills a slot once all three are beyond its previous tenant
+//   aseq[k]      evaluator k: id + 1 of the chunk in its alpha buffer
+//   acons[k]     blender: id + 1 of the last chunk of buffer k it has consumed
+// Chunk ids follow from the batches' counts, which every reader takes from bseq in the same order;
+// evaluator k owns the chunks with id % 2 == k and alpha buffer k.  Spin loops are bounded like the
+// pairs' (pc_fail).
+// ------------------------------------------------------------------------------------------
+#ifndef GRPG_RENDER_PIPE
+#define GRPG_RENDER_PIPE 1
+#endif
+constexpr int PL_NB = 4;                      // batch slots: 4 x 3 KB = s_rec
+constexpr int PL_CHUNK_Q = 8;                 // quads per alpha chunk (32 survivors, 8 KB)
+constexpr uint32_t PL_END = 127u;
+struct PLCtrl {
+  uint32_t bseq[PL_NB];
+  uint32_t eprog[2], bprog, stop;
+  uint32_t aseq[2], acons[2];
+  float box[4];
+  uint32_t okany[2][PL_CHUNK_Q][2];          // per chunk buffer and quad: lanes that accept any of its splats
+};
+
+// returns false on stop / time-out
+template <class Cond>
+__device__ __forceinline__ bool pl_wait(PLCtrl* __restrict__ ctl, const PCErr err, const int lane, Cond ready) {
+  uint32_t spins = 0;
+  while (!ready()) {
+    if (pc_load(&ctl->stop) != 0u) return false;
+    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); pc_store(&ctl->stop, 1u); return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+template <bool WITH_ID = false>
+__device__ __forceinline__ void pl_producer(float4* __restrict__ slots /* PL_NB x WAVE*REC_F4 */,
+                                            uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
+                                            PLCtrl* __restrict__ ctl, const int lane,
+                                            const int quarter, const uint32_t r_begin,
+                                            const uint32_t r_end,
+                                            const uint32_t* __restrict__ point_list,
+                                            const RecView rec, const PCErr err) {
+  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
+  const uint64_t lt = lanemask_lt();
+  uint32_t in_pos = r_begin, head = 0, count = 0;
+  uint32_t win[FILL_Q];
+#pragma unroll
+  for (int q = 0; q < FILL_Q; q++) {
+    const uint32_t i = in_pos + q * WAVE + lane;
+    win[q] = i < r_end ? point_list[i] : 0u;
+  }
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+  uint32_t pos = 0, idc = 0, ncur = 0;
+  uint32_t n = 0;   // batches published
+  const auto slot_free = [&]() {
+    return n < (uint32_t)PL_NB || (pc_load(&ctl->bprog) + PL_NB > n && pc_load(&ctl->eprog[0]) + PL_NB > n &&
+                                   pc_load(&ctl->eprog[1]) + PL_NB > n);
+  };
+  for (;;) {
+    if (pc_load(&ctl->stop) != 0u) return;
+    // ---- FILL ----
+    while (count < (uint32_t)WAVE && in_pos < r_end) {
+      uint32_t v[FILL_Q];
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
+      const uint32_t nxt = in_pos + FILL_Q * WAVE;
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = nxt + q * WAVE + lane;
+        win[q] = i < r_end ? point_list[i] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = in_pos + q * WAVE + lane;
+        const bool keep = (i < r_end) && (v[q] & bit);
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
+          qid[slot] = v[q] & ID_MASK;
+          qpos[slot] = i - r_begin + 1;
+        }
+        count += (uint32_t)__popcll(m);
+      }
+      in_pos = nxt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- POP ----
+    const uint32_t nn = min(count, (uint32_t)WAVE);
+    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
+    uint32_t pos_n = 0, id_n = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (QCAP - 1);
+      id_n = qid[slot];
+      pos_n = qpos[slot];
+      rec.load(id_n, a_n, b_n, c_n);
+    }
+    head = (head + nn) & (QCAP - 1);
+    count -= nn;
+    // ---- cull + compact the previous batch into the next slot, publish it ----
+    if (ncur > 0) {
+      const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
+      const bool keep = ((uint32_t)lane < ncur) &&
+                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
+      const uint64_t mask = __ballot(keep);
+      const int cnt = (int)__popcll(mask);
+      if (cnt > 0) {
+        if (!pl_wait(ctl, err, lane, slot_free)) return;
+        float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
+        if (keep)
+          store_pair_half<WITH_ID>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                                   make_float4(b.w, c.x, c.y, a.z), pos, idc);
+        if (lane < ((4 - (cnt & 3)) & 3)) {
+          const SplatQ zq = {0.f, 0.f, 0.f};
+          store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
+        }
+        pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | (uint32_t)cnt);
+        n++;
+      }
+    }
+    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
+    if (ncur == 0 && in_pos >= r_end) break;
+  }
+  if (!pl_wait(ctl, err, lane, slot_free)) return;   // end-of-list marker
+  pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | PL_END);
+}
+
+__device__ __forceinline__ void pl_evaluator(const float4* __restrict__ slots, float4* __restrict__ abuf /* mine */,
+                                             PLCtrl* __restrict__ ctl, const int k, const int lane,
+                                             const int x0, const int y0, const PCErr err) {
+  const float pxf = (float)(x0 + (lane & 15)), pyf = (float)(y0 + (lane >> 4));
+  uint32_t chunk = 0;
+  for (uint32_t n = 0;; n++) {
+    uint32_t f = 0;
+    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; })) return;
+    const uint32_t cnt = f & 127u;
+    if (cnt == PL_END) return;
+    const float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
+    const int nq = (int)((cnt + 3u) >> 2);
+    for (int q0 = 0; q0 < nq; q0 += PL_CHUNK_Q, chunk++) {
+      if ((int)(chunk & 1u) != k) continue;
+      // my alpha buffer is free once the blender is through my previous chunk (id chunk - 2)
+      if (chunk >= 2u && !pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->acons[k]) + 1u >= chunk; })) return;
+      const int q1 = min(nq, q0 + PL_CHUNK_Q);
+      for (int q = q0; q < q1; q++) {
+        float alpha[4];
+        uint64_t ok[4];
+        eval_quad(my + q * 2 * PAIR_F4, pxf, pyf, alpha, ok);
+        float4 am;
+        am.x = in_mask(ok[0]) ? alpha[0] : 0.0f;
+        am.y = in_mask(ok[1]) ? alpha[1] : 0.0f;
+        am.z = in_mask(ok[2]) ? alpha[2] : 0.0f;
+        am.w = in_mask(ok[3]) ? alpha[3] : 0.0f;
+        abuf[(q - q0) * WAVE + lane] = am;
+        const uint64_t any = ok[0] | ok[1] | ok[2] | ok[3];
+        if (lane == 0) { ctl->okany[k][q - q0][0] = (uint32_t)any; ctl->okany[k][q - q0][1] = (uint32_t)(any >> 32); }
+      }
+      pc_store(&ctl->aseq[k], chunk + 1u);
+    }
+    pc_store(&ctl->eprog[k], n + 1u);
+  }
+}
+
+template <bool AUX = true, int NSEM = 0>
+__device__ __forceinline__ void pl_blender(const float4* __restrict__ slots, const float4* __restrict__ abuf0,
+                                           const float4* __restrict__ abuf1, PLCtrl* __restrict__ ctl,
+                                           const int lane, const int x0, const int y0, const int W, const int H,
+                                           const float* __restrict__ bg,
+                                           float* __restrict__ out_color, float* __restrict__ out_depth,
+                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+                                           CkptWriter ckw, const uint32_t len, const PCErr err,
+                                           const SemSrc sem = SemSrc{nullptr, 0},
+                                           float* __restrict__ out_semantic = nullptr) {
+  SemAcc<NSEM> sa;
+#pragma unroll
+  for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
+  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
+  const float pxf = (float)px;
+  WavePix<1> st;
+  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f};
+  st.last[0] = 0;
+  st.done[0] = lanes(!(px < W && py < H));
+  uint64_t prev_alive = ~0ull;
+  uint32_t chunk = 0;
+  if (~st.done[0] == 0ull) pc_store(&ctl->stop, 1u);   // nothing to do (quarter outside the image)
+  else for (uint32_t n = 0;; n++) {
+    uint32_t f = 0;
+    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; })) break;
+    const uint32_t cnt = f & 127u;
+    if (cnt == PL_END) break;
+    const float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
+    const int nq = (int)((cnt + 3u) >> 2);
+    bool lost = false;
+    for (int q0 = 0; q0 < nq; q0 += PL_CHUNK_Q, chunk++) {
+      const int k = (int)(chunk & 1u);
+      if (!pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->aseq[k]) == chunk + 1u; })) { lost = true; break; }
+      const float4* ab = k ? abuf1 : abuf0;
+      const uint32_t* okw = &ctl->okany[k][lane & (PL_CHUNK_Q - 1)][0];
+      const uint32_t ok_lo = okw[0], ok_hi = okw[1];
+      const int q1 = min(nq, q0 + PL_CHUNK_Q);
+      for (int q = q0; q < q1; q++) {
+        const uint64_t any = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ok_lo, q - q0) |
+                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ok_hi, q - q0) << 32);
+        if ((any & ~st.done[0]) == 0ull) continue;   // no live lane takes any splat of this quad
+        const float4 am = ab[(q - q0) * WAVE + lane];
+        const float alpha[4] = {am.x, am.y, am.z, am.w};
+        const uint64_t ok[4] = {lanes(am.x != 0.0f), lanes(am.y != 0.0f), lanes(am.z != 0.0f), lanes(am.w != 0.0f)};
+        blend_quad_tail<AUX, NSEM>(st, my + q * 2 * PAIR_F4, alpha, ok, &sa, sem);
+      }
+      pc_store(&ctl->acons[k], chunk + 1u);
+    }
+    if (lost) break;
+    if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
+      const float* blk = reinterpret_cast<const float*>(my + (((int)cnt - 1) >> 1) * PAIR_F4);
+      ckpt_batch_end(ckw, lane, st,
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(blk[20 + (((int)cnt - 1) & 1)])));
+    }
+    pc_store(&ctl->bprog, n + 1u);   // hand the batch slot back
+    const uint64_t alive = ~st.done[0];
+    if (alive == 0ull) { pc_store(&ctl->stop, 1u); break; }
+    if (alive != prev_alive) {   // shrink the producer's cull box to the live pixels
+      prev_alive = alive;
+      const bool dn = in_mask(st.done[0]);
+      float bx0 = dn ? 3e38f : pxf, bx1 = dn ? -3e38f : pxf;
+      float by0 = dn ? 3e38f : (float)py, by1 = dn ? -3e38f : (float)py;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+        by0 = fminf(by0, __shfl_xor(by0, d, 64));
+        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+      }
+      if (lane == 0) { ctl->box[0] = bx0; ctl->box[1] = bx1; ctl->box[2] = by0; ctl->box[3] = by1; }
+    }
+  }
+  if (AUX) ckpt_finish(ckw, lane, st, len);
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const size_t HW = (size_t)H * W;
+  if (px < W && py < H) {
+    const size_t pix = (size_t)py * W + px;
+    out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
+    out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
+    out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
+    out_alpha[pix] = 1.0f - st.T[0];
+    out_depth[pix] = st.CbD[0].y;
+    if (AUX) n_contrib[pix] = st.last[0];
+    if (NSEM > 0) sem_write<NSEM>(sa, sem.S, out_semantic, HW, pix);
+  }
+}
+
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
 // 112 KB of LDS per CU so that the other stream's sort workgroups can co-reside) measured slightly
 // ahead of 5 (96 VGPRs, 136 B of scratch per lane): 0.327 vs 0.333 ms, 1640 vs 1600 frames/s.
@@ -947,10 +1236,26 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const uint32_t pc_slots, const CkptArgs ck, const PCErr pc_err,
                       const SemSrc sem, float* __restrict__ out_semantic,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
-  __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
-  __shared__ uint32_t s_qid[RW_WAVES][QCAP];
-  __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
-  __shared__ PCCtrl s_ctl[2];
+  // one object, members in this order: the class-0 pipeline uses qid + qpos as ONE 16 KB area
+  struct RenderLds {
+    float4 rec[RW_WAVES][WAVE * REC_F4];   // 12 KB: per-wave survivor slabs | pipeline: PL_NB batch slots
+    uint32_t qid[RW_WAVES][QCAP];          //  8 KB: per-wave rings          | pipeline: the two alpha chunk
+    uint32_t qpos[RW_WAVES][QCAP];         //  8 KB                          |   buffers (2 x 8 KB)
+#if GRPG_RENDER_PIPE
+    uint32_t pq[2][QCAP];                  //  4 KB: the pipeline producer's ring
+    PLCtrl pl;
+#else
+    PCCtrl ctl[2];
+#endif
+  };
+  __shared__ RenderLds L;
+  auto& s_rec = L.rec;
+  auto& s_qid = L.qid;
+  auto& s_qpos = L.qpos;
+#if !GRPG_RENDER_PIPE
+  auto& s_ctl = L.ctl;
+#endif
+  static_assert(sizeof(L.qid) + sizeof(L.qpos) >= 2 * PL_CHUNK_Q * WAVE * sizeof(float4), "alpha chunks");
 #ifdef GRPG_RENDER_LDS_PAD   // experiment build: unused LDS that caps the workgroups per CU
   __shared__ uint32_t s_pad[GRPG_RENDER_LDS_PAD / 4];
   if (W < 0) s_pad[threadIdx.x] = (uint32_t)H;   // never true: keeps the array allocated
@@ -969,6 +1274,41 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each is rendered by two
   // workgroups (half tiles) with a producer and a consumer wave per quarter.  The first pc_slots
   // workgroups are reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
+#if GRPG_RENDER_PIPE
+  // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each QUARTER is a workgroup of its
+  // own: blender, producer, two evaluators (pipeline above).  The first pc_slots workgroups are
+  // reserved for them (upper bound of 4 n0 computed on the host from num_rendered).
+  if (blockIdx.x < pc_slots) {
+    if (blockIdx.x >= 4u * n0) return;
+    const uint32_t tile = lists[blockIdx.x >> 2];
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+    const uint2 range = ranges[tile];
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    const int q = (int)(blockIdx.x & 3u);
+    const int x0 = tx * TILE, y0 = ty * TILE + q * 4;
+    if (threadIdx.x < (unsigned)(sizeof(PLCtrl) / 4)) reinterpret_cast<uint32_t*>(&L.pl)[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      L.pl.box[0] = (float)x0; L.pl.box[1] = (float)(x0 + 15);
+      L.pl.box[2] = (float)y0; L.pl.box[3] = (float)(y0 + 3);
+    }
+    __syncthreads();   // the only workgroup barriers: all 4 waves of the workgroup take this branch
+    float4* const slots = &L.rec[0][0];
+    float4* const abuf = reinterpret_cast<float4*>(&L.qid[0][0]);   // 2 x PL_CHUNK_Q x WAVE float4
+    if (wave == 0) {
+      pl_blender<WRITE_AUX, NSEM>(slots, abuf, abuf + PL_CHUNK_Q * WAVE, &L.pl, lane, x0, y0, W, H, bg, out_color,
+                                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb,
+                                  pc_err, sem, out_semantic);
+      if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
+    } else if (wave == 1) {
+      pl_producer<(NSEM > 0)>(slots, L.pq[0], L.pq[1], &L.pl, lane, q, rb, re, point_list, rec, pc_err);
+    } else {
+      pl_evaluator(slots, abuf + (wave - 2) * PL_CHUNK_Q * WAVE, &L.pl, wave - 2, lane, x0, y0, pc_err);
+    }
+    return;
+  }
+#else
   if (blockIdx.x < pc_slots) {
     if (blockIdx.x >= 2u * n0) return;
     const uint32_t tile = lists[blockIdx.x >> 1];
@@ -995,6 +1335,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                   rb, re, point_list, rec, pc_err);
     return;
   }
+#endif
   // Dispatch order (longest processing time first): class 0, class 1, the LIGHT tiles, class 2.
   // A light tile is a whole tile on one wave (measured 40-70 us for 100-250 entries), longer than
   // a quarter wave of a class-2 tile (20-30 us), so it must not come last.
@@ -1137,7 +1478,9 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 // workgroups reserved for half tiles of class 0 (producer / consumer wave pairs): at most
 // R / RENDER_PC_MIN tiles can be that long, two workgroups each.  The forward and the backward of one
 // frame agree on it (both derive it from num_rendered).
-uint32_t render_pc_slots(uint32_t R) { return 2u * (uint32_t)((size_t)R / RENDER_PC_MIN + 1); }
+uint32_t render_pc_slots(uint32_t R) {
+  return (GRPG_RENDER_PIPE ? 4u : 2u) * (uint32_t)((size_t)R / RENDER_PC_MIN + 1);
+}
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,

@@ -190,6 +190,36 @@ def test_backward_refuses_an_evaluation_forwards_blob(dev, lib):
     assert rc == 0, err
 
 
+def test_blob_guard_is_settled_by_the_header_not_by_the_address(dev, lib):
+    """the library's table of blob addresses is advisory.  A training blob COPIED to an
+    address the library has never seen is served (its header says it has the gradient records); a
+    copied evaluation blob at an unknown address is still refused (the header says no), and so is
+    memory that holds no geometry blob at all."""
+    sc, cam = hz.toy_scene(800, seed=6, sh_degree=1), hz.trajectory_camera(0, W=96, H=64)
+    names = ("mean2D", "opacity", "mean3D", "sh", "scale", "rot")
+    ref = Frame(lib, dev, sc, cam)
+    want = poisoned(dev, ref.P, ref.M, names)
+    rc, err = ref.backward(want)
+    assert rc == 0, err
+    # (a) training blob moved to a fresh address
+    fr = Frame(lib, dev, sc, cam)
+    fr.geom = fr.geom.clone()
+    got = poisoned(dev, fr.P, fr.M, names)
+    rc, err = fr.backward(got)
+    assert rc == 0, err
+    for k in ("opacity", "scale"):     # float atomics: equal to rounding
+        assert torch.allclose(got[k], want[k], rtol=1e-3, atol=1e-6 * float(want[k].abs().max())), k
+    # (b) evaluation blob copied to an unknown address: refused by its header
+    ev3 = Frame(lib, dev, sc, cam, flags=GRPG_FORWARD_NO_BACKWARD)
+    ev3.geom = torch.cat([ev3.geom, torch.zeros(ev3.P * 64 + 4096, dtype=torch.uint8, device=dev)])
+    rc, err = ev3.backward(poisoned(dev, ev3.P, ev3.M, names))
+    assert rc == GRPG_ERR_BAD_BUFFER and "evaluation forward" in err, (rc, err)
+    # (c) something that is not a geometry blob at all
+    ev3.geom = torch.zeros_like(ev3.geom)
+    rc, err = ev3.backward(poisoned(dev, ev3.P, ev3.M, names))
+    assert rc == GRPG_ERR_BAD_BUFFER and "magic" in err, (rc, err)
+
+
 def test_allocation_failures_are_reported_and_leave_the_library_usable(dev, lib):
     """A grpg_alloc_fn that returns NULL -- for the geometry blob, the image blob or the binning blob
     (the last one is asked for in the middle of the frame, behind launches that are already enqueued) --

@@ -259,7 +259,8 @@ def test_depth_range_beyond_27_bits_takes_the_fourth_sort_pass(dev):
     # two launches are only enqueued while the previous frame needed them (or nothing is known yet).
     # Order: first frame (no history: four passes enqueued) | near (still enqueued, idle) | near (three
     # passes only) | FAR (three passes enqueued, the device reports key_far, the frame is rendered again
-    # with four) | far (four) | a scene in millimetres: near again.
+    # with four) | far (four) | a scene in millimetres: near again (the fourth pass stays enqueued for a
+    # while -- the mark is sticky -- and idles on the device).
     cases = ((1000.0, 2.0e6, False), (1000.0, 2.0e6, False), (3.0e4, 9.0e5, False), (0.21, 2.0e6, True),
              (0.21, 2.0e6, True), (3.0e4, 9.0e5, False))
     scenes = []
@@ -282,10 +283,19 @@ def test_depth_range_beyond_27_bits_takes_the_fourth_sort_pass(dev):
     near, far_ = scenes[2], scenes[3]
     for sc, o, expect_ok in ((near[0], near[1], True), (far_[0], far_[1], False)):
         d = sc.to(dev)
-        if not expect_ok:   # make the history "near" again first
+        if not expect_ok:
+            # The hint's `far` mark is sticky with decay (csrc/api.hip update_hint): ONE near
+            # frame behind the far ones of the loop above does not drop the fourth pass -- a far frame
+            # that alternates with near ones is enqueued with it and is fine ...
             dn = near[0].to(dev)
             rast(means3D=dn.means3D, means2D=None, opacities=dn.opacity, shs=dn.shs, scales=dn.scales,
                  rotations=dn.rotations)
+            t2, *_ = rast.forward_deferred(d.means3D, d.opacity, shs=d.shs, scales=d.scales, rotations=d.rotations)
+            assert frame_ok(t2)
+            # ... and only a long run of near frames makes the history "near" again
+            for _ in range(40):
+                rast(means3D=dn.means3D, means2D=None, opacities=dn.opacity, shs=dn.shs, scales=dn.scales,
+                     rotations=dn.rotations)
         ticket, color, *_ = rast.forward_deferred(d.means3D, d.opacity, shs=d.shs, scales=d.scales,
                                                   rotations=d.rotations)
         assert frame_ok(ticket) == expect_ok

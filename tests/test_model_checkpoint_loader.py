@@ -161,3 +161,21 @@ def test_loader_inverts_the_references_own_writer(tmp_path):
     keep = [i for i in range(len(names)) if i not in sem_cols]     # write_ply has no semantic values to write
     table = np.stack([el[n] for n in names], axis=1)
     assert np.array_equal(table[:, keep], z["table"][:, keep])
+
+
+class _NeedsFullUnpickler:          # what a non-final checkpoint's optimizer / bidict objects look like to
+    def __init__(self):             # torch.load(weights_only=True): a class it does not know
+        self.x = 1
+
+
+def test_unsafe_unpickler_only_on_request(tmp_path, models):
+    """a .pth that weights_only=True cannot read is refused unless the caller opts in."""
+    path = str(tmp_path / "nonfinal.pth")
+    sd = ckpt.state_dict_of(models)
+    sd["optimizer_like"] = _NeedsFullUnpickler()
+    torch.save(sd, path)
+    with pytest.raises(ValueError, match="allow_unsafe=True"):
+        ckpt.load_checkpoint(path)
+    with pytest.warns(UserWarning, match="unsafe"):
+        got = ckpt.load_checkpoint(path, allow_unsafe=True)
+    assert set(got.names()) == set(models)
