@@ -144,6 +144,11 @@ EXPERIMENT_VARIANTS = {
     # round 5: the producer / consumer PAIRS of round 2-4 for the class-0 tiles instead of the three-stage
     # wave pipeline (A/B of the pipeline), and the pipeline from 4096 / 16384 entries
     "pcpair": {"render_fwd.hip": ["-DGRPG_RENDER_PIPE=0"]},
+    "pretouch": {"render_fwd.hip": ["-DGRPG_PL_PRETOUCH"]},
+    # only the class-0 workgroups run (images are wrong): how long is their chain with nothing beside it?
+    "only0": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0"]},
+    "only0pair": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0", "-DGRPG_RENDER_PIPE=0"]},
+    "only0trace": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0", "-DGRPG_TRACE"], "render_bwd.hip": ["-DGRPG_TRACE"]},
     "pipe4096": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=4096"], "api.hip": ["-DGRPG_RENDER_PC_MIN=4096"],
                  "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=4096"]},
     "pipe16384": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=16384"], "api.hip": ["-DGRPG_RENDER_PC_MIN=16384"],

@@ -245,12 +245,19 @@ __device__ __forceinline__ void store_pair_half(float4* __restrict__ my, const i
 
 // The accept half of a quad: alpha and the lanes that take the splat, for the four slots of blk
 // (two pair blocks).  One body for every caller, so that they all get the same bits.
-__device__ __forceinline__ void eval_quad(const float4* __restrict__ blk, const float pxf, const float pyf,
+struct QuadGeom {   // centres, pre-scaled conics and opacities of the four slots of a quad (two pair blocks)
+  float4 f[6];
+  __device__ __forceinline__ void load(const float4* __restrict__ blk) {
+    f[0] = blk[0]; f[1] = blk[1]; f[2] = blk[2];
+    f[3] = blk[PAIR_F4 + 0]; f[4] = blk[PAIR_F4 + 1]; f[5] = blk[PAIR_F4 + 2];
+  }
+};
+__device__ __forceinline__ void eval_quad(const QuadGeom& g, const float pxf, const float pyf,
                                           float (&alpha)[4], uint64_t (&ok)[4]) {
   const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    const float4 f0 = blk[h * PAIR_F4 + 0], f1 = blk[h * PAIR_F4 + 1], f2 = blk[h * PAIR_F4 + 2];
+    const float4 f0 = g.f[3 * h + 0], f1 = g.f[3 * h + 1], f2 = g.f[3 * h + 2];
     const v2f dx = (v2f){f0.x, f0.y} - px2, dy = (v2f){f0.z, f0.w} - py2;
     const v2f p = pair_power_x2(dx, dy, (v2f){f1.x, f1.y}, (v2f){f1.z, f1.w}, (v2f){f2.x, f2.y});
     const v2f G = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
@@ -262,9 +269,30 @@ __device__ __forceinline__ void eval_quad(const float4* __restrict__ blk, const 
   }
 }
 
+// Where the blend half of a quad takes the colour / position blocks of its two pairs from: the LDS pair
+// blocks themselves, read when they are needed (heavy path), or registers filled a quad ahead (the
+// pipeline's blender).  Same values either way.
+struct QuadColsLds {
+  const float4* __restrict__ blk;
+  __device__ __forceinline__ float4 c0(const int h) const { return blk[h * PAIR_F4 + 3]; }
+  __device__ __forceinline__ float4 c1(const int h) const { return blk[h * PAIR_F4 + 4]; }
+  __device__ __forceinline__ float4 pp(const int h) const { return blk[h * PAIR_F4 + 5]; }
+};
+template <bool WITH_PP>
+struct QuadColsReg {
+  float4 c[4], p[2];
+  __device__ __forceinline__ void load(const float4* __restrict__ blk) {
+    c[0] = blk[3]; c[1] = blk[4]; c[2] = blk[PAIR_F4 + 3]; c[3] = blk[PAIR_F4 + 4];
+    if (WITH_PP) { p[0] = blk[5]; p[1] = blk[PAIR_F4 + 5]; }
+  }
+  __device__ __forceinline__ float4 c0(const int h) const { return c[2 * h]; }
+  __device__ __forceinline__ float4 c1(const int h) const { return c[2 * h + 1]; }
+  __device__ __forceinline__ float4 pp(const int h) const { return p[h]; }
+};
+
 // The blend half of a quad, given alpha[i] and ok[i] of its four slots.
-template <bool AUX, int NSEM>
-__device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const float4* __restrict__ blk,
+template <bool AUX, int NSEM, class Cols>
+__device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
                                                 const float (&alpha)[4], const uint64_t (&ok)[4],
                                                 SemAcc<NSEM>* sa, const SemSrc sem);
 
@@ -276,12 +304,14 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
   const float4* blk = my + (j0 >> 1) * PAIR_F4;
   float alpha[4];
   uint64_t ok[4];
-  eval_quad(blk, pxf, pyf, alpha, ok);
-  return blend_quad_tail<AUX, NSEM>(s, blk, alpha, ok, sa, sem);
+  QuadGeom g;
+  g.load(blk);
+  eval_quad(g, pxf, pyf, alpha, ok);
+  return blend_quad_tail<AUX, NSEM>(s, QuadColsLds{blk}, alpha, ok, sa, sem);
 }
 
-template <bool AUX, int NSEM>
-__device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const float4* __restrict__ blk,
+template <bool AUX, int NSEM, class Cols>
+__device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
                                                 const float (&alpha)[4], const uint64_t (&ok)[4],
                                                 SemAcc<NSEM>* sa, const SemSrc sem) {
   const uint64_t live = ~s.done[0];
@@ -305,19 +335,19 @@ __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const float4* __r
   if ((lanes(T < 0.0001f) & live) == 0ull) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4];
+      const float4 c0 = cols.c0(h), c1 = cols.c1(h);
       const v2f w0 = {w[2 * h], w[2 * h]}, w1 = {w[2 * h + 1], w[2 * h + 1]};
       s.CrCg[0] = __builtin_elementwise_fma((v2f){c0.x, c0.y}, w0, s.CrCg[0]);
       s.CbD[0] = __builtin_elementwise_fma((v2f){c0.z, c0.w}, w0, s.CbD[0]);
       s.CrCg[0] = __builtin_elementwise_fma((v2f){c1.x, c1.y}, w1, s.CrCg[0]);
       s.CbD[0] = __builtin_elementwise_fma((v2f){c1.z, c1.w}, w1, s.CbD[0]);
       if (AUX) {   // n_contrib: position of the last splat the pixel took
-        const float4 pp = blk[h * PAIR_F4 + 5];
+        const float4 pp = cols.pp(h);
         s.last[0] = in_mask(ok[2 * h] & live) ? __float_as_uint(pp.x) : s.last[0];
         s.last[0] = in_mask(ok[2 * h + 1] & live) ? __float_as_uint(pp.y) : s.last[0];
       }
       if (NSEM > 0) {   // the same weights feed the semantic planes, in list order
-        const float4 pp = blk[h * PAIR_F4 + 5];
+        const float4 pp = cols.pp(h);
         sem_accumulate<NSEM>(*sa, sem, __float_as_uint(pp.z), w[2 * h]);
         sem_accumulate<NSEM>(*sa, sem, __float_as_uint(pp.w), w[2 * h + 1]);
       }
@@ -327,7 +357,7 @@ __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const float4* __r
   }
 #pragma unroll
   for (int h = 0; h < 2; h++) {   // some pixel terminates in this quad: the exact per-splat blend
-    const float4 c0 = blk[h * PAIR_F4 + 3], c1 = blk[h * PAIR_F4 + 4], pp = blk[h * PAIR_F4 + 5];
+    const float4 c0 = cols.c0(h), c1 = cols.c1(h), pp = cols.pp(h);
     blend_one<1, AUX, NSEM>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x), sa, sem,
                             __float_as_uint(pp.z));
     blend_one<1, AUX, NSEM>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y), sa, sem,
@@ -715,6 +745,88 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------
+// The class-0 producer's view of its tile list: a STREAM read in large windows.
+//
+// blend_heavy's FILL reads the list 256 entries at a time and prefetches ONE step ahead.  With
+// thousands of waves in flight that is enough; a class-0 producer is one wave walking 8 k - 35 k
+// entries, and every FILL step then costs a full memory latency (the list was written by the fill
+// kernel a moment ago: HBM / Infinity Cache, 1 - 2 us): 126 steps of the bench frame's longest list
+// are the 0.19 ms the render launch could not get below in round 4 -- speeding up the CONSUMER side
+// (round 5's evaluator / blender split) alone changed nothing.  Here the stream holds LS_SUB sub-windows
+// of 256 entries in registers (16-byte loads: lane l owns four consecutive entries), all requested
+// together, and consumes them from registers.
+// ------------------------------------------------------------------------------------------
+constexpr int LS_SUB = 8;                    // sub-windows of 256 entries per register window
+constexpr uint32_t LS_SPAN = LS_SUB * 256u;  // entries per register window
+struct ListStream {
+  const uint32_t* pl;
+  uint32_t r_begin, r_end;
+  uint32_t wpos;      // list index (absolute, a multiple of 256) of c0's first entry
+  uint32_t q;         // next sub-window of the register window
+  // Named registers, not an array: a (wave-uniform) dynamic index would send an array to scratch.
+  // ONE bank, refilled when it is used up: all LS_SUB loads of a window are in flight together, so a
+  // window of 2048 entries costs one memory latency (blend_heavy's FILL: one per 256 entries).  A second
+  // bank loaded a window ahead was built three ways (moves between banks, two banks taking turns, a
+  // scheduling barrier between moves and reloads): hipcc either routes the reloads through temporaries
+  // and waits for them on the spot (loop-carried registers are not coalesced with the load destinations)
+  // or waits vmcnt(0) at every use -- no better than this, for twice the registers.
+  uint4 c0, c1, c2, c3, c4, c5, c6, c7;
+  static_assert(LS_SUB == 8, "eight sub-windows per register window");
+  // UNCONDITIONAL load (address clamped into the list; append() drops entries outside [r_begin, r_end) by
+  // index): a predicated load makes the compiler copy the result through a temporary.
+  __device__ __forceinline__ uint4 load(const uint32_t first, const int lane) const {
+    const uint32_t e = min(first + 4u * (uint32_t)lane, (r_end - 1u) & ~3u);   // 16-byte aligned
+    return *reinterpret_cast<const uint4*>(pl + e);
+  }
+  __device__ __forceinline__ void refill(const int lane) {
+    c0 = load(wpos, lane); c1 = load(wpos + 256u, lane); c2 = load(wpos + 512u, lane); c3 = load(wpos + 768u, lane);
+    c4 = load(wpos + 1024u, lane); c5 = load(wpos + 1280u, lane); c6 = load(wpos + 1536u, lane); c7 = load(wpos + 1792u, lane);
+  }
+  __device__ __forceinline__ void open(const uint32_t* point_list, const uint32_t rb, const uint32_t re, const int lane) {
+    pl = point_list; r_begin = rb; r_end = re;
+    wpos = rb & ~255u; q = 0;
+    refill(lane);
+  }
+  __device__ __forceinline__ bool exhausted() const { return wpos + 256u * q >= r_end; }
+  // Appends the entries of sub-window v (first entry e0 for this lane) whose mask has `bit` to the ring, in
+  // list order: lane-major, then the lane's four entries.
+  __device__ __forceinline__ void append(const uint4 v, const uint32_t e0, uint32_t* __restrict__ qid,
+                                         uint32_t* __restrict__ qpos, const uint32_t bit, const uint32_t head,
+                                         uint32_t& count, const uint64_t lt) const {
+    const bool k0 = (e0 >= r_begin) && (e0 < r_end) && (v.x & bit);
+    const bool k1 = (e0 + 1u >= r_begin) && (e0 + 1u < r_end) && (v.y & bit);
+    const bool k2 = (e0 + 2u >= r_begin) && (e0 + 2u < r_end) && (v.z & bit);
+    const bool k3 = (e0 + 3u >= r_begin) && (e0 + 3u < r_end) && (v.w & bit);
+    const uint64_t m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
+    uint32_t sl = head + count + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt) +
+                  (uint32_t)__popcll(m2 & lt) + (uint32_t)__popcll(m3 & lt);
+    const uint32_t p0 = e0 - r_begin + 1u;   // 1-based position in the tile's list
+    if (k0) { qid[sl & (QCAP - 1)] = v.x & ID_MASK; qpos[sl & (QCAP - 1)] = p0; sl++; }
+    if (k1) { qid[sl & (QCAP - 1)] = v.y & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 1u; sl++; }
+    if (k2) { qid[sl & (QCAP - 1)] = v.z & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 2u; sl++; }
+    if (k3) { qid[sl & (QCAP - 1)] = v.w & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 3u; }
+    count += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2) + (uint32_t)__popcll(m3);
+  }
+  // one FILL step: the next sub-window (256 entries); count is the ring's fill state, which must leave
+  // room for 256 entries.  q is wave-uniform: scalar branches, each naming its register.
+  __device__ __forceinline__ void fill(uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos, const uint32_t bit,
+                                       const uint32_t head, uint32_t& count, const int lane, const uint64_t lt) {
+    const uint32_t e0 = wpos + 256u * q + 4u * (uint32_t)lane;
+    switch (q) {
+      case 0u: append(c0, e0, qid, qpos, bit, head, count, lt); break;
+      case 1u: append(c1, e0, qid, qpos, bit, head, count, lt); break;
+      case 2u: append(c2, e0, qid, qpos, bit, head, count, lt); break;
+      case 3u: append(c3, e0, qid, qpos, bit, head, count, lt); break;
+      case 4u: append(c4, e0, qid, qpos, bit, head, count, lt); break;
+      case 5u: append(c5, e0, qid, qpos, bit, head, count, lt); break;
+      case 6u: append(c6, e0, qid, qpos, bit, head, count, lt); break;
+      default: append(c7, e0, qid, qpos, bit, head, count, lt); break;
+    }
+    if (++q == (uint32_t)LS_SUB) { q = 0; wpos += LS_SPAN; refill(lane); }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // Producer / consumer wave pairs for the LONGEST tiles (class 0 when pc_mode is on).
 //
 // A horizon quarter is a serial chain (the T recurrence) that outlives the rest of the launch, and
@@ -779,13 +891,9 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
                                             const RecView rec, const PCErr err) {
   const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
   const uint64_t lt = lanemask_lt();
-  uint32_t in_pos = r_begin, head = 0, count = 0;
-  uint32_t win[FILL_Q];
-#pragma unroll
-  for (int q = 0; q < FILL_Q; q++) {
-    const uint32_t i = in_pos + q * WAVE + lane;
-    win[q] = i < r_end ? point_list[i] : 0u;
-  }
+  uint32_t head = 0, count = 0;
+  ListStream ls;
+  ls.open(point_list, r_begin, r_end, lane);
   float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
   uint32_t pos = 0, idc = 0, ncur = 0;
   int cur = 0;
@@ -793,30 +901,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   for (;;) {
     if (pc_load(&ctl->stop) != 0u) { stopped = true; break; }
     // ---- FILL ----
-    while (count < (uint32_t)WAVE && in_pos < r_end) {
-      uint32_t v[FILL_Q];
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
-      const uint32_t nxt = in_pos + FILL_Q * WAVE;
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) {
-        const uint32_t i = nxt + q * WAVE + lane;
-        win[q] = i < r_end ? point_list[i] : 0u;
-      }
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) {
-        const uint32_t i = in_pos + q * WAVE + lane;
-        const bool keep = (i < r_end) && (v[q] & bit);
-        const uint64_t m = __ballot(keep);
-        if (keep) {
-          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
-          qid[slot] = v[q] & ID_MASK;
-          qpos[slot] = i - r_begin + 1;
-        }
-        count += (uint32_t)__popcll(m);
-      }
-      in_pos = nxt;
-    }
+    while (count < (uint32_t)WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt);
     // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
     // reordering the LDS accesses across this point (costs no instruction)
     __builtin_amdgcn_wave_barrier();
@@ -860,7 +945,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
       }
     }
     a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
-    if (ncur == 0 && in_pos >= r_end) break;
+    if (ncur == 0 && ls.exhausted()) break;
   }
   if (!stopped) {   // end-of-list marker
     uint32_t spins = 0;
@@ -987,18 +1072,24 @@ struct PLCtrl {
   uint32_t aseq[2], acons[2];
   float box[4];
   uint32_t okany[2][PL_CHUNK_Q][2];          // per chunk buffer and quad: lanes that accept any of its splats
+  uint32_t sink[2];
 };
 
 // returns false on stop / time-out
 template <class Cond>
-__device__ __forceinline__ bool pl_wait(PLCtrl* __restrict__ ctl, const PCErr err, const int lane, Cond ready) {
+__device__ __forceinline__ bool pl_wait(PLCtrl* __restrict__ ctl, const PCErr err, const int lane, Cond ready,
+                                        WaveTrace* tr = nullptr /* experiment build: cycles spent waiting */) {
   uint32_t spins = 0;
+  if (ready()) return true;
+  const uint64_t t0 = tr ? __builtin_readcyclecounter() : 0;
+  bool ok = true;
   while (!ready()) {
-    if (pc_load(&ctl->stop) != 0u) return false;
-    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); pc_store(&ctl->stop, 1u); return false; }
+    if (pc_load(&ctl->stop) != 0u) { ok = false; break; }
+    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); pc_store(&ctl->stop, 1u); ok = false; break; }
     __builtin_amdgcn_s_sleep(1);
   }
-  return true;
+  if (tr) { tr->t_stage += (uint32_t)(__builtin_readcyclecounter() - t0); tr->blends++; }
+  return ok;
 }
 
 template <bool WITH_ID = false>
@@ -1008,112 +1099,121 @@ __device__ __forceinline__ void pl_producer(float4* __restrict__ slots /* PL_NB 
                                             const int quarter, const uint32_t r_begin,
                                             const uint32_t r_end,
                                             const uint32_t* __restrict__ point_list,
-                                            const RecView rec, const PCErr err) {
+                                            const RecView rec, const PCErr err, WaveTrace* tr = nullptr) {
   const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
   const uint64_t lt = lanemask_lt();
-  uint32_t in_pos = r_begin, head = 0, count = 0;
-  uint32_t win[FILL_Q];
-#pragma unroll
-  for (int q = 0; q < FILL_Q; q++) {
-    const uint32_t i = in_pos + q * WAVE + lane;
-    win[q] = i < r_end ? point_list[i] : 0u;
-  }
-  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-  uint32_t pos = 0, idc = 0, ncur = 0;
+  uint32_t head = 0, count = 0;
+  ListStream ls;
+  ls.open(point_list, r_begin, r_end, lane);
+  // TWO batches per iteration (every lane gathers two records): the producer is one wave, its record
+  // gather is a dependent HBM / Infinity Cache round trip per iteration, and with one batch per
+  // iteration that latency -- not the producer's instructions -- set its pace (1.9 us per batch measured,
+  // 0.7 us of work).
+  float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, c0 = a0, a1 = a0, b1 = a0, c1 = a0;
+  uint32_t pos0 = 0, id0 = 0, pos1 = 0, id1 = 0, ncur = 0;
   uint32_t n = 0;   // batches published
   const auto slot_free = [&]() {
     return n < (uint32_t)PL_NB || (pc_load(&ctl->bprog) + PL_NB > n && pc_load(&ctl->eprog[0]) + PL_NB > n &&
                                    pc_load(&ctl->eprog[1]) + PL_NB > n);
   };
+  // culls `cnt_in` gathered records (one per lane) against the consumers' live box, compacts the
+  // survivors into the next batch slot and publishes it; false: the consumers have stopped
+  const auto emit = [&](const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc,
+                        const uint32_t cnt_in) -> bool {
+    const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
+    const bool keep = ((uint32_t)lane < cnt_in) &&
+                      !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
+    const uint64_t mask = __ballot(keep);
+    const int cnt = (int)__popcll(mask);
+    if (cnt == 0) return true;
+    if (!pl_wait(ctl, err, lane, slot_free, tr)) return false;
+    if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
+    float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
+    if (keep)
+      store_pair_half<WITH_ID>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                               make_float4(b.w, c.x, c.y, a.z), pos, idc);
+    if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
+      const SplatQ zq = {0.f, 0.f, 0.f};
+      store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
+    }
+    pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | (uint32_t)cnt);
+    n++;
+    return true;
+  };
   for (;;) {
     if (pc_load(&ctl->stop) != 0u) return;
-    // ---- FILL ----
-    while (count < (uint32_t)WAVE && in_pos < r_end) {
-      uint32_t v[FILL_Q];
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
-      const uint32_t nxt = in_pos + FILL_Q * WAVE;
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) {
-        const uint32_t i = nxt + q * WAVE + lane;
-        win[q] = i < r_end ? point_list[i] : 0u;
-      }
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) {
-        const uint32_t i = in_pos + q * WAVE + lane;
-        const bool keep = (i < r_end) && (v[q] & bit);
-        const uint64_t m = __ballot(keep);
-        if (keep) {
-          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
-          qid[slot] = v[q] & ID_MASK;
-          qpos[slot] = i - r_begin + 1;
-        }
-        count += (uint32_t)__popcll(m);
-      }
-      in_pos = nxt;
-    }
+    // ---- FILL: until two batches are queued (ring: < 128 + 256 entries <= QCAP) ----
+    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt);
+    // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
+    // reordering the LDS accesses across this point (costs no instruction)
     __builtin_amdgcn_wave_barrier();
-    // ---- POP ----
-    const uint32_t nn = min(count, (uint32_t)WAVE);
-    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
-    uint32_t pos_n = 0, id_n = 0;
+    // ---- POP: up to 128 entries, two per lane; their records are requested ----
+    const uint32_t nn = min(count, 2u * WAVE);
+    float4 a0n = make_float4(0, 0, 0, 0), b0n = a0n, c0n = a0n, a1n = a0n, b1n = a0n, c1n = a0n;
+    uint32_t pos0n = 0, id0n = 0, pos1n = 0, id1n = 0;
     if ((uint32_t)lane < nn) {
       const uint32_t slot = (head + lane) & (QCAP - 1);
-      id_n = qid[slot];
-      pos_n = qpos[slot];
-      rec.load(id_n, a_n, b_n, c_n);
+      id0n = qid[slot];
+      pos0n = qpos[slot];
+      rec.load(id0n, a0n, b0n, c0n);
+    }
+    if ((uint32_t)lane + WAVE < nn) {
+      const uint32_t slot = (head + WAVE + lane) & (QCAP - 1);
+      id1n = qid[slot];
+      pos1n = qpos[slot];
+      rec.load(id1n, a1n, b1n, c1n);
     }
     head = (head + nn) & (QCAP - 1);
     count -= nn;
-    // ---- cull + compact the previous batch into the next slot, publish it ----
+    // ---- the previous iteration's records: cull, compact, publish (list order: first half first) ----
     if (ncur > 0) {
-      const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
-      const bool keep = ((uint32_t)lane < ncur) &&
-                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
-      const uint64_t mask = __ballot(keep);
-      const int cnt = (int)__popcll(mask);
-      if (cnt > 0) {
-        if (!pl_wait(ctl, err, lane, slot_free)) return;
-        float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
-        if (keep)
-          store_pair_half<WITH_ID>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
-                                   make_float4(b.w, c.x, c.y, a.z), pos, idc);
-        if (lane < ((4 - (cnt & 3)) & 3)) {
-          const SplatQ zq = {0.f, 0.f, 0.f};
-          store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
-        }
-        pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | (uint32_t)cnt);
-        n++;
-      }
+      if (!emit(a0, b0, c0, pos0, id0, min(ncur, (uint32_t)WAVE))) return;
+      if (ncur > (uint32_t)WAVE && !emit(a1, b1, c1, pos1, id1, ncur - WAVE)) return;
     }
-    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
-    if (ncur == 0 && in_pos >= r_end) break;
+    a0 = a0n; b0 = b0n; c0 = c0n; pos0 = pos0n; id0 = id0n;
+    a1 = a1n; b1 = b1n; c1 = c1n; pos1 = pos1n; id1 = id1n;
+    ncur = nn;
+    if (ncur == 0 && ls.exhausted()) break;
   }
-  if (!pl_wait(ctl, err, lane, slot_free)) return;   // end-of-list marker
+  if (!pl_wait(ctl, err, lane, slot_free, tr)) return;   // end-of-list marker
   pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | PL_END);
 }
 
 __device__ __forceinline__ void pl_evaluator(const float4* __restrict__ slots, float4* __restrict__ abuf /* mine */,
                                              PLCtrl* __restrict__ ctl, const int k, const int lane,
-                                             const int x0, const int y0, const PCErr err) {
+                                             const int x0, const int y0, const PCErr err,
+                                             const uint32_t* __restrict__ touch_list = nullptr,
+                                             const uint32_t touch_len = 0u, WaveTrace* tr = nullptr) {
   const float pxf = (float)(x0 + (lane & 15)), pyf = (float)(y0 + (lane >> 4));
   uint32_t chunk = 0;
+#ifdef GRPG_PL_PRETOUCH   // experiment: the whole list is pulled into this XCD's L2 before the producer needs it
+  {
+    uint32_t acc = 0;
+    for (uint32_t i = (uint32_t)(lane + 64 * k) * 32u; i < touch_len; i += 128u * 32u) acc ^= touch_list[i];
+    ctl->sink[k] = acc;
+  }
+#endif
   for (uint32_t n = 0;; n++) {
     uint32_t f = 0;
-    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; })) return;
+    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; }, tr)) return;
     const uint32_t cnt = f & 127u;
     if (cnt == PL_END) return;
     const float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
     const int nq = (int)((cnt + 3u) >> 2);
     for (int q0 = 0; q0 < nq; q0 += PL_CHUNK_Q, chunk++) {
       if ((int)(chunk & 1u) != k) continue;
+      if (tr) tr->batches++;
       // my alpha buffer is free once the blender is through my previous chunk (id chunk - 2)
-      if (chunk >= 2u && !pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->acons[k]) + 1u >= chunk; })) return;
+      if (chunk >= 2u && !pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->acons[k]) + 1u >= chunk; }, tr)) return;
       const int q1 = min(nq, q0 + PL_CHUNK_Q);
+      QuadGeom g_n;   // a quad ahead in registers, like the blender (one LDS round trip per quad otherwise)
+      g_n.load(my + q0 * 2 * PAIR_F4);
       for (int q = q0; q < q1; q++) {
         float alpha[4];
         uint64_t ok[4];
-        eval_quad(my + q * 2 * PAIR_F4, pxf, pyf, alpha, ok);
+        const QuadGeom g = g_n;
+        g_n.load(my + min(q + 1, q1 - 1) * 2 * PAIR_F4);
+        eval_quad(g, pxf, pyf, alpha, ok);
         float4 am;
         am.x = in_mask(ok[0]) ? alpha[0] : 0.0f;
         am.y = in_mask(ok[1]) ? alpha[1] : 0.0f;
@@ -1138,7 +1238,7 @@ __device__ __forceinline__ void pl_blender(const float4* __restrict__ slots, con
                                            float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                                            CkptWriter ckw, const uint32_t len, const PCErr err,
                                            const SemSrc sem = SemSrc{nullptr, 0},
-                                           float* __restrict__ out_semantic = nullptr) {
+                                           float* __restrict__ out_semantic = nullptr, WaveTrace* tr = nullptr) {
   SemAcc<NSEM> sa;
 #pragma unroll
   for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
@@ -1153,27 +1253,40 @@ __device__ __forceinline__ void pl_blender(const float4* __restrict__ slots, con
   if (~st.done[0] == 0ull) pc_store(&ctl->stop, 1u);   // nothing to do (quarter outside the image)
   else for (uint32_t n = 0;; n++) {
     uint32_t f = 0;
-    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; })) break;
+    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; }, tr)) break;
     const uint32_t cnt = f & 127u;
     if (cnt == PL_END) break;
+    if (tr) { tr->batches++; tr->survivors += cnt; }
     const float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
     const int nq = (int)((cnt + 3u) >> 2);
     bool lost = false;
     for (int q0 = 0; q0 < nq; q0 += PL_CHUNK_Q, chunk++) {
       const int k = (int)(chunk & 1u);
-      if (!pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->aseq[k]) == chunk + 1u; })) { lost = true; break; }
-      const float4* ab = k ? abuf1 : abuf0;
+      if (!pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->aseq[k]) == chunk + 1u; }, tr)) { lost = true; break; }
+      const float4* ab = (k ? abuf1 : abuf0) + lane;
       const uint32_t* okw = &ctl->okany[k][lane & (PL_CHUNK_Q - 1)][0];
       const uint32_t ok_lo = okw[0], ok_hi = okw[1];
       const int q1 = min(nq, q0 + PL_CHUNK_Q);
+      // The blender is the chain of the whole launch, and a wave on its own pays every LDS round trip
+      // in full (~130 cycles; the first version read alpha, then the colours, then the positions of a
+      // quad one after the other: 800 cycles per quad, tools/trace_class0.py): the alpha vector and the
+      // colour blocks of quad q + 1 are requested BEFORE quad q is blended and wait in registers.
+      constexpr bool PP = AUX || NSEM > 0;
+      float4 am_n = ab[0];
+      QuadColsReg<PP> col_n;
+      col_n.load(my + q0 * 2 * PAIR_F4);
       for (int q = q0; q < q1; q++) {
+        const float4 am = am_n;
+        const QuadColsReg<PP> col = col_n;
+        const int qn = min(q + 1, q1 - 1);   // (the last quad is read twice: no branch around the loads)
+        am_n = ab[(qn - q0) * WAVE];
+        col_n.load(my + qn * 2 * PAIR_F4);
         const uint64_t any = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ok_lo, q - q0) |
                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ok_hi, q - q0) << 32);
         if ((any & ~st.done[0]) == 0ull) continue;   // no live lane takes any splat of this quad
-        const float4 am = ab[(q - q0) * WAVE + lane];
         const float alpha[4] = {am.x, am.y, am.z, am.w};
         const uint64_t ok[4] = {lanes(am.x != 0.0f), lanes(am.y != 0.0f), lanes(am.z != 0.0f), lanes(am.w != 0.0f)};
-        blend_quad_tail<AUX, NSEM>(st, my + q * 2 * PAIR_F4, alpha, ok, &sa, sem);
+        blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, &sa, sem);
       }
       pc_store(&ctl->acons[k], chunk + 1u);
     }
@@ -1274,6 +1387,9 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each is rendered by two
   // workgroups (half tiles) with a producer and a consumer wave per quarter.  The first pc_slots
   // workgroups are reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
+#ifdef GRPG_RENDER_ONLY_CLASS0   // experiment build: the class-0 tiles alone (their chain, nothing beside it)
+  if (blockIdx.x >= pc_slots) return;
+#endif
 #if GRPG_RENDER_PIPE
   // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each QUARTER is a workgroup of its
   // own: blender, producer, two evaluators (pipeline above).  The first pc_slots workgroups are
@@ -1296,15 +1412,25 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __syncthreads();   // the only workgroup barriers: all 4 waves of the workgroup take this branch
     float4* const slots = &L.rec[0][0];
     float4* const abuf = reinterpret_cast<float4*>(&L.qid[0][0]);   // 2 x PL_CHUNK_Q x WAVE float4
+    WaveTrace* const trp = TRACE ? &tr : nullptr;
     if (wave == 0) {
       pl_blender<WRITE_AUX, NSEM>(slots, abuf, abuf + PL_CHUNK_Q * WAVE, &L.pl, lane, x0, y0, W, H, bg, out_color,
                                   out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb,
-                                  pc_err, sem, out_semantic);
+                                  pc_err, sem, out_semantic, trp);
       if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
     } else if (wave == 1) {
-      pl_producer<(NSEM > 0)>(slots, L.pq[0], L.pq[1], &L.pl, lane, q, rb, re, point_list, rec, pc_err);
+      pl_producer<(NSEM > 0)>(slots, L.pq[0], L.pq[1], &L.pl, lane, q, rb, re, point_list, rec, pc_err, trp);
     } else {
-      pl_evaluator(slots, abuf + (wave - 2) * PL_CHUNK_Q * WAVE, &L.pl, wave - 2, lane, x0, y0, pc_err);
+      pl_evaluator(slots, abuf + (wave - 2) * PL_CHUNK_Q * WAVE, &L.pl, wave - 2, lane, x0, y0, pc_err,
+                   point_list + rb, re - rb, trp);
+    }
+    if (TRACE && lane == 0) {   // class-0 roles: wave 0 blender, 1 producer, 2 / 3 evaluators
+      // [0] tile | 0x40000000  [1] list length  [2] batches / chunks  [3] survivors  [4] waits
+      // [5] wave cycles (wall clock ticks)  [6] start  [7] wave | waiting cycles / 256 << 4
+      uint32_t* o = trace + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
+      o[0] = tile | 0x40000000u; o[1] = re - rb; o[2] = tr.batches; o[3] = tr.survivors; o[4] = tr.blends;
+      o[5] = (uint32_t)(wall_clock64() - t_start); o[6] = (uint32_t)(t_start & 0xFFFFFFFFu);
+      o[7] = (uint32_t)wave | ((tr.t_stage >> 8) << 4);
     }
     return;
   }

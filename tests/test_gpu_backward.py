@@ -75,6 +75,7 @@ def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995, exempt=N
     PARITY_STATS.append(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0],
                              plane="grad:" + name, pixels=int(ref.size), rel_l2=float(l2),
                              frac_within_rtol1e3_atol1e5=float(strict_all),
+                             all_elements_beyond_strict=int((~within).sum()),   # NO exemption at all
                              exempt_gaussians_frac=float(np.mean(exempt)),
                              nonexempt_elements=n_keep, nonexempt_beyond_strict=miss,
                              nonexempt_worst_over_bar=worst))
@@ -432,8 +433,12 @@ def test_fit_psnr_parity_10k(dev):
     the same parameters and see the same target; they differ only by the op's rounding and atomic
     summation order, which Adam amplifies step by step: two runs of the HIP op ITSELF are identical
     to 1e-4 dB at step 50, 0.01 dB apart at step 100 and 0.05 dB apart at step 200
-    (tools/experiments/psnr_noise.py; the reference's float atomics behave the same way).  Bars:
-    +-0.01 dB at step 50, +-0.05 dB at step 100, +-0.15 dB at step 200."""
+    (tools/experiments/psnr_noise.py; the reference's float atomics behave the same way).  So the
+    comparison is made between MEANS, at SURVEY section 8(d)'s own bar: the mean of N_HIP = 5 fits through
+    the HIP op against the mean of 2 fits through the oracle (whose OpenMP backward accumulates in
+    float64 -- its runs agree to 1e-3 dB, asserted), +-0.01 dB at step 50, +-0.05 dB at steps 100 and 200
+    (round 4 compared single runs and had widened the last bar to 0.15 dB: VERDICT r4).  The spread of
+    the HIP runs is recorded in the parity statistics."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from oracle import torch_splat as ts
     from helpers import PARITY_STATS
@@ -484,15 +489,26 @@ def test_fit_psnr_parity_10k(dev):
 
         camd = hz.trajectory_camera(0, W=W, H=H, device=dev)
         rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(camd, 0)))
-        hip = fit(lambda m, o, s, sc_, r: rast(means3D=m, means2D=None, opacities=o, shs=s, scales=sc_,
-                                                rotations=r)[0], dev)
-        cpu = fit(lambda m, o, s, sc_, r: OracleSplat.apply(m, o, s, sc_, r), torch.device("cpu"))
+        N_HIP, N_ORACLE = 5, 2
+        hips = [fit(lambda m, o, s, sc_, r: rast(means3D=m, means2D=None, opacities=o, shs=s, scales=sc_,
+                                                  rotations=r)[0], dev) for _ in range(N_HIP)]
+        cpus = [fit(lambda m, o, s, sc_, r: OracleSplat.apply(m, o, s, sc_, r), torch.device("cpu"))
+                for _ in range(N_ORACLE)]
     finally:
         oracle.use_openmp(False)
+    marks = (0,) + MARKS
+    hip = {k: float(np.mean([h[k] for h in hips])) for k in marks}
+    cpu = {k: float(np.mean([c[k] for c in cpus])) for k in marks}
+    spread = {k: float(np.max([h[k] for h in hips]) - np.min([h[k] for h in hips])) for k in marks}
     PARITY_STATS.append(dict(test="test_fit_psnr_parity_10k", plane="psnr", P=P, steps=STEPS,
+                             hip_runs=N_HIP, oracle_runs=N_ORACLE,
                              psnr_hip={str(k): v for k, v in hip.items()},
-                             psnr_oracle={str(k): v for k, v in cpu.items()}))
+                             psnr_oracle={str(k): v for k, v in cpu.items()},
+                             psnr_hip_runs=[{str(k): v for k, v in h.items()} for h in hips],
+                             psnr_hip_spread={str(k): v for k, v in spread.items()}))
+    for k in marks:   # the oracle's fit is reproducible (float64 accumulation)
+        assert abs(cpus[0][k] - cpus[1][k]) <= 1e-3, (k, cpus)
     assert abs(hip[0] - cpu[0]) <= 1e-3, (hip, cpu)
     assert hip[200] > hip[0] + 15.0 and cpu[200] > cpu[0] + 15.0, (hip, cpu)   # the fits actually fit
-    for mark, bar in ((50, 0.01), (100, 0.05), (200, 0.15)):
-        assert abs(hip[mark] - cpu[mark]) <= bar, (mark, hip, cpu)
+    for mark, bar in ((50, 0.01), (100, 0.05), (200, 0.05)):
+        assert abs(hip[mark] - cpu[mark]) <= bar, (mark, hip, cpu, spread)

@@ -5,6 +5,7 @@ argument patterns:
 * configs[1]  scene-149-like static background, P = 1 M @1920x1280, frame 0,
 * configs[2]  scene-002-like, P = 2 M @1920x1280, frames 0 and 199 -- both: integer outputs exact AND
               colour / depth / alpha / n_contrib against the full (OpenMP) oracle at full size,
+* the README's resolution, 1600x1066 (67 tile rows, the last one partial), at P = 2 M, same bar,
 * configs[3]  the 200-pose tape at P = 2 M, 1920x1280 through trajectory.render_sharded (deferred
               frames, three streams), frames 0 / 99 / 199 byte-equal to their oracle-checked renders;
               plus small-size runs (side streams, in-place pack, gather), world = 1, a two-rank run on
@@ -132,6 +133,21 @@ def test_config1_full_size_parity(dev):
     sc, cam = hz.street_scene(1_000_000, seed=149), hz.trajectory_camera(0)
     got, o = _full_size_parity(dev, sc, cam, 1)
     assert 3_000_000 < got["R"] < 6_000_000
+
+
+def test_readme_resolution_1600x1066_full_size_parity(dev):
+    """The resolution the reference's README quotes its frame rate at (1600x1066, R/README.md:190;
+    SURVEY App. A): 100 x 67 tiles whose last row holds 10 of 16 pixel rows -- a partial tile row and a
+    grid of 7 x 3 super-tiles with ragged edges in both directions, at scale (P = 2 M, frame 37 of the
+    drive).  Same bar as configs[1] / [2]: integers bit-exact, image within 1e-4, n_contrib exact on the
+    non-fragile pixels."""
+    sc, cam = hz.street_scene(2_000_000, seed=2), hz.trajectory_camera(37, W=1600, H=1066)
+    assert (cam.image_height + 15) // 16 == 67 and cam.image_height % 16 == 10
+    got, o = _full_size_parity(dev, sc, cam, 1)
+    assert 5_000_000 < got["R"] < 9_500_000
+    # nothing of the partial row's missing pixels leaks: the planes have exactly H rows and the last
+    # tile row's lists are as long as the oracle's
+    assert got["color"].shape == (3, 1066, 1600)
 
 
 def test_config3_full_size_trajectory(dev):

@@ -25,7 +25,23 @@ summary = {
     "worst_non_exempt_element_over_bar": max((r.get("nonexempt_worst_over_bar", 0.0) for r in grd), default=0.0),
     "exempt_gaussian_share_min_max": [min((r["exempt_gaussians_frac"] for r in grd), default=None),
                                       max((r["exempt_gaussians_frac"] for r in grd), default=None)],
+    # the same bar with NO exemption at all (every element of every Gaussian)
+    "gradient_elements_all": sum(r["pixels"] for r in grd),
+    "of_which_beyond_rtol1e-3_atol1e-5 (NO exemption)": sum(r.get("all_elements_beyond_strict", 0) for r in grd),
+    "worst_array_share_beyond (NO exemption)": max((r.get("all_elements_beyond_strict", 0) / max(r["pixels"], 1) for r in grd), default=0.0),
 }
+# per gradient array name: exempt share and misses with / without the exemption
+per = {}
+for r in grd:
+    a = per.setdefault(r["plane"], dict(arrays=0, elements=0, beyond_no_exemption=0, nonexempt_elements=0,
+                                        nonexempt_beyond=0, exempt_share_max=0.0, rel_l2_max=0.0))
+    a["arrays"] += 1; a["elements"] += r["pixels"]; a["beyond_no_exemption"] += r.get("all_elements_beyond_strict", 0)
+    a["nonexempt_elements"] += r["nonexempt_elements"]; a["nonexempt_beyond"] += r["nonexempt_beyond_strict"]
+    a["exempt_share_max"] = max(a["exempt_share_max"], r["exempt_gaussians_frac"]); a["rel_l2_max"] = max(a["rel_l2_max"], r["rel_l2"])
+summary["per_gradient_array"] = per
+psnr = [r for r in recs if r.get("plane") == "psnr"]
+if psnr:
+    summary["psnr_fit"] = psnr[-1]
 # arrays that missed the HIP-vs-oracle bars and were settled against float64 autograd (tests/test_gpu_sweep.py)
 tru = [r for r in grd if "truth_rel_l2_hip" in r]
 summary["gradient_arrays_settled_against_float64_autograd"] = {
