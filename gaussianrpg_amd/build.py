@@ -141,18 +141,16 @@ EXPERIMENT_VARIANTS = {
     "classicsort": {"api.hip": ["-DGRPG_FORCE_CLASSIC_SORT"]},
     # 96 registers / 101 KB of LDS per sort workgroup: room for another stream's workgroup on the same CU
     "sortlean": {"sort.hip": ["-DGRPG_SORT_LEAN"]},
-    # round 5: the producer / consumer PAIRS of round 2-4 for the class-0 tiles instead of the three-stage
-    # wave pipeline (A/B of the pipeline), and the pipeline from 4096 / 16384 entries
-    "pcpair": {"render_fwd.hip": ["-DGRPG_RENDER_PIPE=0"]},
-    "pretouch": {"render_fwd.hip": ["-DGRPG_PL_PRETOUCH"]},
-    # only the class-0 workgroups run (images are wrong): how long is their chain with nothing beside it?
+    # round 5: only the class-0 workgroups run (images are wrong): how long is the chain of the longest
+    # tiles with nothing beside it?  (+ the per-role trace of it, tools/trace_class0.py)
     "only0": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0"]},
-    "only0pair": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0", "-DGRPG_RENDER_PIPE=0"]},
+    "no0": {"render_fwd.hip": ["-DGRPG_RENDER_NO_CLASS0"]},
     "only0trace": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0", "-DGRPG_TRACE"], "render_bwd.hip": ["-DGRPG_TRACE"]},
-    "pipe4096": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=4096"], "api.hip": ["-DGRPG_RENDER_PC_MIN=4096"],
-                 "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=4096"]},
-    "pipe16384": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=16384"], "api.hip": ["-DGRPG_RENDER_PC_MIN=16384"],
-                  "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=16384"]},
+    # the producer / consumer pairs from 4096 / 16384 entries instead of 8192
+    "pc4096": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=4096"], "api.hip": ["-DGRPG_RENDER_PC_MIN=4096"],
+               "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=4096"]},
+    "pc16384": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=16384"], "api.hip": ["-DGRPG_RENDER_PC_MIN=16384"],
+                "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=16384"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

@@ -88,6 +88,22 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges, const 
 __device__ __forceinline__ uint64_t lanes(const bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 __device__ __forceinline__ bool in_mask(const uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// Bounding box of the pixels whose bit is set in a wave-level lane mask (lane l = column l & 15, row
+// l >> 4 of the wave's 16 x 4 lane grid), from the mask's BITS: a dozen scalar instructions.  Until round 5
+// the box was a 6-step butterfly over four floats per lane (24 ds_bpermute round trips + 24 min / max, every
+// time a pixel saturated: ~900 cycles on a wave that runs alone, i.e. on every chain of the launch).
+struct MaskBox { int c0, c1, r0, r1; };   // columns / rows of the lane grid, inclusive; mask != 0
+__device__ __forceinline__ MaskBox mask_box(const uint64_t m) {
+  MaskBox b;
+  b.r0 = (int)(__builtin_ctzll(m) >> 4);
+  b.r1 = (int)((63 - __builtin_clzll(m)) >> 4);
+  uint32_t cols = (uint32_t)m | (uint32_t)(m >> 32);
+  cols = (cols | (cols >> 16)) & 0xFFFFu;
+  b.c0 = (int)__builtin_ctz(cols);
+  b.c1 = 31 - (int)__builtin_clz(cols);
+  return b;
+}
+
 template <int PX>
 struct WavePix {   // per-lane blending state of PX pixels
   float T[PX];   // out_alpha = sum of alpha_i T_i = 1 - T (telescoping): no separate accumulator
@@ -428,23 +444,18 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
       // with the tight box almost nothing survives the cull and a batch costs little more than
       // its staging.
       prev_alive = alive;
-      float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+      // rows y0 + PX * (lane >> 4) + k: per pixel slot k the box of its live lanes (scalar unit, mask_box)
+      int c0 = 15, c1 = 0, r0 = 4 * PX, r1 = -1;
 #pragma unroll
       for (int k = 0; k < PX; k++) {
-        if (in_mask(~st.done[k])) {
-          bx0 = pxf; bx1 = pxf;
-          by0 = fminf(by0, (float)(py0 + k));
-          by1 = fmaxf(by1, (float)(py0 + k));
+        const uint64_t m = ~st.done[k];
+        if (m != 0ull) {
+          const MaskBox b = mask_box(m);
+          c0 = min(c0, b.c0); c1 = max(c1, b.c1);
+          r0 = min(r0, PX * b.r0 + k); r1 = max(r1, PX * b.r1 + k);
         }
       }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
-        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
-        by0 = fminf(by0, __shfl_xor(by0, d, 64));
-        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
-      }
-      rx0 = bx0; rx1 = bx1; ry0 = by0; ry1 = by1;
+      rx0 = (float)(x0 + c0); rx1 = (float)(x0 + c1); ry0 = (float)(y0 + r0); ry1 = (float)(y0 + r1);
     }
     const uint32_t n = min((uint32_t)WAVE, r_end - base);
     const float4 a = a_n, b = b_n, c = c_n;
@@ -636,17 +647,8 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     if (alive == 0ull) break;
     if (alive != prev_alive) {   // shrink the cull box to the live pixels (exact, see blend_rect)
       prev_alive = alive;
-      const bool dn = in_mask(st.done[0]);
-      float bx0 = dn ? 3e38f : pxf, bx1 = dn ? -3e38f : pxf;
-      float by0 = dn ? 3e38f : (float)py, by1 = dn ? -3e38f : (float)py;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
-        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
-        by0 = fminf(by0, __shfl_xor(by0, d, 64));
-        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
-      }
-      rx0 = bx0; rx1 = bx1; ry0 = by0; ry1 = by1;
+      const MaskBox b = mask_box(alive);
+      rx0 = (float)(x0 + b.c0); rx1 = (float)(x0 + b.c1); ry0 = (float)(y0 + b.r0); ry1 = (float)(y0 + b.r1);
     }
 
     // ---- FILL ----
@@ -881,221 +883,39 @@ __device__ __forceinline__ void pc_store(uint32_t* p, const uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool WITH_ID = false>
-__device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
-                                            uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
-                                            PCCtrl* __restrict__ ctl, const int lane,
-                                            const int quarter, const uint32_t r_begin,
-                                            const uint32_t r_end,
-                                            const uint32_t* __restrict__ point_list,
-                                            const RecView rec, const PCErr err) {
-  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
-  const uint64_t lt = lanemask_lt();
-  uint32_t head = 0, count = 0;
-  ListStream ls;
-  ls.open(point_list, r_begin, r_end, lane);
-  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-  uint32_t pos = 0, idc = 0, ncur = 0;
-  int cur = 0;
-  bool stopped = false;
-  for (;;) {
-    if (pc_load(&ctl->stop) != 0u) { stopped = true; break; }
-    // ---- FILL ----
-    while (count < (uint32_t)WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt);
-    // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
-    // reordering the LDS accesses across this point (costs no instruction)
-    __builtin_amdgcn_wave_barrier();
-    // ---- POP ----
-    const uint32_t nn = min(count, (uint32_t)WAVE);
-    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
-    uint32_t pos_n = 0, id_n = 0;
-    if ((uint32_t)lane < nn) {
-      const uint32_t slot = (head + lane) & (QCAP - 1);
-      id_n = qid[slot];
-      pos_n = qpos[slot];
-      rec.load(id_n, a_n, b_n, c_n);
-    }
-    head = (head + nn) & (QCAP - 1);
-    count -= nn;
-    // ---- cull + compact the previous batch into the free buffer, publish it ----
-    if (ncur > 0) {
-      const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
-      const bool keep = ((uint32_t)lane < ncur) &&
-                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
-      const uint64_t mask = __ballot(keep);
-      const int cnt = (int)__popcll(mask);
-      if (cnt > 0) {
-        uint32_t spins = 0;
-        while (pc_load(&ctl->flag[cur]) != 0u) {   // wait until the consumer released this buffer
-          if (pc_load(&ctl->stop) != 0u) { stopped = true; break; }
-          if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); stopped = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (stopped) break;
-        float4* my = cur ? buf1 : buf0;
-        if (keep)
-          store_pair_half<WITH_ID>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
-                                   make_float4(b.w, c.x, c.y, a.z), pos, idc);
-        if (lane < ((4 - (cnt & 3)) & 3)) {
-          const SplatQ zq = {0.f, 0.f, 0.f};
-          store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
-        }
-        pc_store(&ctl->flag[cur], (uint32_t)cnt + 1u);
-        cur ^= 1;
-      }
-    }
-    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
-    if (ncur == 0 && ls.exhausted()) break;
-  }
-  if (!stopped) {   // end-of-list marker
-    uint32_t spins = 0;
-    while (pc_load(&ctl->flag[cur]) != 0u) {
-      if (pc_load(&ctl->stop) != 0u) return;
-      if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); return; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    pc_store(&ctl->flag[cur], PC_DONE);
-  }
-}
-
-template <bool AUX = true, int NSEM = 0>
-__device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
-                                            const float4* __restrict__ buf1,
-                                            PCCtrl* __restrict__ ctl, const int lane,
-                                            const int x0, const int y0, const int W, const int H,
-                                            const float* __restrict__ bg,
-                                            float* __restrict__ out_color,
-                                            float* __restrict__ out_depth,
-                                            float* __restrict__ out_alpha,
-                                            uint32_t* __restrict__ n_contrib, CkptWriter ckw,
-                                            const uint32_t len, const PCErr err,
-                                            const SemSrc sem = SemSrc{nullptr, 0},
-                                            float* __restrict__ out_semantic = nullptr) {
-  SemAcc<NSEM> sa;
-#pragma unroll
-  for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
-  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
-  const float pxf = (float)px;
-  WavePix<1> st;
-  st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f};
-  st.last[0] = 0;
-  st.done[0] = lanes(!(px < W && py < H));
-  uint64_t prev_alive = ~0ull;
-  int cur = 0;
-  if (~st.done[0] == 0ull) pc_store(&ctl->stop, 1u);   // nothing to do (quarter outside the image)
-  else for (;;) {
-    uint32_t f, spins = 0;
-    while ((f = pc_load(&ctl->flag[cur])) == 0u) {
-      if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); f = PC_DONE; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (f == PC_DONE) break;
-    const int cnt = (int)(f - 1u);
-    const float4* my = cur ? buf1 : buf0;
-    for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad<AUX, NSEM>(st, my, j0, pxf, (float)py, &sa, sem);
-    if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
-      const float* blk = reinterpret_cast<const float*>(my + ((cnt - 1) >> 1) * PAIR_F4);
-      ckpt_batch_end(ckw, lane, st,
-                     (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(blk[20 + ((cnt - 1) & 1)])));
-    }
-    pc_store(&ctl->flag[cur], 0u);   // hand the buffer back
-    cur ^= 1;
-    const uint64_t alive = ~st.done[0];
-    if (alive == 0ull) { pc_store(&ctl->stop, 1u); break; }
-    if (alive != prev_alive) {   // shrink the producer's cull box to the live pixels
-      prev_alive = alive;
-      const bool dn = in_mask(st.done[0]);
-      float bx0 = dn ? 3e38f : pxf, bx1 = dn ? -3e38f : pxf;
-      float by0 = dn ? 3e38f : (float)py, by1 = dn ? -3e38f : (float)py;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
-        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
-        by0 = fminf(by0, __shfl_xor(by0, d, 64));
-        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
-      }
-      if (lane == 0) { ctl->box[0] = bx0; ctl->box[1] = bx1; ctl->box[2] = by0; ctl->box[3] = by1; }
-    }
-  }
-  if (AUX) ckpt_finish(ckw, lane, st, len);
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const size_t HW = (size_t)H * W;
-  if (px < W && py < H) {
-    const size_t pix = (size_t)py * W + px;
-    out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
-    out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
-    out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
-    out_alpha[pix] = 1.0f - st.T[0];
-    out_depth[pix] = st.CbD[0].y;
-    if (AUX) n_contrib[pix] = st.last[0];
-    if (NSEM > 0) sem_write<NSEM>(sa, sem.S, out_semantic, HW, pix);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Class 0, round 5: a THREE-STAGE WAVE PIPELINE per quarter (one quarter per workgroup).
-//
-// With the producer / consumer pairs the launch is as long as the consumer's walk of the ~100 longest
-// lists: ~80 cycles per surviving splat on a wave that issues one instruction per 5-6 cycles whatever
-// it does (a launch holding a quarter of the frame's work still takes 0.195 ms).
-// Cutting the LIST into segments re-does the expensive all-pixels-live head of the walk in every
-// segment (built twice in rounds 1-2: slower).  Cutting the WORK PER SPLAT keeps the walk sequential
-// and its arithmetic bit for bit: the accept half of a quad (power, exp2, alpha, the two tests -- 60 %
-// of the consumer's instructions, and independent of the pixel's state) moves to two EVALUATOR waves,
-// which leave alpha (0 where the lane rejects the splat) in LDS; the BLENDER wave runs only what
-// really is a chain -- the transmittance products, the colour accumulation, termination.
-//
-//   wave 1  PRODUCER   FILL / POP / cull / compaction as before, into PL_NB batch slots (s_rec)
-//   wave 2, 3  EVALUATORS  chunks of PL_CHUNK_Q quads, alternately: eval_quad -> alpha chunk k, ok-any masks
-//   wave 0  BLENDER    blend_quad_tail over the chunks in order; checkpoints, live box, stop, outputs
-//
-// Hand-over: single-writer, monotone words in LDS (workgroup-scope acquire / release, no barrier after
-// the start, nothing is ever reset -- no ABA):
-//   bseq[slot]   producer : ((n + 1) << 7) | cnt   batch n is in slot n % PL_NB (cnt 127: end of list)
-//   eprog[k]     evaluator k: batches it has passed;  bprog  blender: batches blended
-//                -> the producer refills a slot once all three are beyond its previous tenant
-//   aseq[k]      evaluator k: id + 1 of the chunk in its alpha buffer
-//   acons[k]     blender: id + 1 of the last chunk of buffer k it has consumed
-// Chunk ids follow from the batches' counts, which every reader takes from bseq in the same order;
-// evaluator k owns the chunks with id % 2 == k and alpha buffer k.  Spin loops are bounded like the
-// pairs' (pc_fail).
-// ------------------------------------------------------------------------------------------
-#ifndef GRPG_RENDER_PIPE
-#define GRPG_RENDER_PIPE 1
-#endif
-constexpr int PL_NB = 4;                      // batch slots: 4 x 3 KB = s_rec
-constexpr int PL_CHUNK_Q = 8;                 // quads per alpha chunk (32 survivors, 8 KB)
-constexpr uint32_t PL_END = 127u;
-struct PLCtrl {
-  uint32_t bseq[PL_NB];
-  uint32_t eprog[2], bprog, stop;
-  uint32_t aseq[2], acons[2];
-  float box[4];
-  uint32_t okany[2][PL_CHUNK_Q][2];          // per chunk buffer and quad: lanes that accept any of its splats
-  uint32_t sink[2];
-};
-
-// returns false on stop / time-out
+// waits until ready() (false: the consumer stopped, or the hand-over timed out -- reported, see above)
 template <class Cond>
-__device__ __forceinline__ bool pl_wait(PLCtrl* __restrict__ ctl, const PCErr err, const int lane, Cond ready,
-                                        WaveTrace* tr = nullptr /* experiment build: cycles spent waiting */) {
-  uint32_t spins = 0;
+__device__ __forceinline__ bool pc_wait(PCCtrl* __restrict__ ctl, const PCErr err, const int lane, const bool poll_stop,
+                                        Cond ready, WaveTrace* tr = nullptr /* experiment build: cycles waited */) {
   if (ready()) return true;
   const uint64_t t0 = tr ? __builtin_readcyclecounter() : 0;
+  uint32_t spins = 0;
   bool ok = true;
   while (!ready()) {
-    if (pc_load(&ctl->stop) != 0u) { ok = false; break; }
-    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); pc_store(&ctl->stop, 1u); ok = false; break; }
+    if (poll_stop && pc_load(&ctl->stop) != 0u) { ok = false; break; }
+    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); ok = false; break; }
     __builtin_amdgcn_s_sleep(1);
   }
   if (tr) { tr->t_stage += (uint32_t)(__builtin_readcyclecounter() - t0); tr->blends++; }
   return ok;
 }
 
+// Round 5.  With nothing else on the chip the 96 class-0 tiles of the bench frame take 0.197 ms
+// (experiment build `only0pair`): that chain, not throughput, set the render launch's length.  Per-wave
+// traces of a three-stage split of the consumer (evaluator / blender waves, built and measured: no gain,
+// twice the wave slots -- DESIGN_EXPERIMENTS.md) showed BOTH halves of the pair within 10 % of each other:
+//   producer  1.9 us per batch for 0.7 us of work -- one list window and one record gather in flight
+//             per iteration, each a full HBM / Infinity Cache round trip;
+//   consumer  ~650 cycles per quad: three exposed LDS round trips per quad, and per batch the live box
+//             by 24 ds_bpermute round trips, two polls and a batch of only ~26 survivors to amortise them.
+// Hence: the list arrives in 2048-entry windows (ListStream), the producer gathers TWO batches' records
+// per iteration and publishes them as ONE batch when their survivors fit a buffer, the consumer keeps a
+// quad's geometry one quad ahead in registers and requests its colours before the accept arithmetic,
+// and the live box comes from the lane mask's bits (mask_box).
 template <bool WITH_ID = false>
-__device__ __forceinline__ void pl_producer(float4* __restrict__ slots /* PL_NB x WAVE*REC_F4 */,
+__device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
                                             uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
-                                            PLCtrl* __restrict__ ctl, const int lane,
+                                            PCCtrl* __restrict__ ctl, const int lane,
                                             const int quarter, const uint32_t r_begin,
                                             const uint32_t r_end,
                                             const uint32_t* __restrict__ point_list,
@@ -1105,41 +925,27 @@ __device__ __forceinline__ void pl_producer(float4* __restrict__ slots /* PL_NB 
   uint32_t head = 0, count = 0;
   ListStream ls;
   ls.open(point_list, r_begin, r_end, lane);
-  // TWO batches per iteration (every lane gathers two records): the producer is one wave, its record
-  // gather is a dependent HBM / Infinity Cache round trip per iteration, and with one batch per
-  // iteration that latency -- not the producer's instructions -- set its pace (1.9 us per batch measured,
-  // 0.7 us of work).
   float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, c0 = a0, a1 = a0, b1 = a0, c1 = a0;
   uint32_t pos0 = 0, id0 = 0, pos1 = 0, id1 = 0, ncur = 0;
-  uint32_t n = 0;   // batches published
-  const auto slot_free = [&]() {
-    return n < (uint32_t)PL_NB || (pc_load(&ctl->bprog) + PL_NB > n && pc_load(&ctl->eprog[0]) + PL_NB > n &&
-                                   pc_load(&ctl->eprog[1]) + PL_NB > n);
-  };
-  // culls `cnt_in` gathered records (one per lane) against the consumers' live box, compacts the
-  // survivors into the next batch slot and publishes it; false: the consumers have stopped
-  const auto emit = [&](const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc,
-                        const uint32_t cnt_in) -> bool {
-    const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
-    const bool keep = ((uint32_t)lane < cnt_in) &&
-                      !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
-    const uint64_t mask = __ballot(keep);
-    const int cnt = (int)__popcll(mask);
-    if (cnt == 0) return true;
-    if (!pl_wait(ctl, err, lane, slot_free, tr)) return false;
-    if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
-    float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
+  int cur = 0;
+  // the survivors `keep` of one gathered half, compacted behind `base` entries already in buffer `my`
+  const auto put = [&](float4* __restrict__ my, const bool keep, const uint64_t mask, const int base,
+                       const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc) {
     if (keep)
-      store_pair_half<WITH_ID>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+      store_pair_half<WITH_ID>(my, base + (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
                                make_float4(b.w, c.x, c.y, a.z), pos, idc);
-    if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
+  };
+  // neutral pads up to a multiple of 4 (opacity 0), then the hand-over of cnt survivors in buffer `cur`
+  const auto publish = [&](float4* __restrict__ my, const int cnt) {
+    if (lane < ((4 - (cnt & 3)) & 3)) {
       const SplatQ zq = {0.f, 0.f, 0.f};
       store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
     }
-    pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | (uint32_t)cnt);
-    n++;
-    return true;
+    if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
+    pc_store(&ctl->flag[cur], (uint32_t)cnt + 1u);
+    cur ^= 1;
   };
+  const auto buffer_free = [&]() { return pc_load(&ctl->flag[cur]) == 0u; };
   for (;;) {
     if (pc_load(&ctl->stop) != 0u) return;
     // ---- FILL: until two batches are queued (ring: < 128 + 256 entries <= QCAP) ----
@@ -1165,153 +971,106 @@ __device__ __forceinline__ void pl_producer(float4* __restrict__ slots /* PL_NB 
     }
     head = (head + nn) & (QCAP - 1);
     count -= nn;
-    // ---- the previous iteration's records: cull, compact, publish (list order: first half first) ----
+    // ---- the previous iteration's records: cull against the consumer's live box, compact, publish ----
     if (ncur > 0) {
-      if (!emit(a0, b0, c0, pos0, id0, min(ncur, (uint32_t)WAVE))) return;
-      if (ncur > (uint32_t)WAVE && !emit(a1, b1, c1, pos1, id1, ncur - WAVE)) return;
+      const float rx0 = ctl->box[0], rx1 = ctl->box[1], ry0 = ctl->box[2], ry1 = ctl->box[3];
+      const bool k0 = ((uint32_t)lane < ncur) &&
+                      !splat_misses_rect(a0.x, a0.y, b0.x, b0.y, b0.z, a0.w, rx0, rx1, ry0, ry1);
+      const bool k1 = ((uint32_t)lane + WAVE < ncur) &&
+                      !splat_misses_rect(a1.x, a1.y, b1.x, b1.y, b1.z, a1.w, rx0, rx1, ry0, ry1);
+      const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
+      const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1);
+      if (n0 + n1 > 0) {
+        if (!pc_wait(ctl, err, lane, true, buffer_free, tr)) return;
+        float4* my = cur ? buf1 : buf0;
+        if (n0 + n1 <= WAVE) {   // one batch (list order: the first half's survivors first)
+          put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
+          put(my, k1, m1, n0, a1, b1, c1, pos1, id1);
+          publish(my, n0 + n1);
+        } else {                 // two batches
+          put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
+          publish(my, n0);
+          if (!pc_wait(ctl, err, lane, true, buffer_free, tr)) return;
+          my = cur ? buf1 : buf0;
+          put(my, k1, m1, 0, a1, b1, c1, pos1, id1);
+          publish(my, n1);
+        }
+      }
     }
     a0 = a0n; b0 = b0n; c0 = c0n; pos0 = pos0n; id0 = id0n;
     a1 = a1n; b1 = b1n; c1 = c1n; pos1 = pos1n; id1 = id1n;
     ncur = nn;
     if (ncur == 0 && ls.exhausted()) break;
   }
-  if (!pl_wait(ctl, err, lane, slot_free, tr)) return;   // end-of-list marker
-  pc_store(&ctl->bseq[n % PL_NB], ((n + 1u) << 7) | PL_END);
-}
-
-__device__ __forceinline__ void pl_evaluator(const float4* __restrict__ slots, float4* __restrict__ abuf /* mine */,
-                                             PLCtrl* __restrict__ ctl, const int k, const int lane,
-                                             const int x0, const int y0, const PCErr err,
-                                             const uint32_t* __restrict__ touch_list = nullptr,
-                                             const uint32_t touch_len = 0u, WaveTrace* tr = nullptr) {
-  const float pxf = (float)(x0 + (lane & 15)), pyf = (float)(y0 + (lane >> 4));
-  uint32_t chunk = 0;
-#ifdef GRPG_PL_PRETOUCH   // experiment: the whole list is pulled into this XCD's L2 before the producer needs it
-  {
-    uint32_t acc = 0;
-    for (uint32_t i = (uint32_t)(lane + 64 * k) * 32u; i < touch_len; i += 128u * 32u) acc ^= touch_list[i];
-    ctl->sink[k] = acc;
-  }
-#endif
-  for (uint32_t n = 0;; n++) {
-    uint32_t f = 0;
-    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; }, tr)) return;
-    const uint32_t cnt = f & 127u;
-    if (cnt == PL_END) return;
-    const float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
-    const int nq = (int)((cnt + 3u) >> 2);
-    for (int q0 = 0; q0 < nq; q0 += PL_CHUNK_Q, chunk++) {
-      if ((int)(chunk & 1u) != k) continue;
-      if (tr) tr->batches++;
-      // my alpha buffer is free once the blender is through my previous chunk (id chunk - 2)
-      if (chunk >= 2u && !pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->acons[k]) + 1u >= chunk; }, tr)) return;
-      const int q1 = min(nq, q0 + PL_CHUNK_Q);
-      QuadGeom g_n;   // a quad ahead in registers, like the blender (one LDS round trip per quad otherwise)
-      g_n.load(my + q0 * 2 * PAIR_F4);
-      for (int q = q0; q < q1; q++) {
-        float alpha[4];
-        uint64_t ok[4];
-        const QuadGeom g = g_n;
-        g_n.load(my + min(q + 1, q1 - 1) * 2 * PAIR_F4);
-        eval_quad(g, pxf, pyf, alpha, ok);
-        float4 am;
-        am.x = in_mask(ok[0]) ? alpha[0] : 0.0f;
-        am.y = in_mask(ok[1]) ? alpha[1] : 0.0f;
-        am.z = in_mask(ok[2]) ? alpha[2] : 0.0f;
-        am.w = in_mask(ok[3]) ? alpha[3] : 0.0f;
-        abuf[(q - q0) * WAVE + lane] = am;
-        const uint64_t any = ok[0] | ok[1] | ok[2] | ok[3];
-        if (lane == 0) { ctl->okany[k][q - q0][0] = (uint32_t)any; ctl->okany[k][q - q0][1] = (uint32_t)(any >> 32); }
-      }
-      pc_store(&ctl->aseq[k], chunk + 1u);
-    }
-    pc_store(&ctl->eprog[k], n + 1u);
-  }
+  if (!pc_wait(ctl, err, lane, true, buffer_free, tr)) return;   // end-of-list marker
+  pc_store(&ctl->flag[cur], PC_DONE);
 }
 
 template <bool AUX = true, int NSEM = 0>
-__device__ __forceinline__ void pl_blender(const float4* __restrict__ slots, const float4* __restrict__ abuf0,
-                                           const float4* __restrict__ abuf1, PLCtrl* __restrict__ ctl,
-                                           const int lane, const int x0, const int y0, const int W, const int H,
-                                           const float* __restrict__ bg,
-                                           float* __restrict__ out_color, float* __restrict__ out_depth,
-                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                                           CkptWriter ckw, const uint32_t len, const PCErr err,
-                                           const SemSrc sem = SemSrc{nullptr, 0},
-                                           float* __restrict__ out_semantic = nullptr, WaveTrace* tr = nullptr) {
+__device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
+                                            const float4* __restrict__ buf1,
+                                            PCCtrl* __restrict__ ctl, const int lane,
+                                            const int x0, const int y0, const int W, const int H,
+                                            const float* __restrict__ bg,
+                                            float* __restrict__ out_color,
+                                            float* __restrict__ out_depth,
+                                            float* __restrict__ out_alpha,
+                                            uint32_t* __restrict__ n_contrib, CkptWriter ckw,
+                                            const uint32_t len, const PCErr err,
+                                            const SemSrc sem = SemSrc{nullptr, 0},
+                                            float* __restrict__ out_semantic = nullptr, WaveTrace* tr = nullptr) {
   SemAcc<NSEM> sa;
 #pragma unroll
   for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
   const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
-  const float pxf = (float)px;
+  const float pxf = (float)px, pyf = (float)py;
   WavePix<1> st;
   st.T[0] = 1.0f; st.CrCg[0] = (v2f){0.f, 0.f}; st.CbD[0] = (v2f){0.f, 0.f};
   st.last[0] = 0;
   st.done[0] = lanes(!(px < W && py < H));
   uint64_t prev_alive = ~0ull;
-  uint32_t chunk = 0;
+  int cur = 0;
   if (~st.done[0] == 0ull) pc_store(&ctl->stop, 1u);   // nothing to do (quarter outside the image)
-  else for (uint32_t n = 0;; n++) {
+  else for (;;) {
     uint32_t f = 0;
-    if (!pl_wait(ctl, err, lane, [&]() { f = pc_load(&ctl->bseq[n % PL_NB]); return (f >> 7) == n + 1u; }, tr)) break;
-    const uint32_t cnt = f & 127u;
-    if (cnt == PL_END) break;
-    if (tr) { tr->batches++; tr->survivors += cnt; }
-    const float4* my = slots + (n % PL_NB) * (WAVE * REC_F4);
-    const int nq = (int)((cnt + 3u) >> 2);
-    bool lost = false;
-    for (int q0 = 0; q0 < nq; q0 += PL_CHUNK_Q, chunk++) {
-      const int k = (int)(chunk & 1u);
-      if (!pl_wait(ctl, err, lane, [&]() { return pc_load(&ctl->aseq[k]) == chunk + 1u; }, tr)) { lost = true; break; }
-      const float4* ab = (k ? abuf1 : abuf0) + lane;
-      const uint32_t* okw = &ctl->okany[k][lane & (PL_CHUNK_Q - 1)][0];
-      const uint32_t ok_lo = okw[0], ok_hi = okw[1];
-      const int q1 = min(nq, q0 + PL_CHUNK_Q);
-      // The blender is the chain of the whole launch, and a wave on its own pays every LDS round trip
-      // in full (~130 cycles; the first version read alpha, then the colours, then the positions of a
-      // quad one after the other: 800 cycles per quad, tools/trace_class0.py): the alpha vector and the
-      // colour blocks of quad q + 1 are requested BEFORE quad q is blended and wait in registers.
-      constexpr bool PP = AUX || NSEM > 0;
-      float4 am_n = ab[0];
-      QuadColsReg<PP> col_n;
-      col_n.load(my + q0 * 2 * PAIR_F4);
-      for (int q = q0; q < q1; q++) {
-        const float4 am = am_n;
-        const QuadColsReg<PP> col = col_n;
-        const int qn = min(q + 1, q1 - 1);   // (the last quad is read twice: no branch around the loads)
-        am_n = ab[(qn - q0) * WAVE];
-        col_n.load(my + qn * 2 * PAIR_F4);
-        const uint64_t any = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ok_lo, q - q0) |
-                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ok_hi, q - q0) << 32);
-        if ((any & ~st.done[0]) == 0ull) continue;   // no live lane takes any splat of this quad
-        const float alpha[4] = {am.x, am.y, am.z, am.w};
-        const uint64_t ok[4] = {lanes(am.x != 0.0f), lanes(am.y != 0.0f), lanes(am.z != 0.0f), lanes(am.w != 0.0f)};
-        blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, &sa, sem);
-      }
-      pc_store(&ctl->acons[k], chunk + 1u);
+    if (!pc_wait(ctl, err, lane, false, [&]() { f = pc_load(&ctl->flag[cur]); return f != 0u; }, tr)) break;
+    if (f == PC_DONE) break;
+    const int cnt = (int)(f - 1u);
+    if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
+    const float4* my = cur ? buf1 : buf0;
+    // A quad's geometry block waits in registers one quad ahead, its colour / position blocks are
+    // requested before the accept arithmetic: the wave has its SIMD to itself at the end of the
+    // launch, and every LDS round trip it waits for (three per quad until round 5) is the launch's.
+    constexpr bool PP = AUX || NSEM > 0;
+    QuadGeom g_n;
+    g_n.load(my);
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+      const float4* blk = my + (j0 >> 1) * PAIR_F4;
+      const QuadGeom g = g_n;
+      QuadColsReg<PP> col;
+      col.load(blk);
+      g_n.load(my + (min(j0 + 4, cnt - 1) >> 1) * PAIR_F4);   // (the last quad twice: no branch around the loads)
+      float alpha[4];
+      uint64_t ok[4];
+      eval_quad(g, pxf, pyf, alpha, ok);
+      blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, &sa, sem);
     }
-    if (lost) break;
     if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
-      const float* blk = reinterpret_cast<const float*>(my + (((int)cnt - 1) >> 1) * PAIR_F4);
+      const float* blk = reinterpret_cast<const float*>(my + ((cnt - 1) >> 1) * PAIR_F4);
       ckpt_batch_end(ckw, lane, st,
-                     (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(blk[20 + (((int)cnt - 1) & 1)])));
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(blk[20 + ((cnt - 1) & 1)])));
     }
-    pc_store(&ctl->bprog, n + 1u);   // hand the batch slot back
+    pc_store(&ctl->flag[cur], 0u);   // hand the buffer back
+    cur ^= 1;
     const uint64_t alive = ~st.done[0];
     if (alive == 0ull) { pc_store(&ctl->stop, 1u); break; }
     if (alive != prev_alive) {   // shrink the producer's cull box to the live pixels
       prev_alive = alive;
-      const bool dn = in_mask(st.done[0]);
-      float bx0 = dn ? 3e38f : pxf, bx1 = dn ? -3e38f : pxf;
-      float by0 = dn ? 3e38f : (float)py, by1 = dn ? -3e38f : (float)py;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
-        bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
-        by0 = fminf(by0, __shfl_xor(by0, d, 64));
-        by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+      const MaskBox b = mask_box(alive);
+      if (lane == 0) {
+        ctl->box[0] = (float)(x0 + b.c0); ctl->box[1] = (float)(x0 + b.c1);
+        ctl->box[2] = (float)(y0 + b.r0); ctl->box[3] = (float)(y0 + b.r1);
       }
-      if (lane == 0) { ctl->box[0] = bx0; ctl->box[1] = bx1; ctl->box[2] = by0; ctl->box[3] = by1; }
     }
   }
   if (AUX) ckpt_finish(ckw, lane, st, len);
@@ -1349,26 +1108,10 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const uint32_t pc_slots, const CkptArgs ck, const PCErr pc_err,
                       const SemSrc sem, float* __restrict__ out_semantic,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
-  // one object, members in this order: the class-0 pipeline uses qid + qpos as ONE 16 KB area
-  struct RenderLds {
-    float4 rec[RW_WAVES][WAVE * REC_F4];   // 12 KB: per-wave survivor slabs | pipeline: PL_NB batch slots
-    uint32_t qid[RW_WAVES][QCAP];          //  8 KB: per-wave rings          | pipeline: the two alpha chunk
-    uint32_t qpos[RW_WAVES][QCAP];         //  8 KB                          |   buffers (2 x 8 KB)
-#if GRPG_RENDER_PIPE
-    uint32_t pq[2][QCAP];                  //  4 KB: the pipeline producer's ring
-    PLCtrl pl;
-#else
-    PCCtrl ctl[2];
-#endif
-  };
-  __shared__ RenderLds L;
-  auto& s_rec = L.rec;
-  auto& s_qid = L.qid;
-  auto& s_qpos = L.qpos;
-#if !GRPG_RENDER_PIPE
-  auto& s_ctl = L.ctl;
-#endif
-  static_assert(sizeof(L.qid) + sizeof(L.qpos) >= 2 * PL_CHUNK_Q * WAVE * sizeof(float4), "alpha chunks");
+  __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
+  __shared__ uint32_t s_qid[RW_WAVES][QCAP];
+  __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
+  __shared__ PCCtrl s_ctl[2];
 #ifdef GRPG_RENDER_LDS_PAD   // experiment build: unused LDS that caps the workgroups per CU
   __shared__ uint32_t s_pad[GRPG_RENDER_LDS_PAD / 4];
   if (W < 0) s_pad[threadIdx.x] = (uint32_t)H;   // never true: keeps the array allocated
@@ -1390,51 +1133,9 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 #ifdef GRPG_RENDER_ONLY_CLASS0   // experiment build: the class-0 tiles alone (their chain, nothing beside it)
   if (blockIdx.x >= pc_slots) return;
 #endif
-#if GRPG_RENDER_PIPE
-  // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each QUARTER is a workgroup of its
-  // own: blender, producer, two evaluators (pipeline above).  The first pc_slots workgroups are
-  // reserved for them (upper bound of 4 n0 computed on the host from num_rendered).
-  if (blockIdx.x < pc_slots) {
-    if (blockIdx.x >= 4u * n0) return;
-    const uint32_t tile = lists[blockIdx.x >> 2];
-    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
-    const uint2 range = ranges[tile];
-    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
-    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
-    const int q = (int)(blockIdx.x & 3u);
-    const int x0 = tx * TILE, y0 = ty * TILE + q * 4;
-    if (threadIdx.x < (unsigned)(sizeof(PLCtrl) / 4)) reinterpret_cast<uint32_t*>(&L.pl)[threadIdx.x] = 0u;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      L.pl.box[0] = (float)x0; L.pl.box[1] = (float)(x0 + 15);
-      L.pl.box[2] = (float)y0; L.pl.box[3] = (float)(y0 + 3);
-    }
-    __syncthreads();   // the only workgroup barriers: all 4 waves of the workgroup take this branch
-    float4* const slots = &L.rec[0][0];
-    float4* const abuf = reinterpret_cast<float4*>(&L.qid[0][0]);   // 2 x PL_CHUNK_Q x WAVE float4
-    WaveTrace* const trp = TRACE ? &tr : nullptr;
-    if (wave == 0) {
-      pl_blender<WRITE_AUX, NSEM>(slots, abuf, abuf + PL_CHUNK_Q * WAVE, &L.pl, lane, x0, y0, W, H, bg, out_color,
-                                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb,
-                                  pc_err, sem, out_semantic, trp);
-      if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
-    } else if (wave == 1) {
-      pl_producer<(NSEM > 0)>(slots, L.pq[0], L.pq[1], &L.pl, lane, q, rb, re, point_list, rec, pc_err, trp);
-    } else {
-      pl_evaluator(slots, abuf + (wave - 2) * PL_CHUNK_Q * WAVE, &L.pl, wave - 2, lane, x0, y0, pc_err,
-                   point_list + rb, re - rb, trp);
-    }
-    if (TRACE && lane == 0) {   // class-0 roles: wave 0 blender, 1 producer, 2 / 3 evaluators
-      // [0] tile | 0x40000000  [1] list length  [2] batches / chunks  [3] survivors  [4] waits
-      // [5] wave cycles (wall clock ticks)  [6] start  [7] wave | waiting cycles / 256 << 4
-      uint32_t* o = trace + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
-      o[0] = tile | 0x40000000u; o[1] = re - rb; o[2] = tr.batches; o[3] = tr.survivors; o[4] = tr.blends;
-      o[5] = (uint32_t)(wall_clock64() - t_start); o[6] = (uint32_t)(t_start & 0xFFFFFFFFu);
-      o[7] = (uint32_t)wave | ((tr.t_stage >> 8) << 4);
-    }
-    return;
-  }
-#else
+#ifdef GRPG_RENDER_NO_CLASS0     // experiment build: everything BUT the class-0 tiles (the throughput part)
+  if (blockIdx.x < pc_slots) return;
+#endif
   if (blockIdx.x < pc_slots) {
     if (blockIdx.x >= 2u * n0) return;
     const uint32_t tile = lists[blockIdx.x >> 1];
@@ -1451,17 +1152,25 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
       s_ctl[slot].box[2] = (float)y0; s_ctl[slot].box[3] = (float)(y0 + 3);
     }
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
+    WaveTrace* const trp = TRACE ? &tr : nullptr;
     if (wave < 2) {
       pc_consumer<WRITE_AUX, NSEM>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
                   out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err, sem,
-                  out_semantic);
+                  out_semantic, trp);
       if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
     } else
       pc_producer<(NSEM > 0)>(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
-                  rb, re, point_list, rec, pc_err);
+                  rb, re, point_list, rec, pc_err, trp);
+    if (TRACE && lane == 0) {   // class-0 roles: waves 0, 1 consumers, 2, 3 producers
+      // [0] tile | 0x40000000  [1] list length  [2] batches  [3] survivors  [4] waits
+      // [5] wave life (wall clock ticks)  [6] start  [7] wave | waiting cycles / 256 << 4
+      uint32_t* o = trace + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
+      o[0] = tile | 0x40000000u; o[1] = re - rb; o[2] = tr.batches; o[3] = tr.survivors; o[4] = tr.blends;
+      o[5] = (uint32_t)(wall_clock64() - t_start); o[6] = (uint32_t)(t_start & 0xFFFFFFFFu);
+      o[7] = (uint32_t)wave | ((tr.t_stage >> 8) << 4);
+    }
     return;
   }
-#endif
   // Dispatch order (longest processing time first): class 0, class 1, the LIGHT tiles, class 2.
   // A light tile is a whole tile on one wave (measured 40-70 us for 100-250 entries), longer than
   // a quarter wave of a class-2 tile (20-30 us), so it must not come last.
@@ -1604,9 +1313,7 @@ render_semantic_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 // workgroups reserved for half tiles of class 0 (producer / consumer wave pairs): at most
 // R / RENDER_PC_MIN tiles can be that long, two workgroups each.  The forward and the backward of one
 // frame agree on it (both derive it from num_rendered).
-uint32_t render_pc_slots(uint32_t R) {
-  return (GRPG_RENDER_PIPE ? 4u : 2u) * (uint32_t)((size_t)R / RENDER_PC_MIN + 1);
-}
+uint32_t render_pc_slots(uint32_t R) { return 2u * (uint32_t)((size_t)R / RENDER_PC_MIN + 1); }
 
 void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                            const RecView rec, int W, int H, int gx, int gy, const float* bg,

@@ -1,6 +1,6 @@
-"""Summarise the class-0 (three-stage wave pipeline) records of a render trace written with
-GRPG_RENDER_TRACE by the `trace` experiment build (tools/trace_render.py):
-per quarter workgroup the life time of each role and the share of it spent waiting for another role."""
+"""Summarise the class-0 (producer / consumer wave pairs) records of a render trace written with
+GRPG_RENDER_TRACE by the `trace` / `only0trace` experiment builds (tools/trace_render.py): per quarter the
+life time of its consumer and producer wave and the share of it each spent waiting for the other."""
 import sys
 import numpy as np
 raw = np.fromfile(sys.argv[1], dtype=np.uint32)
@@ -12,12 +12,14 @@ if not len(v):
     print("no class-0 records"); sys.exit(0)
 idx = np.nonzero(sel)[0]
 block = idx // 4
-role = v[:, 7] & 15
+wave = v[:, 7] & 15
+role = wave >> 1                     # waves 0, 1: consumers of the workgroup's two quarters; 2, 3: producers
+block = block * 2 + (wave & 1)       # one id per quarter
 wait_cyc = (v[:, 7] >> 4).astype(np.int64) * 256          # shader clocks
 us = v[:, 5].astype(np.int64) / 100.0                       # wall clock: 100 MHz
-names = {0: "blender", 1: "producer", 2: "evaluator0", 3: "evaluator1"}
-print("class-0 quarter workgroups: %d, tiles %d" % (len(np.unique(block)), len(np.unique(v[:, 0]))))
-for r in range(4):
+names = {0: "consumer", 1: "producer"}
+print("class-0 quarters: %d, tiles %d" % (len(np.unique(block)), len(np.unique(v[:, 0]))))
+for r in range(2):
     m = role == r
     if not m.any():
         continue
@@ -33,7 +35,7 @@ order = np.argsort(-bl[:, 5].astype(np.int64))[:10]
 for i in order:
     b = blk[i]
     parts = []
-    for r in range(4):
+    for r in range(2):
         m = (block == b) & (role == r)
         if m.any():
             j = np.nonzero(m)[0][0]
