@@ -112,29 +112,70 @@ struct WavePix {   // per-lane blending state of PX pixels
   uint64_t done[PX];       // lane masks: pixel k of the lane is saturated / outside the image
 };
 
-// N-channel "semantic" planes (forward.cu:442-444: out_semantic[ch] += semantic[ch] alpha T): NSEM
-// accumulators per pixel next to the colour ones, fed by the SAME blend weights -- the heavy path
-// (one pixel per lane) carries them; the semantic row of a splat is wave-uniform, so it arrives
-// through the scalar unit (s_load) and costs the vector ALU one fma per channel and (wave, splat).
+// N-channel "semantic" planes (forward.cu:442-444: out_semantic[ch] += semantic[ch] alpha T).
+//
+// Per quad of splats this is a small matrix product, Out[64 pixels][16 channels] += W[64][4] Sem[4][16],
+// with W the blend weights the colour path computes anyway -- the one contraction on this path, and the
+// matrix pipe idles in this kernel.  Round 4 ran it on the vector ALU (16 fma per splat and wave, the row
+// fetched through the scalar unit): S = 15 made the render 3.6 x as long.  Round 5: v_mfma_f32_16x16x4_f32
+// (fp32 in, fp32 accumulate) per pixel ROW of the quarter:
+//   A (16 pixels x 4 splats)  lane 16 k + m must hold w_k of pixel (column m, row y); the wave holds w_0..3 of
+//                             pixel (m, y) in lane 16 y + m -- a 4 x 4 transpose between lane rows and
+//                             registers: two v_permlane32_swap + two v_permlane16_swap give all four A's;
+//   B (4 splats x 16 channels) lane 16 k + n reads Sem[splat k][channel n] from the batch's rows, which the
+//                             compaction step staged in LDS in survivor order (one ds_read_b32 per quad);
+//   D  four accumulators of 4 registers: pixel columns 4 (l / 16) + i of row y, channel l % 16.
+// Vector-ALU cost per quad: 4 swaps + 4 MFMA issues instead of 64 fma + 4 scalar row fetches.  Products are
+// exact (w x sem in fp32), the accumulation order inside an MFMA differs from the sequential fma chain by
+// rounding only (1e-7 relative; the bar is 1e-4).  A lane that rejects a splat contributes w = 0: semantic
+// values must be FINITE (0 x Inf = NaN; the reference skips rejected splats) -- rows of pad slots are zeros.
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int NSEM>
-struct SemAcc { float v[NSEM > 0 ? NSEM : 1]; };
-struct SemSrc { const float* semantics; int S; };   // [P][S]
-template <int NSEM>
-__device__ __forceinline__ void sem_accumulate(SemAcc<NSEM>& sa, const SemSrc src, const uint32_t id_uniform,
-                                               const float w) {
-  if (NSEM == 0) return;
-  const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id_uniform);
-  const float* __restrict__ row = src.semantics + (size_t)id * (size_t)src.S;
+struct SemAcc {
+  static_assert(NSEM == 0 || NSEM == 16, "the MFMA tile is 16 channels wide");
+  v4f acc[NSEM > 0 ? 4 : 1];
+  __device__ __forceinline__ void clear() {
 #pragma unroll
-  for (int c = 0; c < NSEM; c++) sa.v[c] = fmaf(row[c < src.S ? c : 0], w, sa.v[c]);   // c >= S: never written out
+    for (int y = 0; y < (NSEM > 0 ? 4 : 1); y++) acc[y] = (v4f){0.f, 0.f, 0.f, 0.f};
+  }
+};
+// semantics [P][S] in HBM; rows: the current batch's staged rows in LDS, [slot][16] floats (slots = the
+// batch's compacted survivors incl. pads, same numbering as the pair blocks)
+struct SemSrc { const float* semantics; int S; const float* rows; };
+constexpr int SEM_ROW = 16;
+
+// stages the row of Gaussian `id` (zeros when !valid: a pad) as slot `slot` of the batch
+__device__ __forceinline__ void sem_stage(float* __restrict__ rows, const int slot, const float* __restrict__ semantics,
+                                          const int S, const uint32_t id, const bool valid) {
+  const float* __restrict__ row = semantics + (size_t)id * (size_t)S;
+  float v[SEM_ROW];
+#pragma unroll
+  for (int c = 0; c < SEM_ROW; c++) v[c] = (valid && c < S) ? row[c < S ? c : 0] : 0.f;   // never past the row
+  float4* dst = reinterpret_cast<float4*>(rows + slot * SEM_ROW);
+#pragma unroll
+  for (int c = 0; c < SEM_ROW; c += 4) dst[c >> 2] = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+}
+
+// the quad whose first slot is j0: w[i] = blend weight of slot j0 + i for this lane's pixel
+template <int NSEM>
+__device__ __forceinline__ void sem_quad(SemAcc<NSEM>& sa, const float (&w)[4], const float* __restrict__ rows,
+                                         const int j0, const int lane) {
+  if (NSEM == 0) return;
+  const float b = rows[j0 * SEM_ROW + lane];
+  const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[0]), __float_as_uint(w[2]), false, false);
+  const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[1]), __float_as_uint(w[3]), false, false);
+  const auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+  const auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+  sa.acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t01[0]), b, sa.acc[0], 0, 0, 0);
+  sa.acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t01[1]), b, sa.acc[1], 0, 0, 0);
+  sa.acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t23[0]), b, sa.acc[2], 0, 0, 0);
+  sa.acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t23[1]), b, sa.acc[3], 0, 0, 0);
 }
 
 // In-order blend of one splat into pixel k (forward.cu:425-440); ok_m = lanes that accept it.
-template <int PX, bool AUX = true, int NSEM = 0>
-__device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uint64_t ok_m,
-                                          const float alpha, const float4 col, const uint32_t pos,
-                                          SemAcc<NSEM>* sa = nullptr, const SemSrc src = SemSrc{nullptr, 0},
-                                          const uint32_t id = 0u) {
+template <int PX, bool AUX = true>
+__device__ __forceinline__ float blend_one(WavePix<PX>& s, const int k, const uint64_t ok_m,
+                                           const float alpha, const float4 col, const uint32_t pos) {
   const v2f tw = (v2f){1.0f - alpha, alpha} * (v2f){s.T[k], s.T[k]};   // T (1 - alpha), alpha T
   const uint64_t lt_m = lanes(tw.x < 0.0001f);
   const uint64_t live = ok_m & ~s.done[k];
@@ -153,7 +194,7 @@ __device__ __forceinline__ void blend_one(WavePix<PX>& s, const int k, const uin
   }
   s.T[k] = cont ? tw.x : s.T[k];
   if (AUX) s.last[k] = cont ? pos : s.last[k];   // n_contrib: only a later backward needs it
-  if (NSEM > 0) sem_accumulate<NSEM>(*sa, src, id, w);
+  return w;                                       // the blend weight (0 where the lane does not take the splat)
 }
 
 // LDS slot of a compacted survivor, light path (REC_F4 = 3 float4):
@@ -235,7 +276,7 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
   for (int g = 0; g < G; g++) {   // some pixel terminates inside this group: exact per-splat blend
 #pragma unroll
     for (int k = 0; k < PX; k++)
-      blend_one<PX, AUX>(s, k, ok[g][k], alpha[g][k], rc[g], __float_as_uint(ra[g].w));
+      (void)blend_one<PX, AUX>(s, k, ok[g][k], alpha[g][k], rc[g], __float_as_uint(ra[g].w));
   }
   return true;
 }
@@ -243,20 +284,17 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
 // Heavy path (1 pixel per lane): survivors are stored in PAIRS so that two splats are evaluated
 // per packed instruction.  LDS block of a pair (PAIR_F4 = 6 float4, same 48 B per splat):
 //   [0] gx0 gx1 gy0 gy1   [1] A0 A1 B0 B1   [2] C0 C1 op0 op1
-//   [3] r0 g0 b0 depth0   [4] r1 g1 b1 depth1   [5] pos0 pos1 id0 id1 (ids: semantic frames only)
+//   [3] r0 g0 b0 depth0   [4] r1 g1 b1 depth1   [5] pos0 pos1 - -
 constexpr int PAIR_F4 = 2 * REC_F4;
 
-template <bool WITH_ID = false>
 __device__ __forceinline__ void store_pair_half(float4* __restrict__ my, const int slot,
                                                 const float gx, const float gy, const SplatQ q,
-                                                const float op, const float4 col,
-                                                const uint32_t pos, const uint32_t id = 0u) {
+                                                const float op, const float4 col, const uint32_t pos) {
   float4* blk = my + (slot >> 1) * PAIR_F4;
   float* f = reinterpret_cast<float*>(blk) + (slot & 1);
   f[0] = gx; f[2] = gy; f[4] = q.A; f[6] = q.B; f[8] = q.C; f[10] = op;
   blk[3 + (slot & 1)] = col;
   f[20] = __uint_as_float(pos);
-  if (WITH_ID) f[22] = __uint_as_float(id);
 }
 
 // The accept half of a quad: alpha and the lanes that take the splat, for the four slots of blk
@@ -310,26 +348,27 @@ struct QuadColsReg {
 template <bool AUX, int NSEM, class Cols>
 __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
                                                 const float (&alpha)[4], const uint64_t (&ok)[4],
-                                                SemAcc<NSEM>* sa, const SemSrc sem);
+                                                SemAcc<NSEM>* sa, const SemSrc sem, const int j0, const int lane);
 
 // Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
 template <bool AUX = true, int NSEM = 0>
 __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
                                            const int j0, const float pxf, const float pyf,
-                                           SemAcc<NSEM>* sa = nullptr, const SemSrc sem = SemSrc{nullptr, 0}) {
+                                           SemAcc<NSEM>* sa = nullptr, const SemSrc sem = SemSrc{nullptr, 0, nullptr},
+                                           const int lane = 0) {
   const float4* blk = my + (j0 >> 1) * PAIR_F4;
   float alpha[4];
   uint64_t ok[4];
   QuadGeom g;
   g.load(blk);
   eval_quad(g, pxf, pyf, alpha, ok);
-  return blend_quad_tail<AUX, NSEM>(s, QuadColsLds{blk}, alpha, ok, sa, sem);
+  return blend_quad_tail<AUX, NSEM>(s, QuadColsLds{blk}, alpha, ok, sa, sem, j0, lane);
 }
 
 template <bool AUX, int NSEM, class Cols>
 __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
                                                 const float (&alpha)[4], const uint64_t (&ok)[4],
-                                                SemAcc<NSEM>* sa, const SemSrc sem) {
+                                                SemAcc<NSEM>* sa, const SemSrc sem, const int j0, const int lane) {
   const uint64_t live = ~s.done[0];
   if (((ok[0] | ok[1] | ok[2] | ok[3]) & live) == 0ull) return false;
   // The transmittance chain of the four splats first, with alpha = 0 in the lanes that reject a
@@ -362,23 +401,19 @@ __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
         s.last[0] = in_mask(ok[2 * h] & live) ? __float_as_uint(pp.x) : s.last[0];
         s.last[0] = in_mask(ok[2 * h + 1] & live) ? __float_as_uint(pp.y) : s.last[0];
       }
-      if (NSEM > 0) {   // the same weights feed the semantic planes, in list order
-        const float4 pp = cols.pp(h);
-        sem_accumulate<NSEM>(*sa, sem, __float_as_uint(pp.z), w[2 * h]);
-        sem_accumulate<NSEM>(*sa, sem, __float_as_uint(pp.w), w[2 * h + 1]);
-      }
     }
     s.T[0] = T;
+    if (NSEM > 0) sem_quad<NSEM>(*sa, w, sem.rows, j0, lane);   // the same weights feed the semantic planes
     return true;
   }
 #pragma unroll
   for (int h = 0; h < 2; h++) {   // some pixel terminates in this quad: the exact per-splat blend
-    const float4 c0 = cols.c0(h), c1 = cols.c1(h), pp = cols.pp(h);
-    blend_one<1, AUX, NSEM>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x), sa, sem,
-                            __float_as_uint(pp.z));
-    blend_one<1, AUX, NSEM>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y), sa, sem,
-                            __float_as_uint(pp.w));
+    const float4 c0 = cols.c0(h), c1 = cols.c1(h);
+    const float4 pp = AUX ? cols.pp(h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[2 * h + 0] = blend_one<1, AUX>(s, 0, ok[2 * h + 0], alpha[2 * h + 0], c0, __float_as_uint(pp.x));
+    w[2 * h + 1] = blend_one<1, AUX>(s, 0, ok[2 * h + 1], alpha[2 * h + 1], c1, __float_as_uint(pp.y));
   }
+  if (NSEM > 0) sem_quad<NSEM>(*sa, w, sem.rows, j0, lane);
   return true;
 }
 
@@ -590,13 +625,24 @@ __device__ __forceinline__ void ckpt_publish_items(const CkptArgs& ck, const int
     if (base + k < ck.slots) items[base + k] = make_uint2(tile, k);
 }
 
-// writes the wave's semantic accumulators (channels < min(S, NSEM)); semantics get no background
+// Writes the wave's semantic accumulators (channels < min(S, NSEM)); semantics get no background.  The
+// MFMA accumulators hold, per pixel row y, columns 4 (lane / 16) + i of channel lane % 16: they go through
+// LDS ([channel][pixel of the quarter]; two areas of 8 channels: the wave's dead ring) so that the planes
+// are written by pixel, 64 bytes per row and channel.  inside: this lane's pixel lies in the image.
 template <int NSEM>
 __device__ __forceinline__ void sem_write(const SemAcc<NSEM>& sa, const int S, float* __restrict__ out_semantic,
-                                          const size_t HW, const size_t pix) {
+                                          const size_t HW, const size_t pix, const bool inside, const int lane,
+                                          float* __restrict__ t_lo, float* __restrict__ t_hi) {
+  const int ch = lane & 15, xg = lane >> 4;
+  float* t = (ch < 8 ? t_lo : t_hi) + (ch & 7) * WAVE;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+    *reinterpret_cast<float4*>(t + y * 16 + 4 * xg) = make_float4(sa.acc[y].x, sa.acc[y].y, sa.acc[y].z, sa.acc[y].w);
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int c = 0; c < NSEM; c++)
-    if (c < S) out_semantic[(size_t)c * HW + pix] = sa.v[c];
+    if (c < S && inside) out_semantic[(size_t)c * HW + pix] = (c < 8 ? t_lo : t_hi)[(c & 7) * WAVE + lane];
 }
 
 template <bool TRACE, bool AUX = true, int NSEM = 0>
@@ -612,11 +658,12 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                                             float* __restrict__ out_depth,
                                             float* __restrict__ out_alpha,
                                             uint32_t* __restrict__ n_contrib, WaveTrace* tr,
-                                            CkptWriter ckw, const SemSrc sem = SemSrc{nullptr, 0},
-                                            float* __restrict__ out_semantic = nullptr) {
+                                            CkptWriter ckw, const SemSrc sem = SemSrc{nullptr, 0, nullptr},
+                                            float* __restrict__ out_semantic = nullptr,
+                                            float* __restrict__ semrows = nullptr /* LDS: WAVE x SEM_ROW */) {
   SemAcc<NSEM> sa;
-#pragma unroll
-  for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
+  sa.clear();
+  const SemSrc semb = {sem.semantics, sem.S, semrows};
   const int px = x0 + (lane & 15);
   const int py = y0 + (lane >> 4);
   const float pxf = (float)px;
@@ -701,19 +748,22 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                         !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
       const uint64_t mask = __ballot(keep);
       const int cnt = (int)__popcll(mask);
-      if (keep)
-        store_pair_half<(NSEM > 0)>(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
-                                    make_float4(b.w, c.x, c.y, a.z), pos, idc);
+      if (keep) {
+        store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                        make_float4(b.w, c.x, c.y, a.z), pos);
+        if (NSEM > 0) sem_stage(semrows, (int)__popcll(mask & lt), sem.semantics, sem.S, idc, true);
+      }
       if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
         const SplatQ zq = {0.f, 0.f, 0.f};
-        store_pair_half<(NSEM > 0)>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
+        store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+        if (NSEM > 0) sem_stage(semrows, cnt + lane, sem.semantics, sem.S, 0u, false);
       }
       if (TRACE) tr->survivors += (uint32_t)cnt;
       __builtin_amdgcn_wave_barrier();
       const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
       if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
       for (int j0 = 0; j0 < cnt; j0 += 4) {
-        const bool blended = blend_quad<AUX, NSEM>(st, my, j0, pxf, (float)py, &sa, sem);
+        const bool blended = blend_quad<AUX, NSEM>(st, my, j0, pxf, (float)py, &sa, semb, lane);
         if (TRACE && blended) tr->blends++;
       }
       if (TRACE) {
@@ -742,8 +792,10 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     out_alpha[pix] = 1.0f - st.T[0];
     out_depth[pix] = st.CbD[0].y;
     if (AUX) n_contrib[pix] = st.last[0];
-    if (NSEM > 0) sem_write<NSEM>(sa, sem.S, out_semantic, HW, pix);
   }
+  if (NSEM > 0)   // (all lanes: the accumulators are spread over the wave; the ring is dead by now)
+    sem_write<NSEM>(sa, sem.S, out_semantic, HW, (size_t)py * W + px, px < W && py < H, lane,
+                    reinterpret_cast<float*>(qid), reinterpret_cast<float*>(qpos));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -912,14 +964,17 @@ __device__ __forceinline__ bool pc_wait(PCCtrl* __restrict__ ctl, const PCErr er
 // per iteration and publishes them as ONE batch when their survivors fit a buffer, the consumer keeps a
 // quad's geometry one quad ahead in registers and requests its colours before the accept arithmetic,
 // and the live box comes from the lane mask's bits (mask_box).
-template <bool WITH_ID = false>
+template <bool WITH_SEM = false>
 __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
                                             uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
                                             PCCtrl* __restrict__ ctl, const int lane,
                                             const int quarter, const uint32_t r_begin,
                                             const uint32_t r_end,
                                             const uint32_t* __restrict__ point_list,
-                                            const RecView rec, const PCErr err, WaveTrace* tr = nullptr) {
+                                            const RecView rec, const PCErr err, WaveTrace* tr = nullptr,
+                                            const SemSrc sem = SemSrc{nullptr, 0, nullptr},
+                                            float* __restrict__ semrows0 = nullptr /* LDS rows of buf0 / buf1 */,
+                                            float* __restrict__ semrows1 = nullptr) {
   const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
   const uint64_t lt = lanemask_lt();
   uint32_t head = 0, count = 0;
@@ -931,15 +986,18 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   // the survivors `keep` of one gathered half, compacted behind `base` entries already in buffer `my`
   const auto put = [&](float4* __restrict__ my, const bool keep, const uint64_t mask, const int base,
                        const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc) {
-    if (keep)
-      store_pair_half<WITH_ID>(my, base + (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
-                               make_float4(b.w, c.x, c.y, a.z), pos, idc);
+    if (keep) {
+      store_pair_half(my, base + (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+                      make_float4(b.w, c.x, c.y, a.z), pos);
+      if (WITH_SEM) sem_stage(my == buf0 ? semrows0 : semrows1, base + (int)__popcll(mask & lt), sem.semantics, sem.S, idc, true);
+    }
   };
   // neutral pads up to a multiple of 4 (opacity 0), then the hand-over of cnt survivors in buffer `cur`
   const auto publish = [&](float4* __restrict__ my, const int cnt) {
     if (lane < ((4 - (cnt & 3)) & 3)) {
       const SplatQ zq = {0.f, 0.f, 0.f};
-      store_pair_half<WITH_ID>(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);
+      store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+      if (WITH_SEM) sem_stage(my == buf0 ? semrows0 : semrows1, cnt + lane, sem.semantics, sem.S, 0u, false);
     }
     if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
     pc_store(&ctl->flag[cur], (uint32_t)cnt + 1u);
@@ -1017,11 +1075,14 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             float* __restrict__ out_alpha,
                                             uint32_t* __restrict__ n_contrib, CkptWriter ckw,
                                             const uint32_t len, const PCErr err,
-                                            const SemSrc sem = SemSrc{nullptr, 0},
-                                            float* __restrict__ out_semantic = nullptr, WaveTrace* tr = nullptr) {
+                                            const SemSrc sem = SemSrc{nullptr, 0, nullptr},
+                                            float* __restrict__ out_semantic = nullptr, WaveTrace* tr = nullptr,
+                                            const float* __restrict__ semrows0 = nullptr,
+                                            const float* __restrict__ semrows1 = nullptr,
+                                            float* __restrict__ t_lo = nullptr /* LDS: 8 x WAVE floats each, for the */,
+                                            float* __restrict__ t_hi = nullptr /* final transpose (this wave's idle ring) */) {
   SemAcc<NSEM> sa;
-#pragma unroll
-  for (int c = 0; c < (NSEM > 0 ? NSEM : 1); c++) sa.v[c] = 0.f;
+  sa.clear();
   const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
   const float pxf = (float)px, pyf = (float)py;
   WavePix<1> st;
@@ -1038,10 +1099,11 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     const int cnt = (int)(f - 1u);
     if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
     const float4* my = cur ? buf1 : buf0;
+    const SemSrc semb = {sem.semantics, sem.S, cur ? semrows1 : semrows0};
     // A quad's geometry block waits in registers one quad ahead, its colour / position blocks are
     // requested before the accept arithmetic: the wave has its SIMD to itself at the end of the
     // launch, and every LDS round trip it waits for (three per quad until round 5) is the launch's.
-    constexpr bool PP = AUX || NSEM > 0;
+    constexpr bool PP = AUX;
     QuadGeom g_n;
     g_n.load(my);
     for (int j0 = 0; j0 < cnt; j0 += 4) {
@@ -1053,7 +1115,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
       float alpha[4];
       uint64_t ok[4];
       eval_quad(g, pxf, pyf, alpha, ok);
-      blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, &sa, sem);
+      blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, &sa, semb, j0, lane);
     }
     if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
       const float* blk = reinterpret_cast<const float*>(my + ((cnt - 1) >> 1) * PAIR_F4);
@@ -1084,21 +1146,23 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     out_alpha[pix] = 1.0f - st.T[0];
     out_depth[pix] = st.CbD[0].y;
     if (AUX) n_contrib[pix] = st.last[0];
-    if (NSEM > 0) sem_write<NSEM>(sa, sem.S, out_semantic, HW, pix);
   }
+  if (NSEM > 0)
+    sem_write<NSEM>(sa, sem.S, out_semantic, HW, (size_t)py * W + px, px < W && py < H, lane, t_lo, t_hi);
 }
 
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
 // 112 KB of LDS per CU so that the other stream's sort workgroups can co-reside) measured slightly
 // ahead of 5 (96 VGPRs, 136 B of scratch per lane): 0.327 vs 0.333 ms, 1640 vs 1600 frames/s.
-// A frame with semantic planes (NSEM > 0) carries NSEM more accumulators per lane: 2 waves per SIMD.
+// A frame with semantic planes (NSEM > 0) carries 16 accumulator registers per lane (MFMA) and 4 KB of
+// staged rows per wave: 3 waves per SIMD / 3 workgroups per CU.
 constexpr int RENDER_MIN_WAVES = 4;
 
 // Measured and removed: XCD-contiguous work assignment (0.248 vs 0.232 ms:
 // neighbouring tiles are similarly long, contiguous eighths unbalance the XCDs), occupancy capped
 // with unused LDS, one splat per iteration in the light path, persistent waves.
 template <bool WRITE_AUX, int GPI_L, bool TRACE = false, int NSEM = 0>
-__global__ void __launch_bounds__(256, NSEM > 0 ? 2 : RENDER_MIN_WAVES)
+__global__ void __launch_bounds__(256, NSEM > 0 ? 3 : RENDER_MIN_WAVES)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RecView rec, const int W, const int H, const int gx,
                       const uint32_t T, const uint32_t* __restrict__ work,
@@ -1112,6 +1176,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
   __shared__ PCCtrl s_ctl[2];
+  // staged semantic rows of the batch being blended: per heavy wave, or per batch buffer of the pairs
+  __shared__ float s_sem[NSEM > 0 ? RW_WAVES : 1][NSEM > 0 ? WAVE * SEM_ROW : 4];
 #ifdef GRPG_RENDER_LDS_PAD   // experiment build: unused LDS that caps the workgroups per CU
   __shared__ uint32_t s_pad[GRPG_RENDER_LDS_PAD / 4];
   if (W < 0) s_pad[threadIdx.x] = (uint32_t)H;   // never true: keeps the array allocated
@@ -1156,11 +1222,12 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     if (wave < 2) {
       pc_consumer<WRITE_AUX, NSEM>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
                   out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err, sem,
-                  out_semantic, trp);
+                  out_semantic, trp, s_sem[NSEM > 0 ? slot : 0], s_sem[NSEM > 0 ? slot + 2 : 0],
+                  reinterpret_cast<float*>(s_qid[wave]), reinterpret_cast<float*>(s_qpos[wave]));
       if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
     } else
       pc_producer<(NSEM > 0)>(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q,
-                  rb, re, point_list, rec, pc_err, trp);
+                  rb, re, point_list, rec, pc_err, trp, sem, s_sem[NSEM > 0 ? slot : 0], s_sem[NSEM > 0 ? slot + 2 : 0]);
     if (TRACE && lane == 0) {   // class-0 roles: waves 0, 1 consumers, 2, 3 producers
       // [0] tile | 0x40000000  [1] list length  [2] batches  [3] survivors  [4] waits
       // [5] wave life (wall clock ticks)  [6] start  [7] wave | waiting cycles / 256 << 4
@@ -1189,7 +1256,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     tr_tile = tile; tr_len = re - rb;
     blend_heavy<TRACE, WRITE_AUX, NSEM>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
                        ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
-                       out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re), sem, out_semantic);
+                       out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re), sem, out_semantic,
+                       s_sem[NSEM > 0 ? wave : 0]);
     if (WRITE_AUX && wave == 0) ckpt_publish_items(ck, lane, tile, re - rb);
   } else {
     if (b >= nlwg) return;
@@ -1330,7 +1398,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   // classified: the hierarchical binning's tile scan has already built the work lists
   if (!classified)
     classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, cls, work);
-  const SemSrc sem = {semantics, S};
+  const SemSrc sem = {semantics, S, nullptr};
   // nheavy + ceil(nlight/4) <= ntiles: launch the upper bound, surplus workgroups exit at once
   // aux == false (no backward will follow): n_contrib is neither tracked nor written
 #define RF_ARGS ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, \
