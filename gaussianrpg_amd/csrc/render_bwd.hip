@@ -140,6 +140,10 @@ __device__ __forceinline__ float wave_fold_12(const float (&v)[12], const bool l
   return t;
 }
 
+// Round 5 tried the matrix pipe for these totals (one v_mfma_f32_16x16x4_f32 per quantity with a one-hot B
+// column, 3 adds and two row exchanges behind them: 11 adjacent lanes hold the totals) -- parity-green and
+// 40 % SLOWER (backward 0.91 vs 0.66 ms): eleven dependent 8-pass MFMAs per (wave, splat) are 352 cycles of
+// the one matrix pipe four waves share, more than the trip's vector work.  DESIGN_EXPERIMENTS.md.
 constexpr int BREC = 4;   // float4 per compacted survivor in LDS: record (3) + pre-scaled conic
 
 // One wave, PX pixels per lane: rows y0 + (lane>>4)*PX + k.  bits_mask selects the sub-tile bits
@@ -324,23 +328,23 @@ __device__ __forceinline__ void backward_rect(
         prev_act[k] = act;
       }
       if (changed) {
-        float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+        // from the bits of the lane masks, on the scalar unit (render_fwd.hip mask_box: the butterfly over
+        // four floats per lane this replaces cost 24 ds_bpermute round trips + 24 min / max per update, and
+        // the active set changes at almost every batch); rows y0 + PX (lane >> 4) + k
+        int c0 = 15, c1 = 0, r0 = 4 * PX, r1 = -1;
 #pragma unroll
         for (int k = 0; k < PX; k++) {
-          if (lastc[k] > pos_min) {
-            bx0 = pxf; bx1 = pxf;
-            by0 = fminf(by0, (float)(py0 + k));
-            by1 = fmaxf(by1, (float)(py0 + k));
+          const uint64_t m = prev_act[k];
+          if (m != 0ull) {
+            const int ra = (int)(__builtin_ctzll(m) >> 4), rb = (int)((63 - __builtin_clzll(m)) >> 4);
+            uint32_t cols = (uint32_t)m | (uint32_t)(m >> 32);
+            cols = (cols | (cols >> 16)) & 0xFFFFu;
+            c0 = min(c0, (int)__builtin_ctz(cols)); c1 = max(c1, 31 - (int)__builtin_clz(cols));
+            r0 = min(r0, PX * ra + k); r1 = max(r1, PX * rb + k);
           }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-          bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
-          bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
-          by0 = fminf(by0, __shfl_xor(by0, d, 64));
-          by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
-        }
-        rx0 = bx0; rx1 = bx1; ry0 = by0; ry1 = by1;
+        // no active pixel at all: an empty box (every splat misses it)
+        rx0 = (float)(x0 + c0); rx1 = (float)(x0 + c1); ry0 = (float)(y0 + r0); ry1 = (float)(y0 + r1);
       }
       const bool keep = ((uint32_t)lane < ncur) &&
                         !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);
