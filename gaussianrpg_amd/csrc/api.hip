@@ -529,6 +529,13 @@ BwdStagingSlot* bwd_staging_acquire() {
   return &b;
 }
 
+// grpg_forward_layers: the class of every Gaussian and the two extra plane pairs
+struct LayerArgs {
+  const unsigned char* layer_class;
+  const float* layer_background;
+  float* out_color_bg; float* out_alpha_bg; float* out_color_obj; float* out_alpha_obj;
+};
+
 // Shared body of grpg_forward (segs == NULL: flat input tensors) and grpg_forward_composed (segs:
 // per-model raw parameters, P = sum of their counts, the flat pointers are NULL).
 int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
@@ -541,7 +548,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                  float tan_fovx, float tan_fovy, float* out_color,
                  float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
                  void* hip_stream, const grpg_model_segment* segs, int nseg, unsigned flags = 0u,
-                 DeferSlot* defer = nullptr, bool force_pass3 = false) {
+                 DeferSlot* defer = nullptr, bool force_pass3 = false, const LayerArgs* layers = nullptr) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
@@ -622,6 +629,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // a training forward leaves blend checkpoints of its long tile lists behind the binning blob
     // (common.h CK_*; the backward starts its segments from them)
     const bool with_ckpt = (flags & GRPG_FORWARD_NO_BACKWARD) == 0u && S == 0;
+    // work-list classes of the frame's render (a layered frame: quarter waves for every non-empty tile)
+    const TileClasses frame_classes = layers ? tile_classes_layers() : tile_classes(S);
     auto blob_bytes = [&](const BinLayout& L, uint32_t cap) {
       return L.total + (with_ckpt ? ckpt_bytes(ckpt_slots(cap)) : 0);
     };
@@ -744,8 +753,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       const CkptArgs ck = {(float*)(binp + L.total), (uint32_t*)(img + IL.ck_count),
                            (uint32_t*)(img + IL.bwd_ctl), (BlobHeader*)binp,
                            (uint32_t)(L.total / 256), ckpt_slots(cap)};
+      if (layers)
+        launch_render_layers(stream, ranges, const_cast<uint32_t*>(point_list), rec, width, height, cam.gx, cam.gy,
+                             background, out_color, out_depth, out_alpha, work, frame_classes, &gh->R, cap,
+                             classified, layers->layer_class, layers->layer_background, layers->out_color_bg,
+                             layers->out_alpha_bg, layers->out_color_obj, layers->out_alpha_obj);
+      else
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
-                            out_color, out_depth, out_alpha, n_contrib, work, tile_classes(S), cap,
+                            out_color, out_depth, out_alpha, n_contrib, work, frame_classes, cap,
                             (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified,
                             with_ckpt ? &ck : nullptr,
                             PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3},
@@ -845,7 +860,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                         (uint32_t*)(binp + L.nseg), L.max_seg, ckey, cam.gx, cam.gy,
                         (uint32_t*)(binp + L.seg_table), (uint32_t*)(binp + L.tile_tot),
                         (uint32_t*)(binp + L.tile_start), ranges, &gh->R, nullptr,
-                        &gh->Rc, (BlobHeader*)binp, cap, ccap, work, tile_classes(S));
+                        &gh->Rc, (BlobHeader*)binp, cap, ccap, work, frame_classes);
       STAGE_CHECK("tile counts");
       launch_hier_fill(stream, binp + L.seg_desc, (const uint32_t*)(binp + L.nseg), L.max_seg, ckey, cval, rec,
                        cam.gx, cam.gy, (const uint32_t*)(binp + L.seg_table),
@@ -931,6 +946,12 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipMemsetAsync(out_alpha, 0, N * 4, stream));
     if (S > 0 && out_semantic) HIP_TRY(hipMemsetAsync(out_semantic, 0, (size_t)S * N * 4, stream));
     HIP_TRY(hipMemsetAsync(n_contrib, 0, N * 4, stream));
+    if (layers) {   // like the other planes of an empty call: zeros
+      HIP_TRY(hipMemsetAsync(layers->out_color_bg, 0, 3 * N * 4, stream));
+      HIP_TRY(hipMemsetAsync(layers->out_alpha_bg, 0, N * 4, stream));
+      HIP_TRY(hipMemsetAsync(layers->out_color_obj, 0, 3 * N * 4, stream));
+      HIP_TRY(hipMemsetAsync(layers->out_alpha_obj, 0, N * 4, stream));
+    }
     char* bin = binning_alloc(bin_layout(0).total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");
     launch_frame_init(stream, geom, bin, img, 0u, 0u, 0u, (uint32_t)width, (uint32_t)height,
@@ -1046,6 +1067,30 @@ int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_a
                       semantics, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                       viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth,
                       out_alpha, out_semantic, radii, debug, hip_stream, nullptr, 0, flags);
+}
+
+int grpg_forward_layers(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                        void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D,
+                        const float* shs, const float* colors_precomp, const float* opacities,
+                        const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy,
+                        const unsigned char* layer_class, const float* layer_background, float* out_color,
+                        float* out_depth, float* out_alpha, float* out_color_bg, float* out_alpha_bg,
+                        float* out_color_obj, float* out_alpha_obj, int* radii, int debug, void* hip_stream) {
+  g_last_error.clear();
+  if (!layer_background || !out_color_bg || !out_alpha_bg || !out_color_obj || !out_alpha_obj)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL layer background / layer plane pointer");
+  if (P > 0 && !layer_class) return fail(GRPG_ERR_INVALID_ARGUMENT, "layer_class NULL");
+  if ((unsigned)P >= (1u << 27))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs P < 2^27 (the class travels in bit 27 of the point list)");
+  const LayerArgs la = {layer_class, layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D,
+                      M, 0, background, width, height, means3D, shs, colors_precomp, nullptr, opacities, scales,
+                      scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                      tan_fovy, out_color, out_depth, out_alpha, nullptr, radii, debug, hip_stream, nullptr, 0,
+                      GRPG_FORWARD_NO_BACKWARD, nullptr, false, &la);
 }
 
 int grpg_forward_deferred(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,

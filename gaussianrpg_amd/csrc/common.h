@@ -319,6 +319,8 @@ struct TileClasses { uint32_t c0_min, c1_min, heavy_min; };
 inline TileClasses tile_classes(int S) {
   return TileClasses{RENDER_PC_MIN, RENDER_C1_MIN, S > 0 ? 1u : RENDER_HEAVY_MIN};
 }
+// a LAYERED frame (grpg_forward_layers): every non-empty tile down the quarter-wave path, no wave pairs
+inline TileClasses tile_classes_layers() { return TileClasses{0xFFFFFFFFu, RENDER_C1_MIN, 1u}; }
 __host__ __device__ inline int tile_class(const uint32_t len, const TileClasses tc) {
   return len >= tc.c0_min ? 0 : (len >= tc.c1_min ? 1 : (len >= tc.heavy_min ? 2 : 3));
 }
@@ -451,6 +453,14 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const PCErr pc_err, const float* semantics /* [P][S] or NULL */, int S,
                            float* out_semantic /* the first min(S, RENDER_NSEM) planes are written here */);
 uint32_t render_pc_slots(uint32_t R);   // render_fwd.hip
+// one walk, three blend states: the composition + the background-only and objects-only planes
+// (grpg_forward_layers); marks the class of every point-list entry first (bit 27)
+void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_list, const RecView rec, int W, int H,
+                          int gx, int gy, const float* bg, float* out_color, float* out_depth, float* out_alpha,
+                          uint32_t* work, TileClasses cls, const uint32_t* R_dev, uint32_t cap, bool classified,
+                          const unsigned char* layer_class /* [P]: 0 background, 1 object */,
+                          const float* layer_background /* [3] */, float* out_color_bg, float* out_alpha_bg,
+                          float* out_color_obj, float* out_alpha_obj);
 // channels [c_begin, S) of the semantic planes (stand-alone kernel)
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const RecView rec, const float* semantics, int S, int c_begin, int W, int H,

@@ -160,7 +160,7 @@ __device__ __forceinline__ void sem_stage(float* __restrict__ rows, const int sl
 template <int NSEM>
 __device__ __forceinline__ void sem_quad(SemAcc<NSEM>& sa, const float (&w)[4], const float* __restrict__ rows,
                                          const int j0, const int lane) {
-  if (NSEM == 0) return;
+  if constexpr (NSEM > 0) {
   const float b = rows[j0 * SEM_ROW + lane];
   const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[0]), __float_as_uint(w[2]), false, false);
   const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[1]), __float_as_uint(w[3]), false, false);
@@ -170,6 +170,7 @@ __device__ __forceinline__ void sem_quad(SemAcc<NSEM>& sa, const float (&w)[4], 
   sa.acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t01[1]), b, sa.acc[1], 0, 0, 0);
   sa.acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t23[0]), b, sa.acc[2], 0, 0, 0);
   sa.acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t23[1]), b, sa.acc[3], 0, 0, 0);
+  }
 }
 
 // In-order blend of one splat into pixel k (forward.cu:425-440); ok_m = lanes that accept it.
@@ -1293,6 +1294,266 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     uint32_t* o2 = trace + (size_t)gridDim.x * RW_WAVES * 9 + ((size_t)blockIdx.x * RW_WAVES + wave) * 8;
     for (int i = 0; i < 4; i++) { o2[i] = tr.it[i]; o2[4 + i] = tr.cyc[i]; }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// LAYERED frames (round 5, additive: grpg_forward_layers).  The reference's evaluation path renders every
+// frame three times -- all models, the background model alone, the object models alone
+// (lib/models/street_gaussian_renderer.py:13-40: render_all) -- i.e. three preprocess + binning chains
+// and three walks for what is ONE list walk with three blend states: a (pixel, splat) pair has one alpha;
+// the composition takes every splat, a layer the splats of its class.  A layer's transmittance chain sees
+// alpha = 0 for the other class (T x 1, C + c x 0: exact no-ops), so each plane carries the very bits
+// the op returns for that subset of the scene.
+//   * every entry of the point list carries its Gaussian's class in bit 27 (layer_mark_kernel; ids < 2^27);
+//   * all non-empty tiles take the quarter-wave path (one pixel per lane has the registers for three
+//     states; no producer / consumer pairs: the longest tiles are plain heavy waves here);
+//   * a pixel is finished when all three states are: where no object ever saturates the walk goes on to
+//     the end of the list -- but once the composition and the background are through, FILL keeps OBJECT
+//     entries only (a dead entry costs 1/256 of a FILL step), and the cull box of the non-object
+//     entries is that of the pixels still live in the composition or the background.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t LAYER_BIT = 1u << 27;
+constexpr uint32_t LAYER_ID_MASK = LAYER_BIT - 1u;
+
+__global__ void __launch_bounds__(256)
+layer_mark_kernel(uint32_t* __restrict__ point_list, const uint32_t* __restrict__ R_dev, const uint32_t cap,
+                  const uint8_t* __restrict__ layer_class) {
+  const uint32_t n = min(*R_dev, cap);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t v = point_list[i];
+    if (layer_class[v & LAYER_ID_MASK] != 0) point_list[i] = v | LAYER_BIT;
+  }
+}
+
+struct LayerOut {
+  const float* bg_layer;     // [3] background of the two layer planes (the reference renders them on white)
+  float* color_bg; float* alpha_bg; float* color_obj; float* alpha_obj;
+};
+
+// one quad into the three states: alpha once, then the blend half per state with its own accept masks
+__device__ __forceinline__ void blend_quad_layers(WavePix<1>& sa, WavePix<1>& sb, WavePix<1>& so,
+                                                  const float4* __restrict__ my, const int j0,
+                                                  const float pxf, const float pyf, const int lane) {
+  const float4* blk = my + (j0 >> 1) * PAIR_F4;
+  QuadGeom g;
+  g.load(blk);
+  QuadColsReg<false> cols;
+  cols.load(blk);
+  const float4 p0 = blk[5], p1 = blk[PAIR_F4 + 5];
+  float alpha[4];
+  uint64_t ok[4];
+  eval_quad(g, pxf, pyf, alpha, ok);
+  const uint32_t cls[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.z)),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.w)),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.z)),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.w))};
+  uint64_t okb[4], oko[4];
+  uint64_t anyb = 0ull, anyo = 0ull;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint64_t m = cls[i] ? ~0ull : 0ull;   // the slot's class, as a lane mask (wave-uniform)
+    okb[i] = ok[i] & ~m; oko[i] = ok[i] & m;
+    anyb |= okb[i]; anyo |= oko[i];
+  }
+  const SemSrc nosem = {nullptr, 0, nullptr};
+  SemAcc<0>* nosa = nullptr;
+  blend_quad_tail<false, 0>(sa, cols, alpha, ok, nosa, nosem, j0, lane);
+  if (anyb & ~sb.done[0]) blend_quad_tail<false, 0>(sb, cols, alpha, okb, nosa, nosem, j0, lane);
+  if (anyo & ~so.done[0]) blend_quad_tail<false, 0>(so, cols, alpha, oko, nosa, nosem, j0, lane);
+}
+
+__device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint32_t* __restrict__ qid,
+                                                   uint32_t* __restrict__ qpos, const int lane, const int quarter,
+                                                   const uint32_t r_begin, const uint32_t r_end, const int x0,
+                                                   const int y0, const int W, const int H,
+                                                   const uint32_t* __restrict__ point_list, const RecView rec,
+                                                   const float* __restrict__ bg, float* __restrict__ out_color,
+                                                   float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                   const LayerOut lo) {
+  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
+  const float pxf = (float)px;
+  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
+  const uint64_t lt = lanemask_lt();
+  WavePix<1> sa, sb, so;
+  const uint64_t outside = lanes(!(px < W && py < H));
+  sa.T[0] = 1.0f; sa.CrCg[0] = (v2f){0.f, 0.f}; sa.CbD[0] = (v2f){0.f, 0.f}; sa.last[0] = 0; sa.done[0] = outside;
+  sb = sa; so = sa;
+  // cull boxes: non-object entries against the pixels live in the composition or the background,
+  // object entries against those live in any state
+  float ax0 = (float)x0, ax1 = (float)(x0 + 15), ay0 = (float)y0, ay1 = (float)(y0 + 3);
+  float ox0 = ax0, ox1 = ax1, oy0 = ay0, oy1 = ay1;
+  uint64_t prev_ab = ~0ull, prev_all = ~0ull;
+
+  uint32_t in_pos = r_begin, head = 0, count = 0;
+  uint32_t win[FILL_Q];
+#pragma unroll
+  for (int q = 0; q < FILL_Q; q++) {
+    const uint32_t i = in_pos + q * WAVE + lane;
+    win[q] = i < r_end ? point_list[i] : 0u;
+  }
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+  uint32_t pos = 0, idc = 0, ncur = 0;
+
+  for (;;) {
+    const uint64_t live_ab = ~(sa.done[0] & sb.done[0]);
+    const uint64_t live_all = live_ab | ~so.done[0];
+    if (live_all == 0ull) break;
+    const bool need_ab = live_ab != 0ull;   // wave-uniform: the composition or the background still blends
+    if (live_ab != prev_ab && need_ab) {
+      prev_ab = live_ab;
+      const MaskBox m = mask_box(live_ab);
+      ax0 = (float)(x0 + m.c0); ax1 = (float)(x0 + m.c1); ay0 = (float)(y0 + m.r0); ay1 = (float)(y0 + m.r1);
+    }
+    if (live_all != prev_all) {
+      prev_all = live_all;
+      const MaskBox m = mask_box(live_all);
+      ox0 = (float)(x0 + m.c0); ox1 = (float)(x0 + m.c1); oy0 = (float)(y0 + m.r0); oy1 = (float)(y0 + m.r1);
+    }
+    // ---- FILL ----
+    while (count < (uint32_t)WAVE && in_pos < r_end) {
+      uint32_t v[FILL_Q];
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
+      const uint32_t nxt = in_pos + FILL_Q * WAVE;
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = nxt + q * WAVE + lane;
+        win[q] = i < r_end ? point_list[i] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < FILL_Q; q++) {
+        const uint32_t i = in_pos + q * WAVE + lane;
+        const bool keep = (i < r_end) && (v[q] & bit) && (need_ab || (v[q] & LAYER_BIT));
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
+          qid[slot] = v[q] & (LAYER_ID_MASK | LAYER_BIT);   // id + class
+          qpos[slot] = i - r_begin + 1;
+        }
+        count += (uint32_t)__popcll(m);
+      }
+      in_pos = nxt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- POP ----
+    const uint32_t nn = min(count, (uint32_t)WAVE);
+    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
+    uint32_t pos_n = 0, id_n = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (QCAP - 1);
+      id_n = qid[slot];
+      pos_n = qpos[slot];
+      rec.load(id_n & LAYER_ID_MASK, a_n, b_n, c_n);
+    }
+    head = (head + nn) & (QCAP - 1);
+    count -= nn;
+    // ---- BLEND the previous batch ----
+    if (ncur > 0) {
+      const bool is_obj = (idc & LAYER_BIT) != 0u;
+      const bool keep = ((uint32_t)lane < ncur) && (need_ab || is_obj) &&
+                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, is_obj ? ox0 : ax0, is_obj ? ox1 : ax1,
+                                           is_obj ? oy0 : ay0, is_obj ? oy1 : ay1);
+      const uint64_t mask = __ballot(keep);
+      const int cnt = (int)__popcll(mask);
+      if (keep) {
+        const int slot = (int)__popcll(mask & lt);
+        store_pair_half(my, slot, a.x, a.y, splat_q(b.x, b.y, b.z), a.w, make_float4(b.w, c.x, c.y, a.z), pos);
+        reinterpret_cast<uint32_t*>(my + (slot >> 1) * PAIR_F4)[22 + (slot & 1)] = is_obj ? 1u : 0u;
+      }
+      if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
+        const SplatQ zq = {0.f, 0.f, 0.f};
+        store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+        reinterpret_cast<uint32_t*>(my + ((cnt + lane) >> 1) * PAIR_F4)[22 + ((cnt + lane) & 1)] = 0u;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad_layers(sa, sb, so, my, j0, pxf, (float)py, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
+    if (ncur == 0 && in_pos >= r_end) break;
+  }
+  const size_t HW = (size_t)H * W;
+  if (px < W && py < H) {
+    const size_t pix = (size_t)py * W + px;
+    const float l0 = lo.bg_layer[0], l1 = lo.bg_layer[1], l2 = lo.bg_layer[2];
+    out_color[pix] = sa.CrCg[0].x + sa.T[0] * bg[0];
+    out_color[HW + pix] = sa.CrCg[0].y + sa.T[0] * bg[1];
+    out_color[2 * HW + pix] = sa.CbD[0].x + sa.T[0] * bg[2];
+    out_alpha[pix] = 1.0f - sa.T[0];
+    out_depth[pix] = sa.CbD[0].y;
+    lo.color_bg[pix] = sb.CrCg[0].x + sb.T[0] * l0;
+    lo.color_bg[HW + pix] = sb.CrCg[0].y + sb.T[0] * l1;
+    lo.color_bg[2 * HW + pix] = sb.CbD[0].x + sb.T[0] * l2;
+    lo.alpha_bg[pix] = 1.0f - sb.T[0];
+    lo.color_obj[pix] = so.CrCg[0].x + so.T[0] * l0;
+    lo.color_obj[HW + pix] = so.CrCg[0].y + so.T[0] * l1;
+    lo.color_obj[2 * HW + pix] = so.CbD[0].x + so.T[0] * l2;
+    lo.alpha_obj[pix] = 1.0f - so.T[0];
+  }
+}
+
+// work lists as built for tile_classes_layers(): class 0 empty, classes 1 / 2 = the non-empty tiles, class 3 =
+// the EMPTY tiles (their planes are the backgrounds)
+__global__ void __launch_bounds__(256, 3)
+render_layers_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const RecView rec,
+                     const int W, const int H, const int gx, const uint32_t T, const uint32_t* __restrict__ work,
+                     const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
+                     float* __restrict__ out_alpha, const LayerOut lo) {
+  __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
+  __shared__ uint32_t s_qid[RW_WAVES][QCAP];
+  __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nempty = work[3];
+  const uint32_t* lists = work + NUM_CLASSES;
+  const uint32_t nheavy = n0 + n1 + n2;
+  if (blockIdx.x < nheavy) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = b < n0 ? lists[b] : (b < n0 + n1 ? lists[T + (b - n0)] : lists[2 * T + (b - n0 - n1)]);
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+    const uint2 range = ranges[tile];
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
+    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    blend_heavy_layers(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE, ty * TILE + wave * 4, W,
+                       H, point_list, rec, bg, out_color, out_depth, out_alpha, lo);
+    return;
+  }
+  const uint32_t li = (blockIdx.x - nheavy) * RW_WAVES + (uint32_t)wave;
+  if (li >= nempty) return;
+  const uint32_t tile = lists[3 * (size_t)T + li];
+  const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
+  const int px = tx * TILE + (lane & 15), py0 = ty * TILE + (lane >> 4) * 4;
+  const size_t HW = (size_t)H * W;
+  for (int k = 0; k < 4; k++) {
+    if (px < W && py0 + k < H) {
+      const size_t pix = (size_t)(py0 + k) * W + px;
+      for (int ch = 0; ch < 3; ch++) {
+        out_color[ch * HW + pix] = bg[ch];
+        lo.color_bg[ch * HW + pix] = lo.bg_layer[ch];
+        lo.color_obj[ch * HW + pix] = lo.bg_layer[ch];
+      }
+      out_alpha[pix] = 0.f; out_depth[pix] = 0.f; lo.alpha_bg[pix] = 0.f; lo.alpha_obj[pix] = 0.f;
+    }
+  }
+}
+
+void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_list, const RecView rec, int W, int H,
+                          int gx, int gy, const float* bg, float* out_color, float* out_depth, float* out_alpha,
+                          uint32_t* work, const TileClasses cls, const uint32_t* R_dev, uint32_t cap, bool classified,
+                          const unsigned char* layer_class, const float* layer_background, float* out_color_bg,
+                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj) {
+  const int ntiles = gx * gy;
+  if (ntiles <= 0) return;
+  if (cap > 0) {
+    const size_t nb = ((size_t)cap + 255) / 256;
+    layer_mark_kernel<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, s>>>(point_list, R_dev, cap,
+                                                                        (const uint8_t*)layer_class);
+  }
+  if (!classified)
+    classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, cls, work);
+  const LayerOut lo = {layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
+  // non-empty tiles + ceil(empty / 4) <= ntiles workgroups; surplus ones exit at once
+  render_layers_kernel<<<ntiles, 256, 0, s>>>(ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg,
+                                              out_color, out_depth, out_alpha, lo);
 }
 
 // N-channel "semantic" planes (forward.cu:442-444): same traversal and the same accept/reject

@@ -167,6 +167,70 @@ auto RasterizeGaussiansEvalDeferred(GRPG_RASTERIZE_ARGS) {
   return std::make_tuple(ticket, std::get<1>(r), std::get<2>(r), std::get<3>(r), std::get<4>(r),
                          std::get<5>(r));
 }
+// Layered frame (additive; grpg_forward_layers): the composition + the background-only and objects-only
+// planes of StreetGaussianRenderer.render_all from one pass.  layer_class: uint8 / bool [P], != 0 = object.
+// returns (num_rendered, color, depth, alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj)
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor>
+RasterizeGaussiansLayers(const torch::Tensor& background, const torch::Tensor& layer_background,
+                         const torch::Tensor& layer_class, const torch::Tensor& means3D,
+                         const torch::Tensor& colors, const torch::Tensor& opacity, const torch::Tensor& scales,
+                         const torch::Tensor& rotations, const float scale_modifier,
+                         const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                         const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                         const int image_height, const int image_width, const torch::Tensor& sh,
+                         const int degree, const torch::Tensor& campos, const bool debug) {
+  if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
+  require_device(means3D);
+  TORCH_CHECK(means3D.scalar_type() == torch::kFloat32, "means3D must be float32");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+  const int P = means3D.size(0);
+  const int H = image_height, W = image_width;
+  TORCH_CHECK(layer_class.numel() == P && layer_class.device() == means3D.device() &&
+                  (layer_class.scalar_type() == torch::kUInt8 || layer_class.scalar_type() == torch::kBool),
+              "layer_class must be a uint8 / bool tensor of P elements on the device of means3D");
+  const torch::Tensor k_cls = layer_class.contiguous();
+  auto fo = means3D.options().dtype(torch::kFloat32);
+  torch::Tensor out_color = torch::empty({GRPG_NUM_CHANNELS, H, W}, fo), out_depth = torch::empty({1, H, W}, fo);
+  torch::Tensor out_alpha = torch::empty({1, H, W}, fo);
+  torch::Tensor color_bg = torch::empty({GRPG_NUM_CHANNELS, H, W}, fo), alpha_bg = torch::empty({1, H, W}, fo);
+  torch::Tensor color_obj = torch::empty({GRPG_NUM_CHANNELS, H, W}, fo), alpha_obj = torch::empty({1, H, W}, fo);
+  torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
+  auto byte_opts = means3D.options().dtype(torch::kByte);
+  torch::Tensor geomBuffer = torch::empty({0}, byte_opts), binningBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+  int M = 0;
+  if (sh.size(0) != 0) M = sh.size(1);
+  torch::Tensor k_bg, k_lbg, k_means, k_sh, k_col, k_op, k_sc, k_rot, k_cov, k_view, k_proj, k_cam;
+  const float* p_bg = fptr(background, means3D, "background", k_bg);
+  const float* p_lbg = fptr(layer_background, means3D, "layer_background", k_lbg);
+  const float* p_means = fptr(means3D, means3D, "means3D", k_means);
+  const float* p_sh = fptr(sh, means3D, "sh", k_sh);
+  const float* p_col = fptr(colors, means3D, "colors_precomp", k_col);
+  const float* p_op = fptr(opacity, means3D, "opacities", k_op);
+  const float* p_sc = fptr(scales, means3D, "scales", k_sc);
+  const float* p_rot = fptr(rotations, means3D, "rotations", k_rot);
+  const float* p_cov = fptr(cov3D_precomp, means3D, "cov3D_precomp", k_cov);
+  const float* p_view = fptr(viewmatrix, means3D, "viewmatrix", k_view);
+  const float* p_proj = fptr(projmatrix, means3D, "projmatrix", k_proj);
+  const float* p_cam = fptr(campos, means3D, "campos", k_cam);
+  TORCH_CHECK(p_bg && p_lbg && p_view && p_proj && p_cam, "bg/layer_bg/viewmatrix/projmatrix/campos must be non-empty");
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  int rendered;
+  {
+    pybind11::gil_scoped_release nogil;
+    rendered = grpg_forward_layers(
+        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree, M, p_bg, W, H,
+        p_means, p_sh, p_col, p_op, p_sc, scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, tan_fovx, tan_fovy,
+        P > 0 ? (const unsigned char*)k_cls.data_ptr() : nullptr, p_lbg, out_color.data_ptr<float>(),
+        out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(), color_bg.data_ptr<float>(),
+        alpha_bg.data_ptr<float>(), color_obj.data_ptr<float>(), alpha_obj.data_ptr<float>(),
+        P > 0 ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0, (void*)stream);
+  }
+  if (rendered < 0) raise_abi_error("grpg_forward_layers", rendered);
+  return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj);
+}
+
 // (ok, num_rendered): ok = 1 valid, 0 the frame must be rendered again, -1 not ready (wait = false)
 std::tuple<int, int> FrameStatus(const int ticket, const bool wait) {
   int R = 0, rc;
@@ -785,6 +849,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_gaussians", &RasterizeGaussians);
   m.def("rasterize_gaussians_eval", &RasterizeGaussiansEval);
   m.def("rasterize_gaussians_eval_deferred", &RasterizeGaussiansEvalDeferred);
+  m.def("rasterize_gaussians_layers", &RasterizeGaussiansLayers);
   m.def("frame_status", &FrameStatus, pybind11::arg("ticket"), pybind11::arg("wait") = true);
   m.def("distCUDA2", &distCUDA2);
   m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);

@@ -256,6 +256,29 @@ def render_all(scene: Scene, cam: CameraTensors, obj_mask: torch.Tensor, *, mode
     return result
 
 
+def render_all_fused(scene: Scene, cam: CameraTensors, obj_mask: torch.Tensor) -> dict:
+    """The same result dict as render_all(mode="evaluate") from ONE op call (the additive layered forward,
+    GaussianRasterizer.forward_layers / grpg_forward_layers): no subset tensors are built, preprocess and
+    binning run once, every tile list is walked once with three blend states."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = cam.viewmatrix.device
+    H, W = int(cam.image_height), int(cam.image_width)
+    if scene.means3D.shape[0] == 0:   # render_kernel's P == 0 branch, three times
+        z = torch.zeros(1, H, W, device=dev)
+        return {"rgb": torch.zeros(3, H, W, device=dev), "acc": z, "semantic": torch.zeros(0, H, W, device=dev),
+                "rgb_background": torch.ones(3, H, W, device=dev), "acc_background": z.clone(),
+                "rgb_object": torch.ones(3, H, W, device=dev), "acc_object": z.clone()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(
+        **settings_kwargs(cam, scene.sh_degree, bg=torch.zeros(3, device=dev))))
+    o = rast.forward_layers(scene.means3D, scene.opacity, obj_mask, shs=scene.shs, scales=scene.scales,
+                            rotations=scene.rotations)
+    clamp = lambda t: torch.clamp(t, 0.0, 1.0)   # noqa: E731  (render_kernel :236-237, evaluation mode)
+    return {"rgb": clamp(o["color"]), "acc": o["alpha"], "depth": o["depth"], "viewspace_points": None,
+            "visibility_filter": o["radii"] > 0, "radii": o["radii"],
+            "rgb_background": clamp(o["color_background"]), "acc_background": o["alpha_background"],
+            "rgb_object": clamp(o["color_object"]), "acc_object": o["alpha_object"]}
+
+
 def train_loss(render_pkg: dict, gt_image: torch.Tensor, lidar_depth: Optional[torch.Tensor] = None,
                sky_mask: Optional[torch.Tensor] = None, lambda_l1: float = 1.0,
                lambda_depth_lidar: float = 0.1, lambda_sky: float = 0.05) -> torch.Tensor:

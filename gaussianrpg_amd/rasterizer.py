@@ -195,6 +195,39 @@ class GaussianRasterizer(nn.Module):
                 rs.prefiltered, rs.debug)
         return ticket, color, radii, depth, alpha, semantic
 
+    def forward_layers(self, means3D, opacities, layer_class, shs=None, colors_precomp=None, scales=None,
+                       rotations=None, cov3D_precomp=None, layer_bg=None):
+        """Evaluation-only LAYERED forward (additive; C ABI grpg_forward_layers): what
+        StreetGaussianRenderer.render_all (lib/models/street_gaussian_renderer.py:13-40) gets from THREE calls
+        of the rasterizer -- all models, the background model alone, the object models alone -- from one
+        preprocess + binning pass and one walk of every tile list.  layer_class: bool / uint8 [P], True =
+        object model; layer_bg: background colour of the two layer planes (default white, like the
+        reference's white_background=True).  Returns a dict: color, radii, depth, alpha (the composition, as
+        forward()), color_background, alpha_background, color_object, alpha_object."""
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        shs = _empty() if shs is None else shs
+        colors_precomp = _empty() if colors_precomp is None else colors_precomp
+        scales = _empty() if scales is None else scales
+        rotations = _empty() if rotations is None else rotations
+        cov3D_precomp = _empty() if cov3D_precomp is None else cov3D_precomp
+        if layer_bg is None:
+            layer_bg = torch.ones(3, dtype=torch.float32, device=means3D.device)
+        with torch.no_grad():
+            (_, color, depth, alpha, radii, color_bg, alpha_bg, color_obj,
+             alpha_obj) = _C.rasterize_gaussians_layers(
+                rs.bg, layer_bg, layer_class, means3D, colors_precomp, opacities, scales, rotations,
+                rs.scale_modifier, cov3D_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                rs.image_height, rs.image_width, shs, rs.sh_degree, rs.campos, rs.debug)
+        return {"color": color, "radii": radii, "depth": depth, "alpha": alpha,
+                "color_background": color_bg, "alpha_background": alpha_bg,
+                "color_object": color_obj, "alpha_object": alpha_obj}
+
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         """(radii int32[P], means2D [P,2]) without colour/conic (reference :235-259)."""
         rs = self.raster_settings

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRPG_ABI_VERSION 4   /* 4: grpg_set_capacity_hint, asynchronous-error reporting, backward argument checks */
+#define GRPG_ABI_VERSION 5   /* 5: grpg_forward_layers (one-pass render_all); 4: grpg_set_capacity_hint, asynchronous-error reporting, backward argument checks */
 
 /* Exported symbol (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -132,6 +132,38 @@ GRPG_API int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_use
                  float tan_fovx, float tan_fovy, int prefiltered,
                  float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                  int* radii, int debug, void* hip_stream, unsigned flags);
+
+/*
+ * Layered frame (additive, ABI 5; evaluation only): what the reference's evaluation path obtains with
+ * THREE calls of its rasterizer per frame -- StreetGaussianRenderer.render_all
+ * (lib/models/street_gaussian_renderer.py:13-40): the composition of all models, the background model
+ * alone and the object models alone, the last two on a white background -- from ONE preprocess +
+ * binning pass and ONE walk of every tile list with three blend states.
+ *   layer_class       [P] device bytes: 0 = background model, != 0 = object (actor) model
+ *   layer_background  [3] device floats: background colour of the two layer planes (the reference: white)
+ *   out_color_bg / out_alpha_bg    [3,H,W] / [1,H,W]: colour and accumulated alpha of the class-0 Gaussians
+ *   out_color_obj / out_alpha_obj  the same for the class != 0 Gaussians
+ * out_color / out_depth / out_alpha / radii and the return value are those of grpg_forward_flags with
+ * GRPG_FORWARD_NO_BACKWARD on the whole scene.  Each layer plane equals, bit for bit, what grpg_forward
+ * returns for that SUBSET of the Gaussians in the same order (a layer's transmittance chain sees alpha = 0
+ * for the other class: exact no-ops).  No semantic planes (S = 0), P < 2^27 (the class travels in bit 27 of
+ * the point-list entries), the blobs cannot be handed to grpg_backward.
+ */
+GRPG_API int grpg_forward_layers(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 int P, int D, int M,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy,
+                 const unsigned char* layer_class, const float* layer_background,
+                 float* out_color, float* out_depth, float* out_alpha,
+                 float* out_color_bg, float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj,
+                 int* radii, int debug, void* hip_stream);
 
 /*
  * Deferred frames (additive; for frame loops that do not need num_rendered at once: trajectory /

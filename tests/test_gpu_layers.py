@@ -1,0 +1,159 @@
+"""-m gpu: the layered forward (grpg_forward_layers / GaussianRasterizer.forward_layers / harness.render_all_fused)
+against what it replaces -- the THREE op calls of the reference's StreetGaussianRenderer.render_all
+(lib/models/street_gaussian_renderer.py:13-40): composition, background model alone, object models alone.
+
+The layer planes are not merely close: a layer's transmittance chain sees alpha = 0 for the other class
+(T x 1 and C + c x 0, exact no-ops), so every plane must carry the very bits the op returns for that subset
+of the Gaussians.  Also: the composition's integer outputs, both binning algorithms, a capacity overflow,
+degenerate layers (no objects / only objects), and the frame time against the three calls.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianrpg_amd import harness as hz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X (no ROCm device visible)")
+    return torch.device("cuda:0")
+
+
+def _objects_scene(P_bg, P_obj, seed, depth=6.0):
+    """A background cloud plus a few compact 'actor' clusters in front of / inside it."""
+    bg = hz.toy_scene(P_bg, seed=seed, sh_degree=1, depth=depth)
+    g = torch.Generator().manual_seed(seed + 1000)
+    parts = []
+    centres = torch.tensor([[-1.5, 0.3, depth - 2.0], [1.2, -0.2, depth - 1.0], [0.1, 0.5, depth + 1.5]])
+    per = P_obj // 3
+    for c in centres:
+        o = hz.toy_scene(per, seed=int(torch.randint(0, 10000, (1,), generator=g)), sh_degree=1, depth=0.0,
+                         spread=0.35, scale=0.05)
+        parts.append(hz.Scene(o.means3D * torch.tensor([1.0, 1.0, 0.2]) + c, o.opacity.clamp(min=0.6), o.scales,
+                              o.rotations, o.shs, 1))
+    cat = lambda k: torch.cat([getattr(bg, k)] + [getattr(p, k) for p in parts]).contiguous()   # noqa: E731
+    sc = hz.Scene(cat("means3D"), cat("opacity"), cat("scales"), cat("rotations"), cat("shs"), 1)
+    mask = torch.zeros(sc.means3D.shape[0], dtype=torch.bool)
+    mask[P_bg:] = True
+    # interleave the classes in memory: the op must not rely on the objects sitting behind the background
+    perm = torch.randperm(sc.means3D.shape[0], generator=g)
+    sc = hz.Scene(*(t[perm].contiguous() if isinstance(t, torch.Tensor) else t for t in sc))
+    return sc, mask[perm]
+
+
+def _same_bits(name, a, b):
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "%s: %d of %d values differ, max %.3e" % (
+        name, int((a != b).sum()), a.size, float(np.abs(a - b).max()))
+
+
+def _check(dev, sc, mask, W, H, frame=0):
+    d, m = sc.to(dev), mask.to(dev)
+    cam = hz.trajectory_camera(frame, W=W, H=H, device=dev)
+    with torch.no_grad():
+        three = hz.render_all(d, cam, m)
+        one = hz.render_all_fused(d, cam, m)
+    torch.cuda.synchronize()
+    for k in ("rgb", "acc", "depth", "rgb_background", "acc_background", "rgb_object", "acc_object"):
+        _same_bits(k, one[k], three[k])
+    assert torch.equal(one["radii"], three["radii"])
+    return one
+
+
+@pytest.mark.parametrize("W,H", [(160, 96), (200, 136)])
+def test_layers_equal_three_calls_bit_for_bit(dev, W, H):
+    sc, mask = _objects_scene(6000, 900, seed=3)
+    one = _check(dev, sc, mask, W, H)
+    # the planes are not trivially equal to each other: objects occlude and are occluded
+    assert float((one["rgb"] - one["rgb_background"]).abs().max()) > 0.05
+    assert 0.02 < float(one["acc_object"].mean()) < 0.9
+
+
+def test_layers_long_lists_and_both_binning_algorithms(dev):
+    """Overdraw stress (thousands of entries per tile, class-0 sized lists: plain heavy waves in a layered
+    frame) and the sort-based binning path (the class bit is marked behind either algorithm)."""
+    from gaussianrpg_amd.rasterizer import _C
+    sc, mask = _objects_scene(60000, 6000, seed=11, depth=5.0)
+    sc = hz.Scene(sc.means3D, sc.opacity * 0.35, sc.scales * 2.5, sc.rotations, sc.shs, 1)   # translucent, large
+    alg = _C.get_binning_algorithm()
+    try:
+        for a in (1, 0):
+            _C.set_binning_algorithm(a)
+            _C.reset_capacity_hints()
+            _check(dev, sc, mask, 256, 160)
+            _check(dev, sc, mask, 256, 160, frame=3)      # a speculative frame on the remembered capacity
+    finally:
+        _C.set_binning_algorithm(alg)
+
+
+def test_layers_capacity_overflow_reruns_the_tail(dev):
+    from gaussianrpg_amd.rasterizer import _C
+    sc, mask = _objects_scene(8000, 1200, seed=5)
+    P = sc.means3D.shape[0]
+    _C.set_capacity_hint(P, 160, 96, 3000, 3000)     # far too small: the tail (incl. the class marks) runs twice
+    _check(dev, sc, mask, 160, 96)
+
+
+def test_degenerate_layers(dev):
+    """No object at all: the object planes are the layer background; only objects: the background planes."""
+    sc, mask = _objects_scene(5000, 600, seed=7)
+    d = sc.to(dev)
+    cam = hz.trajectory_camera(0, W=160, H=96, device=dev)
+    none = torch.zeros_like(mask).to(dev)
+    one = hz.render_all_fused(d, cam, none)
+    assert float((one["rgb_object"] - 1.0).abs().max()) == 0.0 and float(one["acc_object"].abs().max()) == 0.0
+    _same_bits("rgb_background", one["rgb_background"], hz.render_kernel(d, cam, white_background=True)["rgb"])
+    every = torch.ones_like(mask).to(dev)
+    one = hz.render_all_fused(d, cam, every)
+    assert float((one["rgb_background"] - 1.0).abs().max()) == 0.0
+    _same_bits("rgb_object", one["rgb_object"], hz.render_kernel(d, cam, white_background=True)["rgb"])
+    # argument checks of the additive entry point
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
+    with pytest.raises(RuntimeError, match="layer_class"):
+        rast.forward_layers(d.means3D, d.opacity, every[:10], shs=d.shs, scales=d.scales, rotations=d.rotations)
+
+
+def test_layers_full_size_and_frame_time(dev):
+    """configs[2]-sized scene (P = 2 M @1920x1280) with 5 % of the Gaussians in ten actor-sized clusters:
+    equal to the three calls bit for bit, and at least twice as fast as they are."""
+    sc = hz.street_scene(2_000_000, seed=2)
+    g = torch.Generator().manual_seed(9)
+    P = sc.means3D.shape[0]
+    mask = torch.zeros(P, dtype=torch.bool)
+    # actors: the Gaussians nearest to ten points on the road ahead
+    for k in range(10):
+        c = torch.tensor([(-1) ** k * 2.0, 1.0, 8.0 + 6.0 * k])
+        d2 = ((sc.means3D - c) ** 2).sum(1)
+        mask[torch.topk(d2, 10000, largest=False).indices] = True
+    d, m = sc.to(dev), mask.to(dev)
+    cam = hz.trajectory_camera(0, device=dev)
+    with torch.no_grad():
+        three = hz.render_all(d, cam, m)
+        one = hz.render_all_fused(d, cam, m)
+        torch.cuda.synchronize()
+        for k in ("rgb", "acc", "depth", "rgb_background", "acc_background", "rgb_object", "acc_object"):
+            _same_bits(k, one[k], three[k])
+
+        def timed(fn, n=8):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        t3 = timed(lambda: hz.render_all(d, cam, m))
+        t1 = timed(lambda: hz.render_all_fused(d, cam, m))
+    from helpers import PARITY_STATS
+    PARITY_STATS.append(dict(test="test_layers_full_size_and_frame_time", plane="render_all_ms",
+                             three_calls_ms=t3, one_pass_ms=t1, speedup=t3 / t1))
+    assert t1 * 2.0 <= t3, "one pass %.3f ms, three calls %.3f ms" % (t1, t3)
