@@ -30,7 +30,7 @@ Extra objects in the line:
                   HIP events on the op's stream around the launch with one frame in flight (a pass of
                   20 frames right behind the timed region; agrees with the rocprofv3 average committed
                   under profiles/), vs 8 TB/s.  `traffic` = HBM bytes per launch from the committed PMC
-                  passes of this round (profiles/round4_traffic.json), null if absent.
+                  passes of this round (profiles/round5_traffic.json), null if absent.
   roofline_overlapped  the same kernel's wall duration INSIDE the timed region, where several
                   frames share the chip: time-sharing, not the kernel's speed.
   roofline_valu   the render kernel's real bound: VALU busy time from the committed PMC pass
@@ -346,7 +346,7 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
                       "gradient allocation, on every other iteration; loss_backward = the loss' own backward "
                       "alone, on the iterations in between).  op_backward_device = HIP events around the op's "
                       "backward alone (gradient zero-fill + render_backward_kernel + "
-                      "preprocess_backward_kernel); per-kernel times: profiles/round3_train_summary.txt",
+                      "preprocess_backward_kernel); per-kernel times: profiles/round5_train_summary.txt",
             "backward_algorithmic_bytes": b_bwd,
             "backward_kernels_ms": {"render_backward_kernel": blend_ms, "preprocess_backward_kernel": prebwd_ms,
                                     "calls": ncalls,
@@ -690,6 +690,34 @@ def main():
                         "what": "rgb8 [H,W,3] in pinned host memory (device pack + async D2H), "
                                 "consumer one frame behind"}
 
+        # The reference's non-lite evaluation path renders every frame three times (render_all: all models,
+        # background alone, objects alone -- street_gaussian_renderer.py:13-40); the additive layered forward
+        # does it in one pass.  Side leg on the bench scene with ten actor-sized clusters marked as objects.
+        render_all_leg = None
+        if world == 1 and not args.no_delivery and not args.checkpoint:
+            obj = torch.zeros(P, dtype=torch.bool, device=dev)
+            for k_ in range(10):
+                c_ = torch.tensor([(-1) ** k_ * 2.0, 1.0, 8.0 + 6.0 * k_], device=dev)
+                obj[torch.topk(((sc.means3D - c_) ** 2).sum(1), 10000, largest=False).indices] = True
+            cam0 = tj.camera_from_tape(tape[0], W=W, H=H, device=dev)
+
+            def _t(fn, n=6):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_) / n * 1e3
+            t3 = _t(lambda: hz.render_all(sc, cam0, obj))
+            t1 = _t(lambda: hz.render_all_fused(sc, cam0, obj))
+            render_all_leg = {"three_op_calls_ms": t3, "one_pass_ms": t1, "speedup": t3 / t1,
+                              "objects": int(obj.sum().item()),
+                              "what": "harness.render_all (the reference's render_all pattern: subset tensors + three "
+                                      "op calls) vs harness.render_all_fused (grpg_forward_layers), wall time per "
+                                      "frame incl. clamps; planes bit-identical (tests/test_gpu_layers.py)"}
+
         if world > 1:
             te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -775,7 +803,7 @@ def main():
         # MI355X_MICROARCH.md prescribes), if a profile of this same workload AND this round's kernels
         # has been committed; otherwise null.  Not measurable inside this process.
         traffic, pmc, pmc_file = None, None, None
-        for name in ("round4_traffic.json", "round3_traffic.json"):
+        for name in ("round5_traffic.json", "round4_traffic.json", "round3_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 wl = tr.get("workload", {})
@@ -894,6 +922,7 @@ def main():
             "timed_region_attempts_s": attempts,
             "frame_latency": latency,
             "delivery": delivery,
+            "render_all": render_all_leg,
             "strong_scaling": strong,
             "train": train,
         }
