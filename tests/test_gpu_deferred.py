@@ -74,6 +74,9 @@ def test_overflowing_frame_is_reported_and_rendered_again(dev):
     """Same (P, W, H) key, far more instances: the deferred frame is enqueued for the small
     scene's capacity, its status says so, DeferredFrames renders it again."""
     from gaussianrpg_amd.rasterizer import _C, frame_ok
+    import os
+    if os.environ.get("GRPG_SYNC_R", "0") not in ("", "0"):
+        pytest.skip("GRPG_SYNC_R=1: exact binning mode, a deferred frame runs synchronously and cannot overflow")
     W, H, P = 640, 384, 6000
     small = hz.toy_scene(P, seed=5, sh_degree=1, depth=30.0).to(dev)
     big = hz.toy_scene(P, seed=5, sh_degree=1, depth=1.5).to(dev)
