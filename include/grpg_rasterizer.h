@@ -84,7 +84,8 @@ GRPG_API const char* grpg_last_error(void);
  * Rasterizer::forward  (rasterizer.h:32-58, rasterizer_impl.cu:197-343).
  * P Gaussians, SH degree D with M coefficients per Gaussian, S semantic channels.
  *   background[3]; means3D[P,3]; shs[P,M,3] or NULL; colors_precomp[P,3] or NULL;
- *   semantics[P,S] (ignored when S==0); opacities[P]; scales[P,3] / rotations[P,4] or NULL with
+ *   semantics[P,S] (ignored when S==0; values must be FINITE: a pixel that rejects a splat adds 0 x sem
+ *   where the reference skips the splat); opacities[P]; scales[P,3] / rotations[P,4] or NULL with
  *   cov3D_precomp[P,6]; viewmatrix[16], projmatrix[16] (row-major storage of the TRANSPOSED
  *   math matrices, as lib/utils/camera_utils.py:50-58 builds them); cam_pos[3].
  * Outputs (caller-allocated, like rasterize_points.cu:70-74): out_color[3,H,W], out_depth[H,W],

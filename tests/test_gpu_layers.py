@@ -157,3 +157,33 @@ def test_layers_full_size_and_frame_time(dev):
     PARITY_STATS.append(dict(test="test_layers_full_size_and_frame_time", plane="render_all_ms",
                              three_calls_ms=t3, one_pass_ms=t1, speedup=t3 / t1))
     assert t1 * 2.0 <= t3, "one pass %.3f ms, three calls %.3f ms" % (t1, t3)
+
+
+# Randomised draws of tests/test_gpu_sweep.py (odd image sizes, P from 1 up, needles, screen-filling splats,
+# Gaussians behind the camera, opacities around 1/255) with a random class per Gaussian: layered forward ==
+# three op calls, bit for bit.  No oracle involved: cheap.  A hunt: GRPG_SWEEP_LAYERS=300 [GRPG_SWEEP_OFFSET=...]
+import os
+
+N_LAYERS = int(os.environ.get("GRPG_SWEEP_LAYERS", "24"))
+OFFSET = int(os.environ.get("GRPG_SWEEP_OFFSET", "0"))
+
+
+@pytest.mark.parametrize("seed", range(OFFSET + 3000, OFFSET + 3000 + N_LAYERS))
+def test_layers_sweep(dev, seed):
+    from test_gpu_sweep import draw
+    d = draw(seed, max_P=40000, max_side=300)
+    sc, cam = d["sc"], d["cam"]
+    P = sc.means3D.shape[0]
+    r = np.random.RandomState(seed)
+    share = float(r.choice([0.0, 0.02, 0.2, 0.5, 1.0]))
+    mask = torch.from_numpy(r.rand(P) < share)
+    dsc, m = sc.to(dev), mask.to(dev)
+    camd = hz.CameraTensors(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, cam.viewmatrix.to(dev),
+                            cam.projmatrix.to(dev), cam.campos.to(dev))
+    with torch.no_grad():
+        three = hz.render_all(dsc, camd, m)
+        one = hz.render_all_fused(dsc, camd, m)
+    torch.cuda.synchronize()
+    for k in ("rgb", "acc", "depth", "rgb_background", "acc_background", "rgb_object", "acc_object"):
+        _same_bits("%s (seed %d, %s, P=%d, %dx%d, objects %.2f)" % (k, seed, d["kind"], P, cam.image_width,
+                                                                   cam.image_height, share), one[k], three[k])
