@@ -6,7 +6,8 @@ nw = raw.size // 17
 t = raw[:nw * 8].reshape(-1, 8)
 tloop = raw[nw * 8:nw * 9]
 bucket = raw[nw * 9:].reshape(-1, 8)   # BLEND iterations / cycles by live-pixel count (<=2, <=8, <=24, >24)
-sel = t[:, 0] != 0xFFFFFFFF
+# (records of the class-0 producer / consumer waves carry bit 30 in their tile word: tools/trace_class0.py)
+sel = (t[:, 0] != 0xFFFFFFFF) & (((t[:, 0] >> 30) & 1) == 0)
 bucket = bucket[sel].astype(np.int64)
 v = t[sel]
 tloop = tloop[sel].astype(np.int64)
