@@ -569,11 +569,99 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
 // Dead entries cost 1/256 of a FILL step instead of a slot of a 64-entry batch; a record is only
 // ever loaded for an entry that can reach the quarter.
 // ------------------------------------------------------------------------------------------
-// (Round 5 also ran the ordinary quarter waves on the producers' 1024 / 2048-entry list stream below: same
-// images, render 0.2095-0.2112 vs 0.2074-0.2104 ms on one box -- thousands of waves hide each other's list
-// latencies, the bulk of the launch is bound by the vector ALUs; the 256-entry windows stay.)
 constexpr int QCAP = 512;            // ring capacity in entries (>= 64 + 256), power of two
-constexpr int FILL_Q = 4;            // list entries per lane per FILL step
+constexpr int FILL_Q = 4;            // list entries per lane per FILL step of the ordinary quarter waves
+
+// ------------------------------------------------------------------------------------------
+// A wave's view of its tile list: a STREAM read in large windows.
+//
+// The ordinary quarter waves (blend_heavy) read the list 256 entries at a time (four predicated 4-byte
+// loads per lane, prefetched ONE step ahead): every FILL step waits out a memory latency (the list was
+// written by the fill kernel a moment ago: HBM / Infinity Cache, 1 - 2 us).  With thousands of waves in
+// flight that is hidden; for ONE wave walking 8 k - 35 k entries -- a class-0 producer, or the quarter wave of
+// such a tile in a layered frame, which has no wave pairs -- those 126 steps are most of its life
+// (tools/trace_class0.py: 1.9 us per batch for 0.7 us of work).  Here a window is SUB sub-windows of 256
+// entries, requested together with 16-byte loads (lane l owns four consecutive entries) and consumed from
+// registers: one memory latency per SUB x 256 entries.  SUB = 8 for the producers (a wave of its own with
+// registers to spare), 4 for the layered frame's quarter waves.  (The ordinary quarter waves were measured on
+// it too: render 0.2095-0.2112 vs 0.2074-0.2104 ms on one box -- the bulk of the launch is bound by the
+// vector ALUs, they keep their 256-entry windows.)
+// ------------------------------------------------------------------------------------------
+template <int SUB>
+struct ListStream {
+  static_assert(SUB == 4 || SUB == 8, "sub-windows per register window");
+  static constexpr uint32_t SPAN = SUB * 256u;   // entries per register window
+  const uint32_t* pl;
+  uint32_t r_begin, r_end;
+  uint32_t wpos;      // list index (absolute, a multiple of 256) of c0's first entry
+  uint32_t q;         // next sub-window of the register window
+  // Named registers, not an array: a (wave-uniform) dynamic index would send an array to scratch.
+  // ONE bank, refilled when it is used up.  A second bank loaded a window ahead was built three ways
+  // (moves between banks, two banks taking turns, a scheduling barrier between moves and reloads): hipcc
+  // either routes the reloads through temporaries and waits for them on the spot (loop-carried registers
+  // are not coalesced with the load destinations) or waits vmcnt(0) at every use -- no better than this,
+  // for twice the registers.
+  uint4 c0, c1, c2, c3, c4, c5, c6, c7;
+  // UNCONDITIONAL load (address clamped into the list; append() drops entries outside [r_begin, r_end) by
+  // index): a predicated load makes the compiler copy the result through a temporary.
+  __device__ __forceinline__ uint4 load(const uint32_t first, const int lane) const {
+    const uint32_t e = min(first + 4u * (uint32_t)lane, (r_end - 1u) & ~3u);   // 16-byte aligned
+    return *reinterpret_cast<const uint4*>(pl + e);
+  }
+  __device__ __forceinline__ void refill(const int lane) {
+    c0 = load(wpos, lane); c1 = load(wpos + 256u, lane); c2 = load(wpos + 512u, lane); c3 = load(wpos + 768u, lane);
+    if (SUB == 8) {
+      c4 = load(wpos + 1024u, lane); c5 = load(wpos + 1280u, lane);
+      c6 = load(wpos + 1536u, lane); c7 = load(wpos + 1792u, lane);
+    }
+  }
+  // re > rb (an empty list must not be opened: the clamp needs r_end >= 1)
+  __device__ __forceinline__ void open(const uint32_t* point_list, const uint32_t rb, const uint32_t re, const int lane) {
+    pl = point_list; r_begin = rb; r_end = re;
+    wpos = rb & ~255u; q = 0;
+    refill(lane);
+  }
+  __device__ __forceinline__ bool exhausted() const { return wpos + 256u * q >= r_end; }
+  // Appends the entries of sub-window v (first entry e0 for this lane) whose mask has `bit` to the ring, in
+  // list order: lane-major, then the lane's four entries.
+  // also != 0: an entry must additionally have one of those bits (a layered frame's "objects only" phase).
+  __device__ __forceinline__ void append(const uint4 v, const uint32_t e0, uint32_t* __restrict__ qid,
+                                         uint32_t* __restrict__ qpos, const uint32_t bit, const uint32_t head,
+                                         uint32_t& count, const uint64_t lt, const uint32_t also) const {
+    const uint32_t any = also ? also : ~0u;
+    const bool k0 = (e0 >= r_begin) && (e0 < r_end) && (v.x & bit) && (v.x & any);
+    const bool k1 = (e0 + 1u >= r_begin) && (e0 + 1u < r_end) && (v.y & bit) && (v.y & any);
+    const bool k2 = (e0 + 2u >= r_begin) && (e0 + 2u < r_end) && (v.z & bit) && (v.z & any);
+    const bool k3 = (e0 + 3u >= r_begin) && (e0 + 3u < r_end) && (v.w & bit) && (v.w & any);
+    const uint64_t m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
+    uint32_t sl = head + count + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt) +
+                  (uint32_t)__popcll(m2 & lt) + (uint32_t)__popcll(m3 & lt);
+    const uint32_t p0 = e0 - r_begin + 1u;   // 1-based position in the tile's list
+    if (k0) { qid[sl & (QCAP - 1)] = v.x & ID_MASK; qpos[sl & (QCAP - 1)] = p0; sl++; }
+    if (k1) { qid[sl & (QCAP - 1)] = v.y & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 1u; sl++; }
+    if (k2) { qid[sl & (QCAP - 1)] = v.z & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 2u; sl++; }
+    if (k3) { qid[sl & (QCAP - 1)] = v.w & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 3u; }
+    count += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2) + (uint32_t)__popcll(m3);
+  }
+  // one FILL step: the next sub-window (256 entries); count is the ring's fill state, which must leave
+  // room for 256 entries.  q is wave-uniform: scalar branches, each naming its register.
+  __device__ __forceinline__ void fill(uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos, const uint32_t bit,
+                                       const uint32_t head, uint32_t& count, const int lane, const uint64_t lt,
+                                       const uint32_t also = 0u) {
+    const uint32_t e0 = wpos + 256u * q + 4u * (uint32_t)lane;
+    switch (q) {
+      case 0u: append(c0, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 1u: append(c1, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 2u: append(c2, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 3u: append(c3, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 4u: append(c4, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 5u: append(c5, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 6u: append(c6, e0, qid, qpos, bit, head, count, lt, also); break;
+      default: append(c7, e0, qid, qpos, bit, head, count, lt, also); break;
+    }
+    if (++q == (uint32_t)SUB) { q = 0; wpos += SPAN; if (wpos < r_end) refill(lane); }
+  }
+};
 
 // Blend checkpoints for the backward (common.h CK_*): per-quarter state of a long tile's walk.
 struct CkptWriter {
@@ -803,88 +891,6 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------
-// The class-0 producer's view of its tile list: a STREAM read in large windows.
-//
-// blend_heavy's FILL reads the list 256 entries at a time and prefetches ONE step ahead.  With
-// thousands of waves in flight that is enough; a class-0 producer is one wave walking 8 k - 35 k
-// entries, and every FILL step then costs a full memory latency (the list was written by the fill
-// kernel a moment ago: HBM / Infinity Cache, 1 - 2 us): 126 steps of the bench frame's longest list
-// are the 0.19 ms the render launch could not get below in round 4 -- speeding up the CONSUMER side
-// (round 5's evaluator / blender split) alone changed nothing.  Here the stream holds LS_SUB sub-windows
-// of 256 entries in registers (16-byte loads: lane l owns four consecutive entries), all requested
-// together, and consumes them from registers.
-// ------------------------------------------------------------------------------------------
-constexpr int LS_SUB = 8;                    // sub-windows of 256 entries per register window
-constexpr uint32_t LS_SPAN = LS_SUB * 256u;  // entries per register window
-struct ListStream {
-  const uint32_t* pl;
-  uint32_t r_begin, r_end;
-  uint32_t wpos;      // list index (absolute, a multiple of 256) of c0's first entry
-  uint32_t q;         // next sub-window of the register window
-  // Named registers, not an array: a (wave-uniform) dynamic index would send an array to scratch.
-  // ONE bank, refilled when it is used up: all LS_SUB loads of a window are in flight together, so a
-  // window of 2048 entries costs one memory latency (blend_heavy's FILL: one per 256 entries).  A second
-  // bank loaded a window ahead was built three ways (moves between banks, two banks taking turns, a
-  // scheduling barrier between moves and reloads): hipcc either routes the reloads through temporaries
-  // and waits for them on the spot (loop-carried registers are not coalesced with the load destinations)
-  // or waits vmcnt(0) at every use -- no better than this, for twice the registers.
-  uint4 c0, c1, c2, c3, c4, c5, c6, c7;
-  static_assert(LS_SUB == 8, "eight sub-windows per register window");
-  // UNCONDITIONAL load (address clamped into the list; append() drops entries outside [r_begin, r_end) by
-  // index): a predicated load makes the compiler copy the result through a temporary.
-  __device__ __forceinline__ uint4 load(const uint32_t first, const int lane) const {
-    const uint32_t e = min(first + 4u * (uint32_t)lane, (r_end - 1u) & ~3u);   // 16-byte aligned
-    return *reinterpret_cast<const uint4*>(pl + e);
-  }
-  __device__ __forceinline__ void refill(const int lane) {
-    c0 = load(wpos, lane); c1 = load(wpos + 256u, lane); c2 = load(wpos + 512u, lane); c3 = load(wpos + 768u, lane);
-    c4 = load(wpos + 1024u, lane); c5 = load(wpos + 1280u, lane); c6 = load(wpos + 1536u, lane); c7 = load(wpos + 1792u, lane);
-  }
-  __device__ __forceinline__ void open(const uint32_t* point_list, const uint32_t rb, const uint32_t re, const int lane) {
-    pl = point_list; r_begin = rb; r_end = re;
-    wpos = rb & ~255u; q = 0;
-    refill(lane);
-  }
-  __device__ __forceinline__ bool exhausted() const { return wpos + 256u * q >= r_end; }
-  // Appends the entries of sub-window v (first entry e0 for this lane) whose mask has `bit` to the ring, in
-  // list order: lane-major, then the lane's four entries.
-  __device__ __forceinline__ void append(const uint4 v, const uint32_t e0, uint32_t* __restrict__ qid,
-                                         uint32_t* __restrict__ qpos, const uint32_t bit, const uint32_t head,
-                                         uint32_t& count, const uint64_t lt) const {
-    const bool k0 = (e0 >= r_begin) && (e0 < r_end) && (v.x & bit);
-    const bool k1 = (e0 + 1u >= r_begin) && (e0 + 1u < r_end) && (v.y & bit);
-    const bool k2 = (e0 + 2u >= r_begin) && (e0 + 2u < r_end) && (v.z & bit);
-    const bool k3 = (e0 + 3u >= r_begin) && (e0 + 3u < r_end) && (v.w & bit);
-    const uint64_t m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
-    uint32_t sl = head + count + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt) +
-                  (uint32_t)__popcll(m2 & lt) + (uint32_t)__popcll(m3 & lt);
-    const uint32_t p0 = e0 - r_begin + 1u;   // 1-based position in the tile's list
-    if (k0) { qid[sl & (QCAP - 1)] = v.x & ID_MASK; qpos[sl & (QCAP - 1)] = p0; sl++; }
-    if (k1) { qid[sl & (QCAP - 1)] = v.y & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 1u; sl++; }
-    if (k2) { qid[sl & (QCAP - 1)] = v.z & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 2u; sl++; }
-    if (k3) { qid[sl & (QCAP - 1)] = v.w & ID_MASK; qpos[sl & (QCAP - 1)] = p0 + 3u; }
-    count += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2) + (uint32_t)__popcll(m3);
-  }
-  // one FILL step: the next sub-window (256 entries); count is the ring's fill state, which must leave
-  // room for 256 entries.  q is wave-uniform: scalar branches, each naming its register.
-  __device__ __forceinline__ void fill(uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos, const uint32_t bit,
-                                       const uint32_t head, uint32_t& count, const int lane, const uint64_t lt) {
-    const uint32_t e0 = wpos + 256u * q + 4u * (uint32_t)lane;
-    switch (q) {
-      case 0u: append(c0, e0, qid, qpos, bit, head, count, lt); break;
-      case 1u: append(c1, e0, qid, qpos, bit, head, count, lt); break;
-      case 2u: append(c2, e0, qid, qpos, bit, head, count, lt); break;
-      case 3u: append(c3, e0, qid, qpos, bit, head, count, lt); break;
-      case 4u: append(c4, e0, qid, qpos, bit, head, count, lt); break;
-      case 5u: append(c5, e0, qid, qpos, bit, head, count, lt); break;
-      case 6u: append(c6, e0, qid, qpos, bit, head, count, lt); break;
-      default: append(c7, e0, qid, qpos, bit, head, count, lt); break;
-    }
-    if (++q == (uint32_t)LS_SUB) { q = 0; wpos += LS_SPAN; refill(lane); }
-  }
-};
-
-// ------------------------------------------------------------------------------------------
 // Producer / consumer wave pairs for the LONGEST tiles (class 0 when pc_mode is on).
 //
 // A horizon quarter is a serial chain (the T recurrence) that outlives the rest of the launch, and
@@ -982,7 +988,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
   const uint64_t lt = lanemask_lt();
   uint32_t head = 0, count = 0;
-  ListStream ls;
+  ListStream<8> ls;
   ls.open(point_list, r_begin, r_end, lane);
   float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, c0 = a0, a1 = a0, b1 = a0, c1 = a0;
   uint32_t pos0 = 0, id0 = 0, pos1 = 0, id1 = 0, ncur = 0;
@@ -1317,6 +1323,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t LAYER_BIT = 1u << 27;
 constexpr uint32_t LAYER_ID_MASK = LAYER_BIT - 1u;
+static_assert((ID_MASK & LAYER_BIT) != 0u, "the ring entries (id & ID_MASK) must keep the class bit");
 
 __global__ void __launch_bounds__(256)
 layer_mark_kernel(uint32_t* __restrict__ point_list, const uint32_t* __restrict__ R_dev, const uint32_t cap,
@@ -1387,13 +1394,9 @@ __device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint
   float ox0 = ax0, ox1 = ax1, oy0 = ay0, oy1 = ay1;
   uint64_t prev_ab = ~0ull, prev_all = ~0ull;
 
-  uint32_t in_pos = r_begin, head = 0, count = 0;
-  uint32_t win[FILL_Q];
-#pragma unroll
-  for (int q = 0; q < FILL_Q; q++) {
-    const uint32_t i = in_pos + q * WAVE + lane;
-    win[q] = i < r_end ? point_list[i] : 0u;
-  }
+  uint32_t head = 0, count = 0;
+  ListStream<4> ls;
+  ls.open(point_list, r_begin, r_end, lane);
   float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
   uint32_t pos = 0, idc = 0, ncur = 0;
 
@@ -1412,31 +1415,9 @@ __device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint
       const MaskBox m = mask_box(live_all);
       ox0 = (float)(x0 + m.c0); ox1 = (float)(x0 + m.c1); oy0 = (float)(y0 + m.r0); oy1 = (float)(y0 + m.r1);
     }
-    // ---- FILL ----
-    while (count < (uint32_t)WAVE && in_pos < r_end) {
-      uint32_t v[FILL_Q];
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) v[q] = win[q];
-      const uint32_t nxt = in_pos + FILL_Q * WAVE;
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) {
-        const uint32_t i = nxt + q * WAVE + lane;
-        win[q] = i < r_end ? point_list[i] : 0u;
-      }
-#pragma unroll
-      for (int q = 0; q < FILL_Q; q++) {
-        const uint32_t i = in_pos + q * WAVE + lane;
-        const bool keep = (i < r_end) && (v[q] & bit) && (need_ab || (v[q] & LAYER_BIT));
-        const uint64_t m = __ballot(keep);
-        if (keep) {
-          const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
-          qid[slot] = v[q] & (LAYER_ID_MASK | LAYER_BIT);   // id + class
-          qpos[slot] = i - r_begin + 1;
-        }
-        count += (uint32_t)__popcll(m);
-      }
-      in_pos = nxt;
-    }
+    // ---- FILL (the ring entry keeps the class bit: ID_MASK covers bit 27) ----
+    while (count < (uint32_t)WAVE && !ls.exhausted())
+      ls.fill(qid, qpos, bit, head, count, lane, lt, need_ab ? 0u : LAYER_BIT);
     __builtin_amdgcn_wave_barrier();
     // ---- POP ----
     const uint32_t nn = min(count, (uint32_t)WAVE);
@@ -1473,7 +1454,7 @@ __device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint
       __builtin_amdgcn_wave_barrier();
     }
     a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
-    if (ncur == 0 && in_pos >= r_end) break;
+    if (ncur == 0 && ls.exhausted()) break;
   }
   const size_t HW = (size_t)H * W;
   if (px < W && py < H) {
