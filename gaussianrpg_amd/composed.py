@@ -194,6 +194,31 @@ class ComposedRasterizer(nn.Module):
         super().__init__()
         self.raster_settings = raster_settings
 
+    def forward_layers(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]],
+                       object_models: Optional[Sequence[bool]] = None, layer_bg=None) -> dict:
+        """Evaluation only: the composition AND the three renders of the reference's
+        ``StreetGaussianRenderer.render_all`` (street_gaussian_renderer.py:13-40: all models, the background
+        model alone, the object models alone -- the last two on ``layer_bg``, default white) from ONE call on the
+        raw parameters (C ABI ``grpg_forward_composed_layers``).  ``object_models``: one flag per model, default
+        "every posed model (actor) is an object".  Returns the dict of ``GaussianRasterizer.forward_layers``;
+        every plane is bit-identical to that call on ``compose(models, poses)``'s output."""
+        rs = self.raster_settings
+        lists, pose_t, idft_t = _pack(models, poses)
+        dev = models[0].xyz.device
+        if layer_bg is None:
+            layer_bg = torch.ones(3, dtype=torch.float32, device=dev)
+        flags = torch.empty(0, dtype=torch.uint8) if object_models is None else \
+            torch.tensor([1 if f else 0 for f in object_models], dtype=torch.uint8)
+        with torch.no_grad():
+            (num_rendered, color, depth, alpha, radii, color_bg, alpha_bg, color_obj,
+             alpha_obj) = _C.rasterize_gaussians_composed_layers(
+                rs.bg, layer_bg, flags, *lists, pose_t, idft_t, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
+                rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug)
+        self.num_rendered = num_rendered
+        return {"color": color, "radii": radii, "depth": depth, "alpha": alpha,
+                "color_background": color_bg, "alpha_background": alpha_bg,
+                "color_object": color_obj, "alpha_object": alpha_obj}
+
     def forward(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]], means2D=None):
         rs = self.raster_settings
         lists, pose_t, idft_t = _pack(models, poses)

@@ -531,6 +531,7 @@ BwdStagingSlot* bwd_staging_acquire() {
 
 // grpg_forward_layers: the class of every Gaussian and the two extra plane pairs
 struct LayerArgs {
+  const unsigned char* segment_class;   // composed frames: [num_segments] HOST bytes (NULL: the segment's rigid flag)
   const unsigned char* layer_class;
   const float* layer_background;
   float* out_color_bg; float* out_alpha_bg; float* out_color_obj; float* out_alpha_obj;
@@ -672,7 +673,9 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
         SegmentDev& d = g_seg_staging[i];
         const grpg_model_segment& g = segs[i];
         d.xyz = g.xyz; d.scaling = g.scaling; d.rotation = g.rotation; d.opacity = g.opacity;
-        d.fdc = g.features_dc; d.frest = g.features_rest; d.flip = g.flip; d.pad1 = nullptr;
+        d.fdc = g.features_dc; d.frest = g.features_rest; d.flip = g.flip;
+        d.pad1 = (const void*)(uintptr_t)(layers ? ((layers->segment_class ? layers->segment_class[i] != 0
+                                                                           : g.rigid != 0) ? 1u : 0u) : 0u);
         d.start = start; d.count = (uint32_t)g.count;
         d.fourier_dim = g.fourier_dim; d.rigid = g.rigid;
         for (int k = 0; k < 4; k++) d.rot[k] = g.obj_rot[k];
@@ -757,7 +760,8 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
         launch_render_layers(stream, ranges, const_cast<uint32_t*>(point_list), rec, width, height, cam.gx, cam.gy,
                              background, out_color, out_depth, out_alpha, work, frame_classes, &gh->R, cap,
                              classified, layers->layer_class, layers->layer_background, layers->out_color_bg,
-                             layers->out_alpha_bg, layers->out_color_obj, layers->out_alpha_obj);
+                             layers->out_alpha_bg, layers->out_color_obj, layers->out_alpha_obj,
+                             segs ? (const SegmentDev*)(geom + GL.seg_table) : nullptr, nseg);
       else
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, frame_classes, cap,
@@ -1085,7 +1089,7 @@ int grpg_forward_layers(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_
   if (P > 0 && !layer_class) return fail(GRPG_ERR_INVALID_ARGUMENT, "layer_class NULL");
   if ((unsigned)P >= (1u << 27))
     return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs P < 2^27 (the class travels in bit 27 of the point list)");
-  const LayerArgs la = {layer_class, layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
+  const LayerArgs la = {nullptr, layer_class, layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
   return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D,
                       M, 0, background, width, height, means3D, shs, colors_precomp, nullptr, opacities, scales,
                       scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
@@ -1155,6 +1159,35 @@ int grpg_forward_composed_flags(grpg_alloc_fn geometry_alloc, void* geometry_use
                       nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
                       projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
                       radii, debug, hip_stream, segments, num_segments, flags);
+}
+
+int grpg_forward_composed_layers(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                                 grpg_alloc_fn binning_alloc, void* binning_user,
+                                 grpg_alloc_fn image_alloc, void* image_user,
+                                 const grpg_model_segment* segments, int num_segments,
+                                 const unsigned char* segment_class, int D, int M,
+                                 const float* background, const float* layer_background, int width, int height,
+                                 float scale_modifier, const float* viewmatrix, const float* projmatrix,
+                                 const float* cam_pos, float tan_fovx, float tan_fovy, float* out_color,
+                                 float* out_depth, float* out_alpha, float* out_color_bg, float* out_alpha_bg,
+                                 float* out_color_obj, float* out_alpha_obj, int* radii, int debug,
+                                 void* hip_stream) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  long long P = 0;
+  if (int rc = check_segments(segments, num_segments, M, &P)) return rc;
+  if (M < 1 || M > 16 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M <= 16");
+  if (!layer_background || !out_color_bg || !out_alpha_bg || !out_color_obj || !out_alpha_obj)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL layer background / layer plane pointer");
+  if (P >= (1ll << 27))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs P < 2^27 (the class travels in bit 27 of the point list)");
+  const LayerArgs la = {segment_class, nullptr, layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                      image_user, (int)P, D, M, 0, background, width, height, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
+                      projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
+                      radii, debug, hip_stream, segments, num_segments, GRPG_FORWARD_NO_BACKWARD, nullptr, false, &la);
 }
 
 int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,

@@ -162,7 +162,7 @@ struct SegmentDev {
   const float* fdc;
   const float* frest;
   const unsigned char* flip; // per-Gaussian flip mask (training symmetry prior) or NULL
-  const void* pad1;
+  const void* pad1;          // low bit: layer class of the model in a layered composed frame (1 = object)
   uint32_t start, count;     // index range [start, start + count) in concatenation order
   int fourier_dim, rigid;
   float rot[4];
@@ -460,7 +460,9 @@ void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_li
                           uint32_t* work, TileClasses cls, const uint32_t* R_dev, uint32_t cap, bool classified,
                           const unsigned char* layer_class /* [P]: 0 background, 1 object */,
                           const float* layer_background /* [3] */, float* out_color_bg, float* out_alpha_bg,
-                          float* out_color_obj, float* out_alpha_obj);
+                          float* out_color_obj, float* out_alpha_obj,
+                          const SegmentDev* seg_table = nullptr /* composed frame: class per model (pad1 & 1) */,
+                          int nseg = 0);
 // channels [c_begin, S) of the semantic planes (stand-alone kernel)
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const RecView rec, const float* semantics, int S, int c_begin, int W, int H,

@@ -1335,6 +1335,31 @@ layer_mark_kernel(uint32_t* __restrict__ point_list, const uint32_t* __restrict_
   }
 }
 
+// composed frames: the class of a Gaussian is its model's (segment table in the geometry blob: start, count,
+// class in the low bits of pad1)
+__global__ void __launch_bounds__(256)
+layer_mark_segments_kernel(uint32_t* __restrict__ point_list, const uint32_t* __restrict__ R_dev, const uint32_t cap,
+                           const SegmentDev* __restrict__ segs, const int nseg) {
+  __shared__ uint32_t s_end[MAX_SEGMENTS];
+  __shared__ uint32_t s_cls[MAX_SEGMENTS];
+  for (int i = (int)threadIdx.x; i < nseg; i += 256) {
+    s_end[i] = segs[i].start + segs[i].count;
+    s_cls[i] = (uint32_t)(uintptr_t)segs[i].pad1 & 1u;
+  }
+  __syncthreads();
+  const uint32_t n = min(*R_dev, cap);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t v = point_list[i];
+    const uint32_t id = v & LAYER_ID_MASK;
+    int lo = 0, hi = nseg - 1;           // first segment whose end lies behind id
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (id < s_end[mid]) hi = mid; else lo = mid + 1;
+    }
+    if (s_cls[lo]) point_list[i] = v | LAYER_BIT;
+  }
+}
+
 struct LayerOut {
   const float* bg_layer;     // [3] background of the two layer planes (the reference renders them on white)
   float* color_bg; float* alpha_bg; float* color_obj; float* alpha_obj;
@@ -1524,13 +1549,17 @@ void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_li
                           int gx, int gy, const float* bg, float* out_color, float* out_depth, float* out_alpha,
                           uint32_t* work, const TileClasses cls, const uint32_t* R_dev, uint32_t cap, bool classified,
                           const unsigned char* layer_class, const float* layer_background, float* out_color_bg,
-                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj) {
+                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj,
+                          const SegmentDev* seg_table, int nseg) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   if (cap > 0) {
     const size_t nb = ((size_t)cap + 255) / 256;
-    layer_mark_kernel<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, s>>>(point_list, R_dev, cap,
-                                                                        (const uint8_t*)layer_class);
+    const unsigned grid = (unsigned)(nb < 4096 ? nb : 4096);
+    if (seg_table)
+      layer_mark_segments_kernel<<<grid, 256, 0, s>>>(point_list, R_dev, cap, seg_table, nseg);
+    else
+      layer_mark_kernel<<<grid, 256, 0, s>>>(point_list, R_dev, cap, (const uint8_t*)layer_class);
   }
   if (!classified)
     classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, cls, work);

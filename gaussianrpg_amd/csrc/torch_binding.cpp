@@ -551,6 +551,69 @@ RasterizeGaussiansComposed(const torch::Tensor& background, const std::vector<to
                          imgBuffer);
 }
 
+// Composition + layered frame (grpg_forward_composed_layers): the reference's whole evaluation render of a frame --
+// StreetGaussianModel's getters and StreetGaussianRenderer.render_all -- from the models' raw parameters.
+// object_model: uint8 [n] on the host, != 0 = the model belongs to the object layer (empty: actors = objects).
+// returns (num_rendered, color, depth, alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj)
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor>
+RasterizeGaussiansComposedLayers(const torch::Tensor& background, const torch::Tensor& layer_background,
+                                 const torch::Tensor& object_model, const std::vector<torch::Tensor>& xyz,
+                                 const std::vector<torch::Tensor>& scaling,
+                                 const std::vector<torch::Tensor>& rotation,
+                                 const std::vector<torch::Tensor>& opacity,
+                                 const std::vector<torch::Tensor>& features_dc,
+                                 const std::vector<torch::Tensor>& features_rest,
+                                 const std::vector<torch::Tensor>& flip, const torch::Tensor& poses,
+                                 const torch::Tensor& idft, const float scale_modifier,
+                                 const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+                                 const float tan_fovx, const float tan_fovy, const int image_height,
+                                 const int image_width, const int degree, const torch::Tensor& campos,
+                                 const bool debug) {
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, flip, poses, idft);
+  const torch::Tensor& like = xyz[0];
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
+  const int H = image_height, W = image_width;
+  const unsigned char* p_cls = nullptr;
+  torch::Tensor k_cls;
+  if (object_model.numel() != 0) {
+    TORCH_CHECK(object_model.numel() == (int64_t)pk.segs.size() && !object_model.is_cuda() &&
+                    (object_model.scalar_type() == torch::kUInt8 || object_model.scalar_type() == torch::kBool),
+                "object_model must be a uint8 / bool HOST tensor with one element per model");
+    k_cls = object_model.contiguous();
+    p_cls = (const unsigned char*)k_cls.data_ptr();
+  }
+  auto fo = like.options().dtype(torch::kFloat32);
+  torch::Tensor out_color = torch::empty({GRPG_NUM_CHANNELS, H, W}, fo), out_depth = torch::empty({1, H, W}, fo);
+  torch::Tensor out_alpha = torch::empty({1, H, W}, fo);
+  torch::Tensor color_bg = torch::empty({GRPG_NUM_CHANNELS, H, W}, fo), alpha_bg = torch::empty({1, H, W}, fo);
+  torch::Tensor color_obj = torch::empty({GRPG_NUM_CHANNELS, H, W}, fo), alpha_obj = torch::empty({1, H, W}, fo);
+  torch::Tensor radii = torch::empty({pk.P}, like.options().dtype(torch::kInt32));
+  auto byte_opts = like.options().dtype(torch::kByte);
+  torch::Tensor geomBuffer = torch::empty({0}, byte_opts), binningBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor k_bg, k_lbg, k_view, k_proj, k_cam;
+  const float* p_bg = fptr(background, like, "background", k_bg);
+  const float* p_lbg = fptr(layer_background, like, "layer_background", k_lbg);
+  const float* p_view = fptr(viewmatrix, like, "viewmatrix", k_view);
+  const float* p_proj = fptr(projmatrix, like, "projmatrix", k_proj);
+  const float* p_cam = fptr(campos, like, "campos", k_cam);
+  TORCH_CHECK(p_bg && p_lbg && p_view && p_proj && p_cam, "bg/layer_bg/viewmatrix/projmatrix/campos must be non-empty");
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  int rendered;
+  {
+    pybind11::gil_scoped_release nogil;
+    rendered = grpg_forward_composed_layers(
+        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, pk.segs.data(),
+        (int)pk.segs.size(), p_cls, degree, pk.M, p_bg, p_lbg, W, H, scale_modifier, p_view, p_proj, p_cam, tan_fovx,
+        tan_fovy, out_color.data_ptr<float>(), out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
+        color_bg.data_ptr<float>(), alpha_bg.data_ptr<float>(), color_obj.data_ptr<float>(),
+        alpha_obj.data_ptr<float>(), radii.data_ptr<int>(), debug ? 1 : 0, (void*)stream);
+  }
+  if (rendered < 0) raise_abi_error("grpg_forward_composed_layers", rendered);
+  return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj);
+}
+
 // Training backward of the fused composition (grpg_backward_composed): gradients with respect to
 // every model's RAW parameter tensors, means2D [P,3] (densification statistic) and the poses [n,8].
 std::tuple<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>,
@@ -866,6 +929,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("image_height"), pybind11::arg("image_width"), pybind11::arg("degree"),
         pybind11::arg("campos"), pybind11::arg("debug"), pybind11::arg("for_backward") = false);
   m.def("rasterize_gaussians_composed_backward", &RasterizeGaussiansComposedBackward);
+  m.def("rasterize_gaussians_composed_layers", &RasterizeGaussiansComposedLayers);
   m.def("compose", &Compose);
   m.def("sky_composite", &SkyComposite, pybind11::arg("cube"), pybind11::arg("ray_matrix"),
         pybind11::arg("fill"), pybind11::arg("clamp_out"), pybind11::arg("rgb"), pybind11::arg("acc"),

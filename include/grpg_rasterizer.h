@@ -259,6 +259,22 @@ GRPG_API int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_
                  float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
                  void* hip_stream);
 
+/* The composed forward as a LAYERED frame (ABI 5; grpg_forward_layers above): scene-graph composition AND the three
+ * renders of StreetGaussianRenderer.render_all from one call on the models' raw parameters.  segment_class: [num_segments]
+ * HOST bytes, != 0 = the model belongs to the object layer (NULL: the segment's `rigid` flag -- actors are objects). */
+GRPG_API int grpg_forward_composed_layers(grpg_alloc_fn geometry_alloc, void* geometry_user,
+                 grpg_alloc_fn binning_alloc, void* binning_user,
+                 grpg_alloc_fn image_alloc, void* image_user,
+                 const grpg_model_segment* segments, int num_segments, const unsigned char* segment_class,
+                 int D, int M,
+                 const float* background, const float* layer_background, int width, int height,
+                 float scale_modifier,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy,
+                 float* out_color, float* out_depth, float* out_alpha,
+                 float* out_color_bg, float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj,
+                 int* radii, int debug, void* hip_stream);
+
 /* grpg_forward_composed with the flags of grpg_forward_flags: flags == 0 keeps what a later
  * grpg_backward_composed needs (n_contrib, room for the gradient records); grpg_forward_composed
  * itself passes GRPG_FORWARD_NO_BACKWARD. */

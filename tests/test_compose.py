@@ -122,6 +122,40 @@ def test_fused_forward_equals_classic_on_composed_tensors(sh_degree):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sh_degree", [1, 2])
+def test_composed_layers_equal_flat_layers_and_three_calls(sh_degree):
+    """grpg_forward_composed_layers: scene-graph composition + the three renders of render_all from the raw
+    parameters.  Bit-identical to the layered forward on compose()'s own output (class = "posed model"), which
+    tests/test_gpu_layers.py ties to the three separate op calls; an explicit model selection likewise."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianrpg_amd.composed import ComposedRasterizer, compose
+    dev = torch.device("cuda:0")
+    models, poses = _scene_graph(sh_degree)
+    models = [_to(m, dev) for m in models]
+    cam = hz.trajectory_camera(2, W=960, H=640, device=dev)
+    rs = GaussianRasterizationSettings(**hz.settings_kwargs(cam, sh_degree, bg=torch.tensor([0.2, 0.1, 0.3], device=dev)))
+    fused = ComposedRasterizer(rs)
+    means, scales, rots, opac, shs = compose(models, poses)
+    counts = [m.xyz.shape[0] for m in models]
+    keys = ("color", "depth", "alpha", "radii", "color_background", "alpha_background", "color_object", "alpha_object")
+    for flags in (None, [False, True, False, True]):
+        one = fused.forward_layers(models, poses, object_models=flags)
+        per_model = [p is not None for p in poses] if flags is None else flags
+        cls = torch.cat([torch.full((n,), bool(f), dtype=torch.bool, device=dev) for n, f in zip(counts, per_model)])
+        flat = GaussianRasterizer(rs).forward_layers(means, opac, cls, shs=shs, scales=scales, rotations=rots)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(one[k], flat[k]), (k, flags)
+        assert float(one["alpha_object"].max()) > 0.5 and float((one["color"] - one["color_background"]).abs().max()) > 0.05
+    # the composition plane is the plain fused forward's
+    c1, r1, d1, a1 = fused(models, poses)
+    assert torch.equal(c1, one["color"]) and torch.equal(d1, one["depth"]) and torch.equal(a1, one["alpha"])
+    # argument check
+    with pytest.raises(RuntimeError, match="object_model"):
+        fused.forward_layers(models, poses, object_models=[True])
+
+
+@pytest.mark.gpu
 def test_single_gaussian_actors():
     """Actors of ONE Gaussian each behind a small one (a workgroup of the preprocess kernels then spans
     four models; empty models are rejected by the binding, test_composed_argument_errors): fused ==

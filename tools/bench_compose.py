@@ -124,8 +124,52 @@ def time_train(fn, n=24):
 
 ta = time_train(train_ref)
 tb = time_train(train_fused)
+
+
+# render_all on the scene graph (street_gaussian_renderer.py:13-40): the reference composes and renders three
+# times per frame -- all models, the background alone, the objects alone (set_visibility + parse_camera + the
+# getters + the op, each time) -- against ONE composed layered forward (grpg_forward_composed_layers)
+def torch_compose_subset(poses, keep_bg, keep_obj):
+    global models
+    full, allposes = models, poses
+    try:
+        if keep_bg and not keep_obj:      # background alone: no actor arithmetic at all
+            m = full[0]
+            return (m.xyz, torch.exp(m.scaling), torch.nn.functional.normalize(m.rotation), torch.sigmoid(m.opacity),
+                    torch.cat((m.features_dc, m.features_rest), 1))
+        x, s, r, o, sh = torch_compose(allposes)
+        if keep_bg:
+            return x, s, r, o, sh
+        nb = full[0].xyz.shape[0]         # objects alone: the actors' slices of the composition
+        return x[nb:], s[nb:], r[nb:], o[nb:], sh[nb:]
+    finally:
+        models = full
+
+
+white = torch.ones(3, device=dev)
+rss_white = [GaussianRasterizationSettings(**hz.settings_kwargs(c, 1, bg=white)) for c in cams]
+
+
+def render_all_ref(f):
+    with torch.no_grad():
+        outs = []
+        for (kb, ko, rs) in ((True, True, rss[f]), (True, False, rss_white[f]), (False, True, rss_white[f])):
+            x, s, r, o, sh = torch_compose_subset(poses_at(f), kb, ko)
+            outs.append(GaussianRasterizer(rs)(means3D=x, means2D=None, opacities=o, shs=sh, scales=s, rotations=r)[0])
+        return outs
+
+
+def render_all_fused(f):
+    return ComposedRasterizer(rss[f]).forward_layers(models, poses_at(f))["color"]
+
+
+ra = hz.time_frames(render_all_ref, 40)
+rb = hz.time_frames(render_all_fused, 40)
 print(json.dumps({"what": "scene-graph composition + forward op, 1.9 M background + 10 actors x 10 k, 1920x1280",
                   "torch_composition_then_op_ms": a, "fused_composed_op_ms": b,
+                  "render_all": {"what": "the evaluation path's three renders per frame (all / background / objects), "
+                                         "each with its own composition, vs one composed layered forward",
+                                 "torch_composition_and_three_ops_ms": ra, "fused_composed_layers_ms": rb},
                   "train_step": {"what": "forward + backward down to the raw parameters (loss = mean colour + "
                                          "0.1 mean depth + mean alpha), synchronize-bracketed wall time",
                                  "torch_composition_autograd_plus_op_ms": ta, "fused_composed_op_ms": tb}}))
