@@ -37,6 +37,22 @@ __device__ __forceinline__ SplatQ splat_q(const float cx, const float cy, const 
   return q;
 }
 
+// True when power2 as computed below cannot come out positive for ANY pixel offset, so that the reference's
+// `power > 0` test (forward.cu:420) can be skipped for this splat without changing a single accept decision.
+//   power2 = fma(dy, fma(C, dy, fl(B dx)), fl(fl(A dx) dx)),  A, C < 0;  its sign is the sign of
+//   -(a dx^2 (1+d1)(1+d2) - B dx dy (1+d3)(1+d4) + c dy^2 (1+d4)),  a = -A, c = -C, |d_i| <= 2^-24,
+// and the exact form a dx^2 - B dx dy + c dy^2 is >= lambda_min (dx^2 + dy^2), while the rounding terms are
+// below 2.01 * 2^-24 (max(a, c) + |B| / 2) (dx^2 + dy^2).  The test asks for lambda_min > k = 2^-17 (a + c + |B|)
+// -- sixty times that bound -- in its sqrt-free form: a > k, c > k, (a - k)(c - k) > B^2 / 4.  The floor 1e-12
+// keeps the products far from the denormal range for pixel offsets >= 1e-4 (pixel centres are integers, splat
+// centres floats of magnitude <= a few thousand); non-finite conics fail every comparison.  An exact zero offset
+// gives power2 = +-0, which is not > 0 either.  Fails only for 2-D Gaussians of axis ratio beyond ~300 : 1.
+__device__ __forceinline__ bool splat_power_never_positive(const SplatQ q) {
+  const float a = -q.A, c = -q.C;
+  const float k = fmaxf(7.62939453125e-06f * (a + c + fabsf(q.B)), 1e-12f);
+  return a > k && c > k && (a - k) * (c - k) > 0.25f * q.B * q.B;
+}
+
 struct SplatTerms {   // per (lane, splat): everything that does not depend on the pixel row
   float hA, bdx, hc;
 };

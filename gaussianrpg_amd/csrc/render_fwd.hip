@@ -212,7 +212,7 @@ __device__ __forceinline__ void store_slot(float4* __restrict__ my, const int sl
 // Evaluate G consecutive compacted survivors (LDS slots j0 .. j0+G-1, all present) for the lane's
 // PX pixels: G*PX independent power/exp/alpha chains, then the in-order blend.  Returns true if
 // the blend part ran (some lane accepted some splat).
-template <int PX, int G, bool AUX = true>
+template <int PX, int G, bool AUX = true, bool SAFE = false>
 __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __restrict__ my,
                                             const int j0, const float pxf, const int py0) {
   float4 ra[G], rq[G], rc[G];
@@ -234,7 +234,8 @@ __device__ __forceinline__ bool blend_group(WavePix<PX>& s, const float4* __rest
       const float dy = ra[g].y - (float)(py0 + k);
       const float p = pair_power(st, dy);
       alpha[g][k] = fminf(ALPHA_MAX, ra[g].z * __builtin_amdgcn_exp2f(p));   // == pair_alpha
-      ok[g][k] = lanes(!(p > 0.0f)) & lanes(!(alpha[g][k] < ALPHA_MIN));
+      // SAFE: every survivor of the batch has splat_power_never_positive (blend_math.h): p > 0 cannot happen
+      ok[g][k] = SAFE ? lanes(!(alpha[g][k] < ALPHA_MIN)) : (lanes(!(p > 0.0f)) & lanes(!(alpha[g][k] < ALPHA_MIN)));
       any |= ok[g][k] & ~s.done[k];
     }
   }
@@ -307,6 +308,10 @@ struct QuadGeom {   // centres, pre-scaled conics and opacities of the four slot
     f[3] = blk[PAIR_F4 + 0]; f[4] = blk[PAIR_F4 + 1]; f[5] = blk[PAIR_F4 + 2];
   }
 };
+// SAFE: every slot of the quad has splat_power_never_positive (blend_math.h) or is a neutral pad, so the
+// `power > 0` compares -- which could never reject anything -- are not executed (4 of the quad's 32 vector
+// instructions, at the half rate of v_cmp).
+template <bool SAFE = false>
 __device__ __forceinline__ void eval_quad(const QuadGeom& g, const float pxf, const float pyf,
                                           float (&alpha)[4], uint64_t (&ok)[4]) {
   const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
@@ -319,8 +324,13 @@ __device__ __forceinline__ void eval_quad(const QuadGeom& g, const float pxf, co
     const v2f al = (v2f){f2.z, f2.w} * G;
     alpha[2 * h + 0] = fminf(ALPHA_MAX, al.x);
     alpha[2 * h + 1] = fminf(ALPHA_MAX, al.y);
-    ok[2 * h + 0] = lanes(!(p.x > 0.0f)) & lanes(!(alpha[2 * h + 0] < ALPHA_MIN));
-    ok[2 * h + 1] = lanes(!(p.y > 0.0f)) & lanes(!(alpha[2 * h + 1] < ALPHA_MIN));
+    if (SAFE) {
+      ok[2 * h + 0] = lanes(!(alpha[2 * h + 0] < ALPHA_MIN));
+      ok[2 * h + 1] = lanes(!(alpha[2 * h + 1] < ALPHA_MIN));
+    } else {
+      ok[2 * h + 0] = lanes(!(p.x > 0.0f)) & lanes(!(alpha[2 * h + 0] < ALPHA_MIN));
+      ok[2 * h + 1] = lanes(!(p.y > 0.0f)) & lanes(!(alpha[2 * h + 1] < ALPHA_MIN));
+    }
   }
 }
 
@@ -352,7 +362,7 @@ __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
                                                 SemAcc<NSEM>* sa, const SemSrc sem, const int j0, const int lane);
 
 // Four consecutive slots j0..j0+3 (j0 % 4 == 0; absent slots are neutral pads: opacity 0).
-template <bool AUX = true, int NSEM = 0>
+template <bool AUX = true, int NSEM = 0, bool SAFE = false>
 __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restrict__ my,
                                            const int j0, const float pxf, const float pyf,
                                            SemAcc<NSEM>* sa = nullptr, const SemSrc sem = SemSrc{nullptr, 0, nullptr},
@@ -362,7 +372,7 @@ __device__ __forceinline__ bool blend_quad(WavePix<1>& s, const float4* __restri
   uint64_t ok[4];
   QuadGeom g;
   g.load(blk);
-  eval_quad(g, pxf, pyf, alpha, ok);
+  eval_quad<SAFE>(g, pxf, pyf, alpha, ok);
   return blend_quad_tail<AUX, NSEM>(s, QuadColsLds{blk}, alpha, ok, sa, sem, j0, lane);
 }
 
@@ -840,8 +850,11 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                         !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, rx0, rx1, ry0, ry1);
       const uint64_t mask = __ballot(keep);
       const int cnt = (int)__popcll(mask);
+      const SplatQ sq = splat_q(b.x, b.y, b.z);
+      // wave-uniform: no survivor of this batch can produce power > 0 (all but pathological conics)
+      const bool batch_safe = __ballot(keep && !splat_power_never_positive(sq)) == 0ull;
       if (keep) {
-        store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, splat_q(b.x, b.y, b.z), a.w,
+        store_pair_half(my, (int)__popcll(mask & lt), a.x, a.y, sq, a.w,
                         make_float4(b.w, c.x, c.y, a.z), pos);
         if (NSEM > 0) sem_stage(semrows, (int)__popcll(mask & lt), sem.semantics, sem.S, idc, true);
       }
@@ -854,9 +867,16 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
       __builtin_amdgcn_wave_barrier();
       const uint64_t tc1 = TRACE ? __builtin_readcyclecounter() : 0;
       if (TRACE) tr->t_stage += (uint32_t)(tc1 - tc0);
-      for (int j0 = 0; j0 < cnt; j0 += 4) {
-        const bool blended = blend_quad<AUX, NSEM>(st, my, j0, pxf, (float)py, &sa, semb, lane);
-        if (TRACE && blended) tr->blends++;
+      if (batch_safe) {
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+          const bool blended = blend_quad<AUX, NSEM, true>(st, my, j0, pxf, (float)py, &sa, semb, lane);
+          if (TRACE && blended) tr->blends++;
+        }
+      } else {
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+          const bool blended = blend_quad<AUX, NSEM, false>(st, my, j0, pxf, (float)py, &sa, semb, lane);
+          if (TRACE && blended) tr->blends++;
+        }
       }
       if (TRACE) {
         const uint64_t tc2 = __builtin_readcyclecounter();
@@ -902,7 +922,8 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 // blends quads.  Hand-over protocol
 // (all in LDS, workgroup-scope acquire/release, no workgroup barrier after the start):
 //   flag[b] == 0          buffer b is free (consumer -> producer)
-//   flag[b] == cnt + 1    buffer b holds cnt compacted survivors (producer -> consumer)
+//   flag[b] == cnt + 1    buffer b holds cnt compacted survivors (producer -> consumer); + PC_SAFE when none
+//                         of them can produce power > 0 (blend_math.h splat_power_never_positive)
 //   flag[b] == PC_DONE    end of the list
 //   stop                  the consumer saturated all its pixels: the producer may quit
 //   box[4]                bounding box of the still-live pixels (consumer -> producer).  The
@@ -922,6 +943,7 @@ constexpr uint32_t PC_DONE = 0xFFFFFFFFu;
 #define GRPG_PC_SPIN_LIMIT (1u << 24)
 #endif
 constexpr uint32_t PC_SPIN_LIMIT = GRPG_PC_SPIN_LIMIT;
+constexpr uint32_t PC_SAFE = 0x100u;   // above cnt + 1 <= 65
 
 __device__ __forceinline__ void pc_fail(const PCErr err, const int lane) {
   if (lane == 0) {
@@ -1003,14 +1025,14 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
     }
   };
   // neutral pads up to a multiple of 4 (opacity 0), then the hand-over of cnt survivors in buffer `cur`
-  const auto publish = [&](float4* __restrict__ my, const int cnt) {
+  const auto publish = [&](float4* __restrict__ my, const int cnt, const bool safe) {
     if (lane < ((4 - (cnt & 3)) & 3)) {
       const SplatQ zq = {0.f, 0.f, 0.f};
       store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
       if (WITH_SEM) sem_stage(my == buf0 ? semrows0 : semrows1, cnt + lane, sem.semantics, sem.S, 0u, false);
     }
     if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
-    pc_store(&ctl->flag[cur], (uint32_t)cnt + 1u);
+    pc_store(&ctl->flag[cur], ((uint32_t)cnt + 1u) | (safe ? PC_SAFE : 0u));
     cur ^= 1;
   };
   const auto buffer_free = [&]() { return pc_load(&ctl->flag[cur]) == 0u; };
@@ -1048,20 +1070,22 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
                       !splat_misses_rect(a1.x, a1.y, b1.x, b1.y, b1.z, a1.w, rx0, rx1, ry0, ry1);
       const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
       const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1);
+      const bool safe0 = __ballot(k0 && !splat_power_never_positive(splat_q(b0.x, b0.y, b0.z))) == 0ull;
+      const bool safe1 = __ballot(k1 && !splat_power_never_positive(splat_q(b1.x, b1.y, b1.z))) == 0ull;
       if (n0 + n1 > 0) {
         if (!pc_wait(ctl, err, lane, true, buffer_free, tr)) return;
         float4* my = cur ? buf1 : buf0;
         if (n0 + n1 <= WAVE) {   // one batch (list order: the first half's survivors first)
           put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
           put(my, k1, m1, n0, a1, b1, c1, pos1, id1);
-          publish(my, n0 + n1);
+          publish(my, n0 + n1, safe0 && safe1);
         } else {                 // two batches
           put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
-          publish(my, n0);
+          publish(my, n0, safe0);
           if (!pc_wait(ctl, err, lane, true, buffer_free, tr)) return;
           my = cur ? buf1 : buf0;
           put(my, k1, m1, 0, a1, b1, c1, pos1, id1);
-          publish(my, n1);
+          publish(my, n1, safe1);
         }
       }
     }
@@ -1072,6 +1096,29 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   }
   if (!pc_wait(ctl, err, lane, true, buffer_free, tr)) return;   // end-of-list marker
   pc_store(&ctl->flag[cur], PC_DONE);
+}
+
+// one handed-over batch: a quad's geometry block waits in registers one quad ahead, its colour / position
+// blocks are requested before the accept arithmetic (the wave has its SIMD to itself at the end of the
+// launch, and every LDS round trip it waits for -- three per quad until round 5 -- is the launch's)
+template <bool AUX, int NSEM, bool SAFE>
+__device__ __forceinline__ void pc_blend_batch(WavePix<1>& st, const float4* __restrict__ my, const int cnt,
+                                               const float pxf, const float pyf, SemAcc<NSEM>* sa,
+                                               const SemSrc semb, const int lane) {
+  constexpr bool PP = AUX;
+  QuadGeom g_n;
+  g_n.load(my);
+  for (int j0 = 0; j0 < cnt; j0 += 4) {
+    const float4* blk = my + (j0 >> 1) * PAIR_F4;
+    const QuadGeom g = g_n;
+    QuadColsReg<PP> col;
+    col.load(blk);
+    g_n.load(my + (min(j0 + 4, cnt - 1) >> 1) * PAIR_F4);   // (the last quad twice: no branch around the loads)
+    float alpha[4];
+    uint64_t ok[4];
+    eval_quad<SAFE>(g, pxf, pyf, alpha, ok);
+    blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, sa, semb, j0, lane);
+  }
 }
 
 template <bool AUX = true, int NSEM = 0>
@@ -1106,27 +1153,12 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     uint32_t f = 0;
     if (!pc_wait(ctl, err, lane, false, [&]() { f = pc_load(&ctl->flag[cur]); return f != 0u; }, tr)) break;
     if (f == PC_DONE) break;
-    const int cnt = (int)(f - 1u);
+    const int cnt = (int)((f & (PC_SAFE - 1u)) - 1u);
     if (tr) { tr->batches++; tr->survivors += (uint32_t)cnt; }
     const float4* my = cur ? buf1 : buf0;
     const SemSrc semb = {sem.semantics, sem.S, cur ? semrows1 : semrows0};
-    // A quad's geometry block waits in registers one quad ahead, its colour / position blocks are
-    // requested before the accept arithmetic: the wave has its SIMD to itself at the end of the
-    // launch, and every LDS round trip it waits for (three per quad until round 5) is the launch's.
-    constexpr bool PP = AUX;
-    QuadGeom g_n;
-    g_n.load(my);
-    for (int j0 = 0; j0 < cnt; j0 += 4) {
-      const float4* blk = my + (j0 >> 1) * PAIR_F4;
-      const QuadGeom g = g_n;
-      QuadColsReg<PP> col;
-      col.load(blk);
-      g_n.load(my + (min(j0 + 4, cnt - 1) >> 1) * PAIR_F4);   // (the last quad twice: no branch around the loads)
-      float alpha[4];
-      uint64_t ok[4];
-      eval_quad(g, pxf, pyf, alpha, ok);
-      blend_quad_tail<AUX, NSEM>(st, col, alpha, ok, &sa, semb, j0, lane);
-    }
+    if (f & PC_SAFE) pc_blend_batch<AUX, NSEM, true>(st, my, cnt, pxf, pyf, &sa, semb, lane);
+    else pc_blend_batch<AUX, NSEM, false>(st, my, cnt, pxf, pyf, &sa, semb, lane);
     if (AUX && ckw.recs != nullptr) {   // list position of the batch's last survivor (pair layout above)
       const float* blk = reinterpret_cast<const float*>(my + ((cnt - 1) >> 1) * PAIR_F4);
       ckpt_batch_end(ckw, lane, st,
@@ -1377,7 +1409,7 @@ __device__ __forceinline__ void blend_quad_layers(WavePix<1>& sa, WavePix<1>& sb
   const float4 p0 = blk[5], p1 = blk[PAIR_F4 + 5];
   float alpha[4];
   uint64_t ok[4];
-  eval_quad(g, pxf, pyf, alpha, ok);
+  eval_quad(g, pxf, pyf, alpha, ok);   // (the batch-level SAFE form costs this kernel 18 registers: 0.45 -> 0.49 ms)
   const uint32_t cls[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.z)),
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.w)),
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.z)),

@@ -18,6 +18,11 @@ for k in range(4):
 buf = (ctypes.c_ulonglong * (4 * 4 * 10))()
 print("rc", lib.grpg_debug_ds_trace(buf))
 for p in range(3):
+    t0s = [buf[(p * 4 + w) * 10 + 0] for w in range(4)]
+    t8s = [buf[(p * 4 + w) * 10 + 8] for w in range(4)]
+    base = min(t0s)
+    print("pass %d: workgroups 0 / 50 / 120 / 170 start at +%s us, end at +%s us of the first start" % (
+        p, " / ".join("%.2f" % ((t - base) / 100.0) for t in t0s), " / ".join("%.2f" % ((t - base) / 100.0) for t in t8s)))
     for w in range(4):
         t = [buf[(p * 4 + w) * 10 + i] for i in range(9)]
         print("pass %d wg-probe %d: " % (p, w) + "  ".join("%s +%.2fus" % (names[i], (t[i] - t[i - 1]) / 100.0) for i in range(1, 9)) + "  | total %.2f us" % ((t[8] - t[0]) / 100.0))
