@@ -251,6 +251,12 @@ std::atomic<int> g_binning_alg{[] {
   return (e && strcmp(e, "sort") == 0) ? GRPG_BINNING_ALG_SORT : GRPG_BINNING_ALG_HIER;
 }()};
 bool binning_is_hier() { return g_binning_alg.load() == GRPG_BINNING_ALG_HIER; }
+// GRPG_COARSE_EMIT=unfused: the coarse emit behind the two-launch offsets scan, as before round 5 (still the path
+// of grids beyond 255 x 255 tiles); read once.  For A/B runs and for the tests that keep that path covered.
+std::atomic<bool> g_unfused_coarse_emit{[] {
+  const char* e = getenv("GRPG_COARSE_EMIT");
+  return e && strcmp(e, "unfused") == 0;
+}()};
 
 int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit in b bits
   int b = 0;
@@ -834,7 +840,12 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       uint32_t* btotals = (uint32_t*)(binp + L.totals);
       uint2* cranges = (uint2*)(binp + L.cranges);
       tm.mark(2);
-      if (rect_sorted_by_sort)   // counts and rectangles are already in depth order
+      // counts and rectangles already in depth order (from the sort's last pass): the emit scans the offsets it
+      // needs itself from the block sums (binning.hip emit_coarse_fused_kernel); otherwise the two-launch scan
+      const bool fused_emit = rect_sorted_by_sort && emit_coarse_fused_ok(GL.nblocks_scan) && !g_unfused_coarse_emit.load();
+      if (fused_emit)
+        launch_offsets_reduce(stream, (uint32_t)P, &gh->V, tiles_sorted, block_sums, GL.nblocks_scan);
+      else if (rect_sorted_by_sort)
         launch_offsets_scan(stream, (uint32_t)P, &gh->V, tiles_sorted, nullptr, nullptr, offsets,
                             block_sums, GL.nblocks_scan, &gh->Rc, nullptr, emit_win, GL.emit_win_cap);
       else
@@ -843,9 +854,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                             rect_sorted);
       STAGE_CHECK("coarse offsets scan");
       tm.mark(3);
-      launch_emit_coarse(stream, &gh->V, &gh->Rc, ccap, sorted_gid, rect_sorted, offsets, emit_win,
-                         GL.emit_win_cap, sgx, sgy, ckey_a, cval_a, cpasses > 0 ? btable : nullptr,
-                         (1u << cbits0) - 1u, L.nchunks_coarse, cranges, NS);
+      if (fused_emit)
+        launch_emit_coarse_fused(stream, &gh->V, &gh->Rc, ccap, sorted_gid, tiles_sorted, block_sums,
+                                 GL.nblocks_scan, rect_sorted, sgx, ckey_a, cval_a, cpasses > 0 ? btable : nullptr,
+                                 (1u << cbits0) - 1u, L.nchunks_coarse, cranges, NS);
+      else
+        launch_emit_coarse(stream, &gh->V, &gh->Rc, ccap, sorted_gid, rect_sorted, offsets, emit_win,
+                           GL.emit_win_cap, sgx, sgy, ckey_a, cval_a, cpasses > 0 ? btable : nullptr,
+                           (1u << cbits0) - 1u, L.nchunks_coarse, cranges, NS);
       STAGE_CHECK("coarse emit");
       tm.mark(4);
       bool in_b = false;

@@ -265,6 +265,206 @@ void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc
       sgy, st_keys, vals, hist_table, hist_mask, nchunks, cranges, NS);
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: the coarse emit with the offsets scan's down-sweep inside it (one launch and one pass over
+// the counts fewer: scan_down wrote the V offsets and the window table only for this kernel to read
+// them back).  Preconditions (api.hip): the super-tile counts and rectangles arrive in depth order from
+// the fat sort's last pass, which drops culled Gaussians -- so EVERY one of the V entries owns >= 1
+// slot -- and the scan's reduce launch has left the sums of 2048-Gaussian blocks (<= FUSED_MAX_BLOCKS).
+// A workgroup owns EMIT_PER_BLOCK output slots [o0, o1):
+//   1. it scans the block sums itself (the spine: a few KB, L2-resident) -> total (= the coarse count,
+//      published by workgroup 0) and the block B0 that holds the owner of slot o0;
+//   2. it loads the counts of the 4096 Gaussians from B0's first one on and scans them: the owners of
+//      its slots lie among them (the owner of o0 is within B0's 2048, and 2048 slots have <= 2048
+//      owners behind it);
+//   3. then exactly emit_kernel<true>'s window logic on those offsets.
+// ------------------------------------------------------------------------------------------
+constexpr int FUSED_MAX_BLOCKS = 4 * EMIT_THREADS;   // 2048 blocks = 4 M Gaussians (the fat sort's limit)
+constexpr int FUSED_WIN = 2 * SC_CHUNK;              // Gaussians whose offsets a workgroup computes
+static_assert(FUSED_WIN == 8 * EMIT_THREADS, "8 counts per thread");
+static_assert(SC_CHUNK == EMIT_PER_BLOCK, "a slot block's owners must fit two Gaussian blocks");
+
+// inclusive scan of one value per thread over the 512-thread workgroup; s_wave: EMIT_WAVES words
+__device__ __forceinline__ uint32_t emit_block_inclusive(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += t;
+  }
+  __syncthreads();   // s_wave is reused across calls
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < EMIT_WAVES; w++) {
+    const uint32_t c = s_wave[w];
+    if ((uint32_t)w < wave) base += c;
+    sum += c;
+  }
+  *total = sum;
+  return base + inc;
+}
+
+__global__ void __launch_bounds__(EMIT_THREADS)
+emit_coarse_fused_kernel(const uint32_t* __restrict__ V_dev, uint32_t* __restrict__ Rc_out, const uint32_t R_cap,
+                         const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ counts,
+                         const uint32_t* __restrict__ block_sums, const uint32_t nblocks,
+                         const uint2* __restrict__ rect_sorted, const int sgx,
+                         uint32_t* __restrict__ st_keys, uint32_t* __restrict__ vals,
+                         uint32_t* __restrict__ hist_table /* [digit][nchunks], may be NULL */,
+                         const uint32_t hist_mask, const uint32_t nchunks,
+                         uint2* __restrict__ zero_ranges, const uint32_t nzero) {
+  __shared__ uint32_t s_spine[FUSED_MAX_BLOCKS];   // exclusive prefix of the block sums
+  __shared__ uint32_t s_off[FUSED_WIN];            // offsets of Gaussians G0 .. G0 + 4095
+  __shared__ uint32_t s_own[EMIT_PER_BLOCK];
+  __shared__ uint32_t s_wave[EMIT_WAVES];
+  __shared__ uint32_t s_hist[RS_MAX_RADIX];
+  __shared__ uint32_t s_win[3];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t o0 = blockIdx.x * EMIT_PER_BLOCK;
+  if (blockIdx.x == 0)
+    for (uint32_t i = tid; i < nzero; i += EMIT_THREADS) zero_ranges[i] = make_uint2(0u, 0u);
+  // ---- 1. the spine ----
+  uint32_t total;
+  {
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t b = 4 * tid + k;
+      v[k] = b < nblocks ? block_sums[b] : 0u;
+      sum += v[k];
+    }
+    uint32_t ex = emit_block_inclusive(sum, s_wave, &total) - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s_spine[4 * tid + k] = ex; ex += v[k]; }
+  }
+  if (blockIdx.x == 0 && tid == 0) *Rc_out = total;
+  const uint32_t R = min(total, R_cap);
+  if (o0 >= R) return;   // whole workgroup
+  const uint32_t o1 = min(R, o0 + EMIT_PER_BLOCK);
+  const uint32_t nG = *V_dev;
+#pragma unroll
+  for (int r = 0; r < EMIT_PER_BLOCK / EMIT_THREADS; r++) s_own[r * EMIT_THREADS + tid] = 0u;
+  if (tid < RS_MAX_RADIX) s_hist[tid] = 0u;
+  __syncthreads();
+  // the last block whose prefix is <= o0 (blocks without Gaussians sit at prefix == total > o0)
+  uint32_t B0;
+  {
+    uint32_t lo = 0, hi = nblocks - 1;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo + 1) / 2;
+      if (s_spine[mid] <= o0) lo = mid; else hi = mid - 1;
+    }
+    B0 = lo;
+  }
+  // ---- 2. offsets of the 4096 Gaussians from block B0 on ----
+  const uint32_t G0 = B0 * SC_CHUNK;
+  {
+    const uint32_t i0 = G0 + 8 * tid;
+    uint32_t c[8], sum = 0;
+    if (i0 + 8 <= nG) {   // G0 and 8 tid are multiples of 8, the array is 256-byte aligned
+      const uint4 a = reinterpret_cast<const uint4*>(counts + i0)[0], b = reinterpret_cast<const uint4*>(counts + i0)[1];
+      c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = i0 + k < nG ? counts[i0 + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += c[k];
+    uint32_t dummy;
+    uint32_t ex = emit_block_inclusive(sum, s_wave, &dummy) - sum + s_spine[B0];
+    if (tid < 2) s_win[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      s_off[8 * tid + k] = ex;
+      // window bounds: the owners of the first and the last slot (every Gaussian owns >= 1 slot: unique)
+      if (c[k] > 0u) {
+        if (ex <= o0 && o0 < ex + c[k]) s_win[0] = 8 * tid + k;
+        if (ex <= o1 - 1u && o1 - 1u < ex + c[k]) s_win[1] = 8 * tid + k;
+      }
+      ex += c[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t lo = s_win[0], hi = max(s_win[1], lo);   // local indices (Gaussian G0 + index)
+  const uint32_t nwin = hi - lo + 1;                      // <= 2049
+  const uint32_t* __restrict__ woff = s_off + lo;
+  // ---- 3. as emit_kernel<true>: run starts marked with the largest window index, then a max-scan ----
+  for (uint32_t j = tid; j < nwin; j += EMIT_THREADS) {
+    const uint32_t o = woff[j];
+    if (j > 0 && o < o1) atomicMax(&s_own[o - o0], j);   // j > 0  =>  o > o0
+  }
+  __syncthreads();
+  uint32_t own[4];
+  {
+    const uint4 v = reinterpret_cast<const uint4*>(s_own)[tid];
+    own[0] = v.x; own[1] = max(own[0], v.y); own[2] = max(own[1], v.z); own[3] = max(own[2], v.w);
+  }
+  uint32_t inc = own[3];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc = max(inc, t);
+  }
+  __syncthreads();   // s_wave: the scans above are done with it
+  if (lane == 63) s_wave[wave] = inc;
+  const uint32_t excl_w = __shfl_up(inc, 1, 64);
+  __syncthreads();
+  uint32_t before = lane > 0 ? excl_w : 0u;
+#pragma unroll
+  for (int w2 = 0; w2 < EMIT_WAVES - 1; w2++)
+    if ((uint32_t)w2 < wave) before = max(before, s_wave[w2]);
+  const uint32_t s0 = o0 + 4 * tid;
+  uint32_t key[4], val[4], gid4[4], k4[4], j4[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t j = max(own[r], before);
+    const bool on = s0 + r < o1;
+    j4[r] = j;
+    gid4[r] = on ? sorted_gid[G0 + lo + j] : 0u;
+    k4[r] = s0 + r - woff[j];
+  }
+  uint2 rc4[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) rc4[r] = (s0 + r < o1) ? rect_sorted[G0 + lo + j4[r]] : make_uint2(0u, 0u);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    key[r] = 0u; val[r] = 0u;
+    if (s0 + r < o1) {
+      emit_coarse_instance(gid4[r], k4[r], rc4[r], sgx, key[r], val[r]);
+      if (hist_table) atomicAdd(&s_hist[key[r] & hist_mask], 1u);
+    }
+  }
+  if (s0 + 3 < o1) {   // o0 is a multiple of 2048 and the arrays are 256-byte aligned
+    reinterpret_cast<uint4*>(st_keys)[s0 >> 2] = make_uint4(key[0], key[1], key[2], key[3]);
+    reinterpret_cast<uint4*>(vals)[s0 >> 2] = make_uint4(val[0], val[1], val[2], val[3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (s0 + r < o1) { st_keys[s0 + r] = key[r]; vals[s0 + r] = val[r]; }
+  }
+  if (hist_table) {   // pass-0 digit histogram of this chunk of the tile partition
+    __syncthreads();
+    if (tid <= hist_mask) hist_table[(size_t)tid * nchunks + blockIdx.x] = s_hist[tid];
+  }
+}
+
+bool emit_coarse_fused_ok(uint32_t nblocks_scan) { return nblocks_scan >= 1u && nblocks_scan <= (uint32_t)FUSED_MAX_BLOCKS; }
+
+void launch_emit_coarse_fused(hipStream_t s, const uint32_t* V_dev, uint32_t* Rc_out, uint32_t cap,
+                              const uint32_t* sorted_gid, const uint32_t* counts_sorted,
+                              const uint32_t* block_sums, uint32_t nblocks, const uint2* rect_sorted, int sgx,
+                              uint32_t* st_keys, uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask,
+                              uint32_t nchunks, uint2* cranges, uint32_t NS) {
+  const uint32_t grid = cap ? (cap + EMIT_PER_BLOCK - 1) / EMIT_PER_BLOCK : 1u;   // block 0 clears the runs
+  emit_coarse_fused_kernel<<<grid, EMIT_THREADS, 0, s>>>(V_dev, Rc_out, cap, sorted_gid, counts_sorted, block_sums,
+                                                         nblocks, rect_sorted, sgx, st_keys, vals, hist_table,
+                                                         hist_mask, nchunks, cranges, NS);
+}
+
 void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
                         const uint32_t* tile_keys, uint2* ranges, uint32_t T, uint32_t key_mask) {
   // ranges were zeroed by frame_init_kernel (same stream, earlier in the frame)

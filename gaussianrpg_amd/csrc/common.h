@@ -407,6 +407,14 @@ void launch_tile_ranges(hipStream_t s, const uint32_t* R_dev, uint32_t R_cap,
                         uint32_t key_mask = 0xFFFFFFFFu);
 
 // Hierarchical binning (hier_binning.hip; coarse emit in binning.hip).
+void launch_offsets_reduce(hipStream_t s, uint32_t n, const uint32_t* n_dev, const uint32_t* counts,
+                           uint32_t* block_sums, uint32_t nblocks);
+bool emit_coarse_fused_ok(uint32_t nblocks_scan);
+void launch_emit_coarse_fused(hipStream_t s, const uint32_t* V_dev, uint32_t* Rc_out, uint32_t cap,
+                              const uint32_t* sorted_gid, const uint32_t* counts_sorted,
+                              const uint32_t* block_sums, uint32_t nblocks, const uint2* rect_sorted, int sgx,
+                              uint32_t* st_keys, uint32_t* vals, uint32_t* hist_table, uint32_t hist_mask,
+                              uint32_t nchunks, uint2* cranges, uint32_t NS);
 void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc_dev, uint32_t cap,
                         const uint32_t* sorted_gid, const uint2* rect_sorted, const uint32_t* offsets,
                         const uint32_t* emit_win, uint32_t emit_win_cap, int sgx, int sgy, uint32_t* st_keys,

@@ -925,6 +925,15 @@ scan_down_kernel(const uint32_t n_cap, const uint32_t* __restrict__ n_dev,
   }
 }
 
+// the reduce launch alone: sums of SC_CHUNK-element blocks of `counts` (zeros beyond *n_dev) -- what the fused
+// coarse emit (binning.hip emit_coarse_fused_kernel) scans itself
+void launch_offsets_reduce(hipStream_t s, uint32_t n, const uint32_t* n_dev, const uint32_t* counts,
+                           uint32_t* block_sums, uint32_t nblocks) {
+  if (n == 0) return;
+  scan_reduce_kernel<<<nblocks, SC_THREADS, 0, s>>>(n, n_dev, counts, block_sums, nullptr, nullptr, nullptr,
+                                                     nullptr, nullptr);
+}
+
 void launch_offsets_scan(hipStream_t s, uint32_t n, const uint32_t* n_dev,
                          uint32_t* tiles_sorted, const uint32_t* gather_gid,
                          const uint32_t* tiles_by_id, uint32_t* offsets, uint32_t* block_sums,
