@@ -272,3 +272,26 @@ def binding_trace(wrapper_module, rec, backward_alias=None):
         out[scenario] = dict(calls=calls, returned=returned, input_grads=grads,
                              mark_visible_returns=rec.describe(vis), filter_returns=[rec.describe(t) for t in filt])
     return out
+
+
+def power_never_positive(conic):
+    """numpy restatement (fp32 like the device) of blend_math.h splat_power_never_positive: True where the computed
+    power2 provably cannot be positive for any pixel offset.  conic: [n, 3] float32 (a, b, c)."""
+    f = np.float32
+    log2e = f(1.4426950408889634)
+    A = (f(-0.5) * log2e) * conic[:, 0]; B = (-log2e) * conic[:, 1]; C = (f(-0.5) * log2e) * conic[:, 2]
+    a, c = -A, -C
+    k = np.maximum(f(7.62939453125e-06) * (a + c + np.abs(B)), f(1e-12))
+    with np.errstate(invalid="ignore"):   # inf - inf of non-finite conics: NaN compares false, like on the device
+        return (a > k) & (c > k) & ((a - k) * (c - k) > f(0.25) * B * B)
+
+
+def device_power2(conic, dx, dy):
+    """The device's power2 = fma(dy, fma(C, dy, fl(B dx)), fl(fl(A dx) dx)) on fp32 arrays (blend_math.h pair_power;
+    the fused steps through float64, which holds a product of two floats exactly)."""
+    f = np.float32
+    log2e = f(1.4426950408889634)
+    A = (f(-0.5) * log2e) * conic[:, 0]; B = (-log2e) * conic[:, 1]; C = (f(-0.5) * log2e) * conic[:, 2]
+    fma = lambda a, b, c: (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)  # noqa: E731
+    return fma(dy, fma(C, dy, B * dx), (A * dx) * dx)
+

@@ -11,7 +11,8 @@ import torch
 
 import oracle
 from gaussianrpg_amd import harness as hz
-from helpers import (FRAGILE_ATOL, assert_image_close, fixture_oracle_inputs, load_fixture, oracle_kwargs)
+from helpers import (FRAGILE_ATOL, assert_image_close, fixture_oracle_inputs, load_fixture, oracle_kwargs,
+                     power_never_positive)
 
 pytestmark = pytest.mark.gpu
 
@@ -211,16 +212,6 @@ def test_giant_splat_and_single_tile(dev):
     _check(_rasterize(dev, sc, cam1), o1, max_fragile_frac=0.5)
 
 
-def _never_positive(conic):
-    """numpy restatement of blend_math.h splat_power_never_positive (fp32 like the device)."""
-    f = np.float32
-    log2e = f(1.4426950408889634)
-    A = (f(-0.5) * log2e) * conic[:, 0]; B = (-log2e) * conic[:, 1]; C = (f(-0.5) * log2e) * conic[:, 2]
-    a, c = -A, -C
-    k = np.maximum(f(7.62939453125e-06) * (a + c + np.abs(B)), f(1e-12))
-    return (a > k) & (c > k) & ((a - k) * (c - k) > f(0.25) * B * B)
-
-
 def test_needle_splats_take_the_exact_accept_path(dev):
     """Round 5: batches whose survivors all have a safely definite conic skip the reference's `power > 0`
     compare (forward.cu:420; blend_math.h splat_power_never_positive).  Needles -- 2-D Gaussians hundreds of
@@ -240,7 +231,7 @@ def test_needle_splats_take_the_exact_accept_path(dev):
     o = oracle.forward(needles.means3D, needles.opacity, shs=needles.shs, scales=needles.scales,
                        rotations=needles.rotations, **oracle_kwargs(cam, 1))
     vis = o["radii"] > 0
-    unsafe = vis & ~_never_positive(o["conic_opacity"][:, :3].astype(np.float32))
+    unsafe = vis & ~power_never_positive(o["conic_opacity"][:, :3].astype(np.float32))
     assert unsafe[:n].sum() == n and unsafe[n:].sum() == 0, (int(unsafe[:n].sum()), int(unsafe[n:].sum()))
     lens = o["ranges"][:, 1] - o["ranges"][:, 0]
     assert (lens >= 256).sum() > 100 and lens.max() >= 2048   # quarter waves: the path that has the fast form
