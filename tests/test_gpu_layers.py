@@ -156,7 +156,10 @@ def test_layers_full_size_and_frame_time(dev):
     from helpers import PARITY_STATS
     PARITY_STATS.append(dict(test="test_layers_full_size_and_frame_time", plane="render_all_ms",
                              three_calls_ms=t3, one_pass_ms=t1, speedup=t3 / t1))
-    assert t1 * 2.0 <= t3, "one pass %.3f ms, three calls %.3f ms" % (t1, t3)
+    # measured 3.4x on a box of its own (2.79 -> 0.81 ms); the bar only guards against the one pass silently doing the
+    # three calls' work, and stays clear of what contention does to both sides (1.98x with four test processes
+    # sharing the GPU, tools/gpu_hunt.sh)
+    assert t1 * 1.4 <= t3, "one pass %.3f ms, three calls %.3f ms" % (t1, t3)
 
 
 # Randomised draws of tests/test_gpu_sweep.py (odd image sizes, P from 1 up, needles, screen-filling splats,
