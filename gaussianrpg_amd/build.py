@@ -143,6 +143,8 @@ EXPERIMENT_VARIANTS = {
     "sortlean": {"sort.hip": ["-DGRPG_SORT_LEAN"]},
     # round 5: only the class-0 workgroups run (images are wrong): how long is the chain of the longest
     # tiles with nothing beside it?  (+ the per-role trace of it, tools/trace_class0.py)
+    # round 5: the coarse emit behind the two-launch offsets scan again (what the fused emit is measured against)
+    "unfusedemit": {"api.hip": ["-DGRPG_UNFUSED_COARSE_EMIT"]},
     "only0": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0"]},
     "no0": {"render_fwd.hip": ["-DGRPG_RENDER_NO_CLASS0"]},
     "only0trace": {"render_fwd.hip": ["-DGRPG_RENDER_ONLY_CLASS0", "-DGRPG_TRACE"], "render_bwd.hip": ["-DGRPG_TRACE"]},

@@ -251,12 +251,13 @@ std::atomic<int> g_binning_alg{[] {
   return (e && strcmp(e, "sort") == 0) ? GRPG_BINNING_ALG_SORT : GRPG_BINNING_ALG_HIER;
 }()};
 bool binning_is_hier() { return g_binning_alg.load() == GRPG_BINNING_ALG_HIER; }
-// GRPG_COARSE_EMIT=unfused: the coarse emit behind the two-launch offsets scan, as before round 5 (still the path
-// of grids beyond 255 x 255 tiles); read once.  For A/B runs and for the tests that keep that path covered.
-std::atomic<bool> g_unfused_coarse_emit{[] {
-  const char* e = getenv("GRPG_COARSE_EMIT");
-  return e && strcmp(e, "unfused") == 0;
-}()};
+// -DGRPG_UNFUSED_COARSE_EMIT (experiment build `unfusedemit`): the coarse emit behind the two-launch offsets scan, as
+// before round 5 (still the path of grids beyond 255 x 255 tiles), for A/B runs on one box
+#ifdef GRPG_UNFUSED_COARSE_EMIT
+constexpr bool UNFUSED_COARSE_EMIT = true;
+#else
+constexpr bool UNFUSED_COARSE_EMIT = false;
+#endif
 
 int bits_for(uint32_t T) {  // smallest b with (1 << b) >= T, i.e. tile ids fit in b bits
   int b = 0;
@@ -842,7 +843,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       tm.mark(2);
       // counts and rectangles already in depth order (from the sort's last pass): the emit scans the offsets it
       // needs itself from the block sums (binning.hip emit_coarse_fused_kernel); otherwise the two-launch scan
-      const bool fused_emit = rect_sorted_by_sort && emit_coarse_fused_ok(GL.nblocks_scan) && !g_unfused_coarse_emit.load();
+      const bool fused_emit = rect_sorted_by_sort && emit_coarse_fused_ok(GL.nblocks_scan) && !UNFUSED_COARSE_EMIT;
       if (fused_emit)
         launch_offsets_reduce(stream, (uint32_t)P, &gh->V, tiles_sorted, block_sums, GL.nblocks_scan);
       else if (rect_sorted_by_sort)
