@@ -362,11 +362,27 @@ def train_leg(dev, steps=12, warmup=4, P=1_000_000):
                                           "render_backward_kernel launch, DESIGN.md §7), not HBM-bound"}}
 
 
+def _check_device_count(n):
+    """RCCL runs one rank per GPU: with fewer devices than ranks every rank would `set_device(local_rank)` and die
+    inside the communicator's init with an unreadable error.  Fail before anything is started, with the remedy.
+    (GRPG_BENCH_BACKEND=gloo is the single-GPU debugging aid: all ranks share cuda:0, no check.)"""
+    if os.environ.get("GRPG_BENCH_BACKEND", "nccl") != "nccl" or n <= 1:
+        return
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py: --gpus %d over RCCL needs %d ROCm devices, this node shows %d "
+                         "(HIP_VISIBLE_DEVICES=%s).  Run with --gpus %d, or -- for a single-GPU check of the "
+                         "multi-rank code path only -- GRPG_BENCH_BACKEND=gloo (ranks share cuda:0, frames are "
+                         "gathered through host memory)" % (n, n, have, os.environ.get("HIP_VISIBLE_DEVICES", "unset"),
+                                                           max(have, 1)))
+
+
 def _self_launch(n):
     """Re-run this very command line as n ranks of one node (the driver's N > 1 form, started by
     bench.py itself when no launcher set WORLD_SIZE); returns the launcher's exit code."""
     import socket
     import subprocess
+    _check_device_count(n)
     with socket.socket() as so:           # a free rendezvous port on the loopback interface
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -421,6 +437,7 @@ def main():
     if args.rendezvous_only:
         return _rendezvous_only(world, rank)
     assert torch.cuda.is_available(), "bench.py needs ROCm devices (no CPU fallback exists)"
+    _check_device_count(world)
     torch.set_num_threads(max(1, min(effective_cores() // max(world, 1), 16)))   # host-side scene synthesis
     # GRPG_BENCH_BACKEND=gloo is a single-GPU debugging aid only (all ranks share cuda:0, the
     # gather is staged through host memory); the real multi-GPU run uses RCCL ("nccl").
@@ -580,7 +597,17 @@ def main():
             ssum, nc = _C.stage_timing() if stage_timing else ([0.0] * 8, 0)
             return t1 - t0, ssum, nc
 
-        elapsed, stage_sum, ncalls = timed_region()
+        try:
+            elapsed, stage_sum, ncalls = timed_region()
+        except BaseException as exc:
+            # the launch-path evidence survives a failure of the timed region: how many
+            # ranks the communicator really joined was established during the warm-up
+            if rank == 0:
+                print(json.dumps({"error": "timed region failed: %r" % (exc,), "n_gpus": world,
+                                  "rccl_ranks_seen": ranks_seen[0],
+                                  "collective_backend": (("rccl" if backend == "nccl" else backend)
+                                                         if world > 1 else None)}), flush=True)
+            raise
 
         # short serial (one stream) pass: per-stage durations without the interference of the
         # overlapped frames, reported beside the timed-region figures
@@ -888,13 +915,26 @@ def main():
                                    "frames sharded round-robin over ranks" % NUM_FRAMES,
                        "P": P, "V_avg": V_avg, "R_avg": R_avg, "T": T_tiles, "width": W,
                        "height": H, "sh_degree": sc.sh_degree, "M": M, "S": 0,
-                       "streams_per_gpu": ns, "binning_mode": "exact" if args.binning_mode else "speculative",
+                       "streams_per_gpu": ns,
+                       "single_stream_frame_latency_ms": latency["median_ms"] if latency else None,
+                       "single_stream_op_device_ms": op_events["median_ms"] if op_events else None,
+                       "binning_mode": "exact" if args.binning_mode else "speculative",
                        "binning_algorithm": "hierarchical" if STAGES is STAGES_HIER else "sort",
                        "entry_point": ("GaussianRasterizer.forward" if args.entry == "forward"
                                        else "GaussianRasterizer.forward_deferred"),
                        "deferred_count": args.entry == "deferred", "frames_rendered_twice": redone_frames[0],
                        "gather_batch_frames": args.gather_batch if world > 1 else None,
                        "parallelism": "replicas x%d, frame-sharded, final uint8 gather" % world},
+            # ONE FRAME IN FLIGHT on one stream -- what the closed-loop simulator (simulator.py:226-243: pose in,
+            # image out, strictly sequential) and render.py's timer see; `value` above keeps three frames in flight
+            "single_stream": None if latency is None or op_events is None else {
+                "frame_latency_median_ms": latency["median_ms"],
+                "frames_per_s": 1000.0 / latency["median_ms"],
+                "op_device_time_median_ms": op_events["median_ms"],
+                "serial_stage_sum_ms": serial_sum_ms,
+                "what": "frame_latency: synchronize-bracketed wall time of op + clamp + uint8 pack per frame "
+                        "(render.py:30-60's timer); op_device_time: HIP events around the op alone; details under "
+                        "frame_latency / op_device_time"},
             "collective_backend": (("rccl" if backend == "nccl" else backend) if world > 1 else None),
             "rccl_ranks_seen": ranks_seen[0],     # all_reduce of ones over the job's process group
             "roofline": roof,

@@ -55,6 +55,22 @@ def test_launcher_mismatch_is_an_error_not_a_hang():
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
 
 
+def test_rccl_with_too_few_devices_fails_fast_with_the_remedy():
+    """`--gpus 2` over RCCL (the default backend) on a node with fewer than two devices: refused before any rank
+    is started, with a message that names the device count and the way out -- not N ranks dying inside RCCL's
+    init.  On a node that HAS two devices the same command simply forms the group."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the command succeeds (covered by the driver's multi-GPU run)")
+    env = _clean_env()
+    env.pop("GRPG_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "needs 2 ROCm devices" in p.stderr and "GRPG_BENCH_BACKEND=gloo" in p.stderr
+    assert "starting 2 ranks" not in p.stderr
+
+
 @pytest.mark.gpu
 def test_self_launched_two_ranks_render_on_one_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",

@@ -1,0 +1,67 @@
+"""-m gpu: parity at the TRUE size of the reference's only script that touches the op
+(script/test_gaussian_rasterization.py:6-87): P = 10 000 uniform-random Gaussians seen by the hard-coded
+KITTI-like camera at 1242 x 375, SH degree 0 with shs [P, 4, 3], first S = 0 and then S = 15 semantic channels.
+
+That scene is an overdraw stress: scales are uniform in [0, 1) a few units in front of the camera, so splats
+are up to 2250 px wide, num_rendered = 13.3 M (1.5 x the headline frame's) and almost every one of the 1872
+tiles holds 5-10 k entries (SURVEY.md section 4's probe of the real kernels reports the same counts).  It is
+the first long-list check of the semantic planes' MFMA path (render_fwd.hip SemAcc / sem_quad), which the
+rest of the suite only sees on toy lists, and of the S = 15 backward (render_bwd.hip) at that size.
+
+The script itself compares nothing ("Pass ... !" is printed when the call returns), so the checker is the
+oracle (OpenMP build, ~3 s per pass): integers bit-exact, every plane through assert_image_close, n_contrib
+exact on non-fragile pixels, gradients at the suite's array-level bars.
+"""
+import pytest
+import torch
+
+import oracle
+from gaussianrpg_amd import harness as hz
+from helpers import oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+W, H, P = 1242, 375, 10000
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X (no ROCm device visible)")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _openmp_oracle():
+    was = bool(getattr(oracle, "_use_omp", False))
+    oracle.use_openmp(True)
+    yield
+    oracle.use_openmp(was)
+
+
+def _semantics(S):
+    return torch.rand(P, S, generator=torch.Generator().manual_seed(1000 + S)) if S else None
+
+
+@pytest.mark.parametrize("S", [0, 15])
+def test_smoke_script_forward_true_size(dev, S):
+    """Test 1 (S = 0) and Test 2 (S = 15) of the script, bg = zeros(3), debug settings aside."""
+    from test_gpu_forward import _check, _rasterize
+    sc, cam = hz.smoke_scene(P, seed=0), hz.smoke_camera(W, H)
+    sem = _semantics(S)
+    o = oracle.forward(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                       semantics=sem, **oracle_kwargs(cam, sc.sh_degree))
+    assert o["num_rendered"] > 10_000_000          # the overdraw the script is known for
+    got = _rasterize(dev, sc, cam, semantics=sem)
+    if S:
+        assert got["semantic"].shape == (S, H, W)
+    # fragile pixels: 5.4 % of this frame (thousands of accept decisions per pixel, many near 1/255)
+    _check(got, o, max_fragile_frac=0.1)
+
+
+def test_smoke_script_backward_true_size_S15(dev):
+    """The S = 15 call of the script with a backward behind it: every gradient array (incl. dL_dsemantic) against
+    oracle.backward at 13.3 M tile instances."""
+    from test_gpu_backward import STRICT_MISS_FRAC_LONG_LISTS, _run
+    sc, cam = hz.smoke_scene(P, seed=0), hz.smoke_camera(W, H)
+    _run(dev, sc, cam, torch.zeros(3), S=15, seed=77, miss_frac=STRICT_MISS_FRAC_LONG_LISTS)
