@@ -153,6 +153,12 @@ EXPERIMENT_VARIANTS = {
                "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=4096"]},
     "pc16384": {"render_fwd.hip": ["-DGRPG_RENDER_PC_MIN=16384"], "api.hip": ["-DGRPG_RENDER_PC_MIN=16384"],
                 "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=16384"]},
+    # round 6: the layered kernel allocated for 3 waves per SIMD (168 VGPRs, no scratch) instead of 4
+    # round 6 (wrong images): the layered walk without the object layer's state / without the background layer's
+    "lay_noobj": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=1"]},
+    "lay_nobg": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=2"]},
+    "lay_none": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=3"]},
+    "layers3w": {"render_fwd.hip": ["-DGRPG_LAYERS_MIN_WAVES=3"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

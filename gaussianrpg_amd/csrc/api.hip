@@ -637,8 +637,13 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     // a training forward leaves blend checkpoints of its long tile lists behind the binning blob
     // (common.h CK_*; the backward starts its segments from them)
     const bool with_ckpt = (flags & GRPG_FORWARD_NO_BACKWARD) == 0u && S == 0;
-    // work-list classes of the frame's render (a layered frame: quarter waves for every non-empty tile)
-    const TileClasses frame_classes = layers ? tile_classes_layers() : tile_classes(S);
+    // work-list classes of the frame's render.  A layered frame: the plain frame's classes, plus one flag per tile
+    // -- does its list hold an object entry (preprocess sets the flags; they live in the image blob's checkpoint-count
+    // area, which only a training forward uses) -- that sends short tiles WITH objects down the quarter-wave path
+    unsigned char* const tile_obj = layers ? (unsigned char*)(img + IL.ck_count) : nullptr;
+    const uint32_t tile_obj_words = layers ? (T + 3u) / 4u : 0u;
+    const TileClasses frame_classes = layers ? tile_classes_layers(tile_obj, cam.gx) : tile_classes(S);
+    const LayerMarks marks = {layers ? layers->layer_class : nullptr, tile_obj, cam.gx};
     auto blob_bytes = [&](const BinLayout& L, uint32_t cap) {
       return L.total + (with_ckpt ? ckpt_bytes(ckpt_slots(cap)) : 0);
     };
@@ -663,14 +668,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
                       (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
                       geom + GL.zero_begin, GL.zero_end - GL.zero_begin,
-                      (flags & GRPG_FORWARD_NO_BACKWARD) == 0u);
+                      (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, (uint32_t*)tile_obj, tile_obj_words);
     uint2* rects = hier ? (uint2*)(geom + GL.rects) : nullptr;
     uint2* rect_sorted = (uint2*)(geom + GL.rect_sorted);
     uint4* pre_counts = (uint4*)(geom + GL.pre_counts);
     if (segs == nullptr) {
       launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                         cov3D_precomp, colors_precomp, cam, radii_int, rec_w, key_a, tiles, rects,
-                        fat_sort ? ds_table : nullptr, pre_counts);
+                        fat_sort ? ds_table : nullptr, pre_counts, marks);
     } else {
       // segment table: host structs -> pinned staging -> the geometry blob (asynchronous copy)
       if (!g_seg_staging)
@@ -695,7 +700,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
       HIP_TRY(hipMemcpyAsync(seg_dev, g_seg_staging, sizeof(SegmentDev) * (size_t)nseg,
                              hipMemcpyHostToDevice, stream));
       launch_preprocess_composed(stream, P, D, M, seg_dev, nseg, scale_modifier, cam, radii_int, rec_w,
-                                 key_a, tiles, rects, fat_sort ? ds_table : nullptr, pre_counts);
+                                 key_a, tiles, rects, fat_sort ? ds_table : nullptr, pre_counts, marks);
     }
     // num_rendered (and the coarse pair count) as sums of the per-Gaussian counts: in the pinned
     // word ~70 us into the frame, with an event behind it.  The host looks at it only after the
@@ -765,10 +770,10 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                            (uint32_t)(L.total / 256), ckpt_slots(cap)};
       if (layers)
         launch_render_layers(stream, ranges, const_cast<uint32_t*>(point_list), rec, width, height, cam.gx, cam.gy,
-                             background, out_color, out_depth, out_alpha, work, frame_classes, &gh->R, cap,
-                             classified, layers->layer_class, layers->layer_background, layers->out_color_bg,
+                             background, out_color, out_depth, out_alpha, work, frame_classes, cap,
+                             classified, layers->layer_background, layers->out_color_bg,
                              layers->out_alpha_bg, layers->out_color_obj, layers->out_alpha_obj,
-                             segs ? (const SegmentDev*)(geom + GL.seg_table) : nullptr, nseg);
+                             PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3});
       else
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, frame_classes, cap,
@@ -967,11 +972,12 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     HIP_TRY(hipMemsetAsync(out_alpha, 0, N * 4, stream));
     if (S > 0 && out_semantic) HIP_TRY(hipMemsetAsync(out_semantic, 0, (size_t)S * N * 4, stream));
     HIP_TRY(hipMemsetAsync(n_contrib, 0, N * 4, stream));
-    if (layers) {   // like the other planes of an empty call: zeros
-      HIP_TRY(hipMemsetAsync(layers->out_color_bg, 0, 3 * N * 4, stream));
-      HIP_TRY(hipMemsetAsync(layers->out_alpha_bg, 0, N * 4, stream));
-      HIP_TRY(hipMemsetAsync(layers->out_color_obj, 0, 3 * N * 4, stream));
-      HIP_TRY(hipMemsetAsync(layers->out_alpha_obj, 0, N * 4, stream));
+    if (layers) {
+      // ONE contract for an empty layer: its colour plane is layer_background, its alpha plane zero --
+      // what the kernels write for an empty class when P > 0, and what the reference's render_kernel returns for a
+      // model set without Gaussians (street_gaussian_renderer.py:131-144: ones on a white background, acc zeros)
+      launch_fill_layer_planes(stream, N, layers->layer_background, layers->out_color_bg, layers->out_alpha_bg,
+                               layers->out_color_obj, layers->out_alpha_obj);
     }
     char* bin = binning_alloc(bin_layout(0).total, binning_user);
     if (!bin) return fail(GRPG_ERR_ALLOC, "binning buffer allocation failed");

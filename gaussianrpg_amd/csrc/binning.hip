@@ -46,7 +46,8 @@ __device__ __forceinline__ uint32_t last_leq(const uint32_t* __restrict__ a, uin
 __device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k, const float4 r0,
                                               const float4 r1, const int gx, const int gy,
                                               uint32_t& key, uint32_t& val) {
-  const int radius = __float_as_int(r0.w);
+  const int radius = (int)(__float_as_uint(r0.w) & ~REC_CLASS_BIT);
+  const uint32_t cls = (__float_as_uint(r0.w) & REC_CLASS_BIT) ? POINT_CLASS_BIT : 0u;   // layered frames only
   int minx, miny, maxx, maxy;
   get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
   const uint32_t w = (uint32_t)(maxx - minx);
@@ -62,7 +63,7 @@ __device__ __forceinline__ void emit_instance(const uint32_t g, const uint32_t k
   // of the value, so render knows before loading a record whether it is needed.
   const uint32_t bits = quarter_reach_mask(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, (float)(tx * TILE),
                                            (float)(ty * TILE));
-  val = g | (bits << SUBTILE_SHIFT);
+  val = g | cls | (bits << SUBTILE_SHIFT);
 }
 
 // Coarse instance (hierarchical binning, hier_binning.hip): slot k of Gaussian g's SUPER-TILE
@@ -539,10 +540,11 @@ frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint
                   const uint32_t V_init, const uint32_t Rcap, const uint32_t W, const uint32_t H,
                   const uint32_t S, uint2* __restrict__ ranges, const uint32_t T,
                   uint32_t* __restrict__ work, uint4* __restrict__ zero16, const size_t nzero16,
-                  const uint32_t geom_has_grad) {
+                  const uint32_t geom_has_grad, uint32_t* __restrict__ zero_words, const uint32_t n_zero_words) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = t; i < nzero16; i += stride) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = t; i < n_zero_words; i += stride) zero_words[i] = 0u;   // layered frame: object-tile bit rows
   if (ranges)
     for (size_t i = t; i < T; i += stride) ranges[i] = make_uint2(0u, 0u);
   if (work && t < 4) { work[t] = 0u; work[4 + 4 * (size_t)T + t] = 0u; }   // list counters, bwd_ctl
@@ -560,7 +562,8 @@ frame_init_kernel(BlobHeader* geom, BlobHeader* bin, BlobHeader* img, const uint
 
 void launch_frame_init(hipStream_t s, char* geom, char* bin, char* img, uint32_t P, uint32_t V_init,
                        uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S, uint2* ranges, uint32_t T,
-                       uint32_t* work, char* zero_begin, size_t zero_bytes, bool geom_has_grad) {
+                       uint32_t* work, char* zero_begin, size_t zero_bytes, bool geom_has_grad,
+                       uint32_t* zero_words, uint32_t n_zero_words) {
   const size_t nzero16 = zero_bytes / 16;   // the region is 256-byte aligned at both ends
   size_t items = nzero16 > (size_t)T ? nzero16 : (size_t)T;
   uint32_t blocks = (uint32_t)((items + 255) / 256);
@@ -568,7 +571,8 @@ void launch_frame_init(hipStream_t s, char* geom, char* bin, char* img, uint32_t
   if (blocks > 2048) blocks = 2048;
   frame_init_kernel<<<blocks, 256, 0, s>>>((BlobHeader*)geom, (BlobHeader*)bin, (BlobHeader*)img, P,
                                             V_init, Rcap, W, H, S, ranges, T, work,
-                                            (uint4*)zero_begin, nzero16, geom_has_grad ? 1u : 0u);
+                                            (uint4*)zero_begin, nzero16, geom_has_grad ? 1u : 0u,
+                                            zero_words, zero_words ? n_zero_words : 0u);
 }
 
 // Binning-blob header alone (the blob was sized after num_rendered became known), or a re-run of

@@ -36,6 +36,11 @@ constexpr int SUBTILE_SHIFT = 28;
 //   a = { px, py, depth, opacity }   b = { conic.x, conic.y, conic.z, R }
 //   c = { G, B, clamp bits, radius bits }
 // ---------------------------------------------------------------------------------------
+// Layered frames: preprocess parks the Gaussian's class (object = 1) in bit 30 of the radius word (radii stay far
+// below 2^30); the point-list fill, which has the record's first sector in registers anyway, turns it into bit 27
+// of every list entry (POINT_CLASS_BIT) -- round 5 marked the R entries in a pass of its own (40 us at R = 8.8 M).
+constexpr uint32_t REC_CLASS_BIT = 1u << 30;
+constexpr uint32_t POINT_CLASS_BIT = 1u << 27;   // == render_fwd.hip LAYER_BIT; ids < 2^27 in a layered frame
 constexpr int REC_F4 = 3;           // float4 per LDS slot of a staged record
 constexpr int REC_STRIDE = 4;       // float4 per Gaussian in HBM (64 bytes)
 struct RecView {
@@ -315,15 +320,50 @@ inline ImgLayout img_layout(size_t T, size_t N) {
 constexpr uint32_t RENDER_PC_MIN = GRPG_RENDER_PC_MIN, RENDER_C1_MIN = GRPG_RENDER_C1_MIN, RENDER_HEAVY_MIN = 256;
 constexpr int RENDER_NSEM = 16;   // semantic channels fused into the main render launch
 static_assert(RENDER_HEAVY_MIN <= CK_LONG_MIN, "lists with blend checkpoints must take the heavy path");
-struct TileClasses { uint32_t c0_min, c1_min, heavy_min; };
+// A LAYERED frame (grpg_forward_layers) knows, per tile, whether its list holds an entry of an OBJECT-class
+// Gaussian: one byte per tile, set by preprocess from the object Gaussians' tile rectangles (every tile of the
+// rectangle gets a list entry, rasterizer_impl.cu:98-108, so the flag is exact) and cleared by frame_init.  Plain
+// byte stores of the value 1 -- no read-modify-write: atomicOr on bit rows was tried first and cost preprocess
+// 95 us (63 k object Gaussians hammering ~300 words with memory-side atomics; the plain pre-check in front of them
+// reads the XCD's own L2 and never sees the bits).  The render walks a tile WITHOUT object entries with one blend
+// state and the plain frame's kernel paths (its three planes follow from that one state); a tile WITH object
+// entries carries three states.
+struct TileObjBits {
+  const unsigned char* flags;   // [T], NULL: not a layered frame
+  int gx;
+  __host__ __device__ bool tile(const uint32_t t) const { return flags[t] != 0; }
+};
+#ifndef GRPG_LAYERS_PC_MIN      // experiment builds: from how many entries a tile WITH object entries gets a producer
+#define GRPG_LAYERS_PC_MIN 2048 // wave and one consumer wave per layer (render_fwd.hip pc3_*)
+#endif
+constexpr uint32_t LAYERS_PC_MIN = GRPG_LAYERS_PC_MIN;
+struct TileClasses { uint32_t c0_min, c1_min, heavy_min; TileObjBits obj; uint32_t c0_obj_min; };
 inline TileClasses tile_classes(int S) {
-  return TileClasses{RENDER_PC_MIN, RENDER_C1_MIN, S > 0 ? 1u : RENDER_HEAVY_MIN};
+  return TileClasses{RENDER_PC_MIN, RENDER_C1_MIN, S > 0 ? 1u : RENDER_HEAVY_MIN, TileObjBits{nullptr, 0}, RENDER_PC_MIN};
 }
-// a LAYERED frame (grpg_forward_layers): every non-empty tile down the quarter-wave path, no wave pairs
-inline TileClasses tile_classes_layers() { return TileClasses{0xFFFFFFFFu, RENDER_C1_MIN, 1u}; }
+// a LAYERED frame: the plain frame's classes (wave pairs for the longest tiles, quarter waves, light tiles); a
+// short tile WITH object entries takes the quarter-wave path (three states at four pixels per lane do not fit
+// the register file)
+inline TileClasses tile_classes_layers(const unsigned char* obj_flags, int gx) {
+  return TileClasses{RENDER_PC_MIN, RENDER_C1_MIN, RENDER_HEAVY_MIN, TileObjBits{obj_flags, gx}, LAYERS_PC_MIN};
+}
 __host__ __device__ inline int tile_class(const uint32_t len, const TileClasses tc) {
   return len >= tc.c0_min ? 0 : (len >= tc.c1_min ? 1 : (len >= tc.heavy_min ? 2 : 3));
 }
+// class of tile t (list length len); the object flags are device memory
+__host__ __device__ inline int tile_class_of(const uint32_t t, const uint32_t len, const TileClasses tc) {
+  if (tc.obj.flags == nullptr || len == 0u || !tc.obj.tile(t)) return tile_class(len, tc);
+  // a tile WITH object entries (layered frame): class 0 = one producer + three consumer waves per quarter, the
+  // rest on three-state quarter waves (never the four-pixel light path)
+  return len >= tc.c0_obj_min ? 0 : (len >= tc.c1_min ? 1 : 2);
+}
+// what preprocess needs to set those bits: the class of Gaussian idx (flat frames: layer_class[idx]; composed
+// frames: its model's, segment table) and the bit rows
+struct LayerMarks {
+  const unsigned char* layer_class;   // [P] or NULL (composed frame: SegmentDev::pad1 & 1)
+  unsigned char* tile_obj;            // [T] flags, NULL = not a layered frame
+  int gx;
+};
 
 // ------------------------------- launchers (one per .hip TU) ---------------------------
 struct CameraArgs {
@@ -341,7 +381,8 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles,
                        uint2* rects /* packed tile rectangles (hierarchical binning), or NULL */,
                        uint32_t* ds_table0 /* pass-0 counts of the fat depth sort, or NULL */,
-                       uint4* pre_counts /* [ceil(P/256)] per-workgroup (instances, coarse pairs, min key, max key), or NULL */);
+                       uint4* pre_counts /* [ceil(P/256)] per-workgroup (instances, coarse pairs, min key, max key), or NULL */,
+                       LayerMarks lm = LayerMarks{nullptr, nullptr, 0} /* layered frame: object-tile bits */);
 // sums pre_counts -> pinned host words [0] num_rendered, [1] coarse pairs; header words R_pre,
 // Rc_pre, key_base, key_far (sort.hip)
 void launch_publish_counts(hipStream_t s, const uint4* pre_counts, uint32_t nblocks,
@@ -350,7 +391,7 @@ void launch_publish_counts(hipStream_t s, const uint4* pre_counts, uint32_t nblo
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
                                 uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                                uint32_t* ds_table0, uint4* pre_counts);
+                                uint32_t* ds_table0, uint4* pre_counts, LayerMarks lm = LayerMarks{nullptr, nullptr, 0});
 void launch_compose(hipStream_t s, int P, int M, const SegmentDev* segs, int nseg, float* means3D,
                     float* scales, float* rotations, float* opacities, float* shs);
 void launch_visible_filter(hipStream_t s, int P, const float* means3D, const float* scales,
@@ -461,16 +502,16 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            const PCErr pc_err, const float* semantics /* [P][S] or NULL */, int S,
                            float* out_semantic /* the first min(S, RENDER_NSEM) planes are written here */);
 uint32_t render_pc_slots(uint32_t R);   // render_fwd.hip
-// one walk, three blend states: the composition + the background-only and objects-only planes
-// (grpg_forward_layers); marks the class of every point-list entry first (bit 27)
+// a layered frame's render (grpg_forward_layers): the composition's planes + the background-only and objects-only
+// planes from one walk; the list entries carry their class (bit 27), cls.obj says which tiles hold object entries
 void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_list, const RecView rec, int W, int H,
                           int gx, int gy, const float* bg, float* out_color, float* out_depth, float* out_alpha,
-                          uint32_t* work, TileClasses cls, const uint32_t* R_dev, uint32_t cap, bool classified,
-                          const unsigned char* layer_class /* [P]: 0 background, 1 object */,
+                          uint32_t* work, TileClasses cls, uint32_t cap, bool classified,
                           const float* layer_background /* [3] */, float* out_color_bg, float* out_alpha_bg,
-                          float* out_color_obj, float* out_alpha_obj,
-                          const SegmentDev* seg_table = nullptr /* composed frame: class per model (pad1 & 1) */,
-                          int nseg = 0);
+                          float* out_color_obj, float* out_alpha_obj, const PCErr pc_err);
+// P == 0 call of a layered frame: both layers empty (colour = layer_background, alpha = 0)
+void launch_fill_layer_planes(hipStream_t s, size_t N, const float* layer_background, float* color_bg, float* alpha_bg,
+                              float* color_obj, float* alpha_obj);
 // channels [c_begin, S) of the semantic planes (stand-alone kernel)
 void launch_render_semantic(hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                             const RecView rec, const float* semantics, int S, int c_begin, int W, int H,
@@ -508,7 +549,8 @@ void launch_frame_init(hipStream_t s, char* geom, char* bin /* may be NULL */, c
                        uint32_t V_init, uint32_t Rcap, uint32_t W, uint32_t H, uint32_t S,
                        uint2* ranges /* zeroed, may be NULL */, uint32_t T,
                        uint32_t* work /* render counters zeroed, may be NULL */, char* zero_begin,
-                       size_t zero_bytes, bool geom_has_grad /* -> geometry header has_grad_rec */);
+                       size_t zero_bytes, bool geom_has_grad /* -> geometry header has_grad_rec */,
+                       uint32_t* zero_words = nullptr /* layered frame: the object-tile flags */, uint32_t n_zero_words = 0);
 void launch_bin_header(hipStream_t s, char* bin, uint32_t P, uint32_t Rcap, uint32_t W, uint32_t H,
                        uint32_t S, uint2* ranges /* zeroed, may be NULL */, uint32_t T,
                        uint32_t* work /* zeroed, may be NULL */);

@@ -297,7 +297,7 @@ hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
         ranges[t] = v[k] ? make_uint2(min(ex, R_cap), min(ex + v[k], R_cap)) : make_uint2(0u, 0u);
       }
       const uint32_t len = min(ex + v[k], R_cap) - min(ex, R_cap);
-      cls[k] = t >= T ? -1 : tile_class(len, tc);
+      cls[k] = t >= T ? -1 : tile_class_of(t, len, tc);
       n01 += cls[k] == 0 ? 1u : (cls[k] == 1 ? 0x10000u : 0u);
       n23 += cls[k] == 2 ? 1u : (cls[k] == 3 ? 0x10000u : 0u);
       ex += v[k];
@@ -404,7 +404,8 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t e = i * HB_FILL_THREADS + tid;
       const QuarterPre q = quarter_pre(g1[i].x, g1[i].y, g1[i].z, g0[i].z);
-      s_gid[e] = gid[i];
+      // (layered frame: the class bit of the record becomes bit 27 of the list entries; 0 in every other frame)
+      s_gid[e] = gid[i] | ((__float_as_uint(g0[i].w) & REC_CLASS_BIT) ? POINT_CLASS_BIT : 0u);
       s_m[e] = (uint16_t)(key[i] >> 16);      // entries beyond n carry mask 0
       s_fl[e] = (uint8_t)((q.sane ? 1u : 0u) | (q.transparent ? 2u : 0u));
       s_xy[e] = make_float2(g0[i].x, g0[i].y);

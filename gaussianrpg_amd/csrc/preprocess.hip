@@ -142,6 +142,39 @@ __device__ __forceinline__ void block_count_sums(const uint32_t my_tiles, const 
                                         max(max(s_cnt[3], s_cnt[7]), max(s_cnt[11], s_cnt[15])));
 }
 
+// Layered frames (common.h TileObjBits): an OBJECT-class Gaussian flags every tile of its rectangle (plain byte
+// stores of 1: every writer stores the same value, nothing is read back inside this launch).  A rectangle of up to
+// MARK_SMALL tiles is flagged by its own thread; larger ones (a metre-sized splat near the camera covers thousands
+// of tiles: one thread looping over them held its whole workgroup for 40 us) are handed to the wave.
+constexpr int MARK_SMALL = 16;
+struct MarkRect { int minx, miny, maxx, maxy; };
+__device__ __forceinline__ void mark_object_tiles(const LayerMarks lm, const int minx, const int miny,
+                                                  const int maxx, const int maxy) {
+  for (int ty = miny; ty < maxy; ty++)
+    for (int tx = minx; tx < maxx; tx++) lm.tile_obj[(size_t)ty * lm.gx + tx] = 1;
+}
+// all lanes of the wave (reconverged): the rectangles of the lanes with `big`, 64 tiles per step
+__device__ __forceinline__ void mark_object_tiles_wave(const LayerMarks lm, const bool big, const MarkRect r) {
+  const int lane = (int)(threadIdx.x & 63);
+  for (uint64_t todo = __ballot(big); todo != 0ull; todo &= todo - 1ull) {
+    const int l = (int)__builtin_ctzll(todo);
+    const int x0 = __builtin_amdgcn_readlane(r.minx, l), y0 = __builtin_amdgcn_readlane(r.miny, l);
+    const int w = __builtin_amdgcn_readlane(r.maxx, l) - x0, h = __builtin_amdgcn_readlane(r.maxy, l) - y0;
+    if (w >= 64) {          // rows of >= 64 tiles: lanes along the row
+      for (int ty = 0; ty < h; ty++)
+        for (int tx = lane; tx < w; tx += 64) lm.tile_obj[(size_t)(y0 + ty) * lm.gx + x0 + tx] = 1;
+    } else {                // narrow: 64 / w rows per step (w < 64: float division is exact enough, corrected)
+      const int n = w * h;
+      for (int i = lane; i < n; i += 64) {
+        int ty = (int)((float)i * __builtin_amdgcn_rcpf((float)w));
+        ty -= (ty * w > i) ? 1 : 0;
+        ty += ((ty + 1) * w <= i) ? 1 : 0;
+        lm.tile_obj[(size_t)(y0 + ty) * lm.gx + x0 + (i - ty * w)] = 1;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_kernel(const int P, const int D, const int M, const float* __restrict__ means3D,
                   const float* __restrict__ scales, const float scale_modifier,
@@ -156,7 +189,7 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
                   uint2* __restrict__ rects /* packed tile rectangles (hierarchical binning), or NULL */,
                   uint32_t* __restrict__ ds_table0 /* [chunk][DS_RADIX] pass-0 counts of the fat depth sort, or NULL */,
                   uint4* __restrict__ pre_counts /* [workgroups] (instances, coarse pairs, min key, max key) */,
-                  const int vec_ok /* means3D, scales, shs are 16-byte aligned */) {
+                  const int vec_ok /* means3D, scales, shs are 16-byte aligned */, const LayerMarks lm) {
   // The 64-byte records leave through LDS: every thread stages its record, then the workgroup
   // stores the 16 KB slab with consecutive lanes on consecutive 16-byte pieces (whole sectors, fully
   // coalesced; a lane-per-record store would touch 64 sectors per instruction).  Culled Gaussians
@@ -196,6 +229,8 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
   const int idx = base + threadIdx.x;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   uint32_t my_key = CULLED_KEY, my_tiles = 0u, my_st = 0u;
+  bool mark_big = false;   // layered frame: an object Gaussian whose rectangle the wave flags together
+  MarkRect mark_rect = {0, 0, 0, 0};
   float mx = 0.f, my = 0.f, mz = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (idx < P) {
     mx = s_mean[3 * threadIdx.x]; my = s_mean[3 * threadIdx.x + 1]; mz = s_mean[3 * threadIdx.x + 2];
@@ -252,13 +287,20 @@ preprocess_kernel(const int P, const int D, const int M, const float* __restrict
         rects[idx] = rc;
         my_st = rect_super_tiles(rc.x, rc.y);
       }
+      uint32_t cls_bit = 0u;   // layered frame: the class rides in the record (common.h REC_CLASS_BIT)
+      if (lm.tile_obj != nullptr && lm.layer_class[idx] != 0) {
+        if (my_tiles <= (uint32_t)MARK_SMALL) mark_object_tiles(lm, o.minx, o.miny, o.maxx, o.maxy);
+        else { mark_big = true; mark_rect = MarkRect{o.minx, o.miny, o.maxx, o.maxy}; }
+        cls_bit = REC_CLASS_BIT;
+      }
       depth_key[idx] = __float_as_uint(o.depth);
       my_key = __float_as_uint(o.depth);
-      r0 = make_float4(o.px, o.py, opac, __int_as_float(o.radius));
+      r0 = make_float4(o.px, o.py, opac, __uint_as_float((uint32_t)o.radius | cls_bit));
       r1 = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
       r2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
     }
   }
+  if (lm.tile_obj != nullptr) mark_object_tiles_wave(lm, mark_big, mark_rect);
   s_out[REC_STRIDE * threadIdx.x + 0] = r0;
   s_out[REC_STRIDE * threadIdx.x + 1] = r1;
   s_out[REC_STRIDE * threadIdx.x + 2] = r2;
@@ -359,7 +401,7 @@ preprocess_composed_kernel(const int P, const int D, const int M,
                            const float focal_y, int* __restrict__ radii, float4* __restrict__ rec,
                            uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles,
                            uint2* __restrict__ rects, uint32_t* __restrict__ ds_table0,
-                           uint4* __restrict__ pre_counts) {
+                           uint4* __restrict__ pre_counts, const LayerMarks lm) {
   __shared__ float4 s_out[256 * REC_STRIDE];
   __shared__ uint32_t s_dh[DS_RADIX];
 #pragma unroll
@@ -368,6 +410,8 @@ preprocess_composed_kernel(const int P, const int D, const int M,
   const int idx = base + threadIdx.x;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
   uint32_t my_key = CULLED_KEY, my_tiles = 0u, my_st = 0u;
+  bool mark_big = false;   // layered frame: an object Gaussian whose rectangle the wave flags together
+  MarkRect mark_rect = {0, 0, 0, 0};
   if (idx < P) {
     const SegmentDev& sg = *find_segment(segs, nseg, (uint32_t)idx);
     const uint32_t j = (uint32_t)idx - sg.start;
@@ -405,13 +449,20 @@ preprocess_composed_kernel(const int P, const int D, const int M,
         rects[idx] = rc;
         my_st = rect_super_tiles(rc.x, rc.y);
       }
+      uint32_t cls_bit = 0u;   // layered frame: the class rides in the record (common.h REC_CLASS_BIT)
+      if (lm.tile_obj != nullptr && ((uint32_t)(uintptr_t)sg.pad1 & 1u)) {
+        if (my_tiles <= (uint32_t)MARK_SMALL) mark_object_tiles(lm, o.minx, o.miny, o.maxx, o.maxy);
+        else { mark_big = true; mark_rect = MarkRect{o.minx, o.miny, o.maxx, o.maxy}; }
+        cls_bit = REC_CLASS_BIT;
+      }
       depth_key[idx] = __float_as_uint(o.depth);
       my_key = __float_as_uint(o.depth);
-      r0 = make_float4(o.px, o.py, a.opacity, __int_as_float(o.radius));
+      r0 = make_float4(o.px, o.py, a.opacity, __uint_as_float((uint32_t)o.radius | cls_bit));
       r1 = make_float4(o.conic[0], o.conic[1], o.conic[2], o.depth);
       r2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamped));
     }
   }
+  if (lm.tile_obj != nullptr) mark_object_tiles_wave(lm, mark_big, mark_rect);
   s_out[REC_STRIDE * threadIdx.x + 0] = r0;
   s_out[REC_STRIDE * threadIdx.x + 1] = r1;
   s_out[REC_STRIDE * threadIdx.x + 2] = r2;
@@ -441,13 +492,13 @@ preprocess_composed_kernel(const int P, const int D, const int M,
 void launch_preprocess_composed(hipStream_t s, int P, int D, int M, const SegmentDev* segs, int nseg,
                                 float scale_modifier, const CameraArgs& cam, int* radii, float4* rec,
                                 uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                                uint32_t* ds_table0, uint4* pre_counts) {
+                                uint32_t* ds_table0, uint4* pre_counts, LayerMarks lm) {
   if (P <= 0) return;
 #define PC_LAUNCH(M4)                                                                           \
   preprocess_composed_kernel<M4><<<(P + 255) / 256, 256, 0, s>>>(                                \
       P, D, M, segs, nseg, scale_modifier, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx,  \
       cam.gy, cam.tan_fovx, cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, \
-      rects, ds_table0, pre_counts)
+      rects, ds_table0, pre_counts, lm)
   if (M == 4) PC_LAUNCH(true); else PC_LAUNCH(false);
 #undef PC_LAUNCH
 }
@@ -464,13 +515,13 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, const CameraArgs& cam, int* radii,
                        float4* rec, uint32_t* depth_key, uint32_t* tiles, uint2* rects,
-                       uint32_t* ds_table0, uint4* pre_counts) {
+                       uint32_t* ds_table0, uint4* pre_counts, LayerMarks lm) {
   if (P <= 0) return;
   preprocess_kernel<<<(P + 255) / 256, 256, 0, s>>>(
       P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
       colors_precomp, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.gx, cam.gy, cam.tan_fovx,
       cam.tan_fovy, cam.focal_x, cam.focal_y, radii, rec, depth_key, tiles, rects, ds_table0,
-      pre_counts, ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0);
+      pre_counts, ((((uintptr_t)means3D | (uintptr_t)scales | (uintptr_t)shs) & 15) == 0) ? 1 : 0, lm);
 }
 
 

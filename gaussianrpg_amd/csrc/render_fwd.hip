@@ -40,6 +40,10 @@
 #include "blend_math.h"
 #include "common.h"
 
+#ifndef GRPG_LAYERS_ABLATE
+#define GRPG_LAYERS_ABLATE 0
+#endif
+
 namespace grpg {
 
 constexpr int RW_WAVES = 4;
@@ -63,7 +67,7 @@ classify_tiles_kernel(const uint32_t T, const uint2* __restrict__ ranges, const 
   if (t < T) {
     const uint2 r = ranges[t];
     const uint32_t len = r.y - r.x;
-    cls = tile_class(len, tc);
+    cls = tile_class_of(t, len, tc);
   }
   // wave-aggregated slot allocation: one atomic per (wave, class) instead of one per tile
   // (9600 same-address atomics serialise at ~11 ns each = 100 us, measured)
@@ -428,19 +432,85 @@ __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
   return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// Where a wave's final per-pixel state goes.  One body per frame kind, so that every path of the launch (light
+// tiles, quarter waves, the pairs' consumers) writes the same planes:
+//   PlainOut   the op's planes: colour on the background, depth, alpha (= 1 - T), n_contrib (AUX)
+//   LayersOut  a LAYERED frame (grpg_forward_layers, below): the composition's planes plus the two layer pairs.
+//              pixel(): a tile WITHOUT object entries was walked with ONE state -- the background layer's chain
+//              saw the very same splats (same bits), the object layer saw none (T = 1, C = 0);
+//              pixel3(): a tile with object entries, three states.
+// ------------------------------------------------------------------------------------------
+struct PlainOut {
+  const float* bg; float* out_color; float* out_depth; float* out_alpha; uint32_t* n_contrib;
+  int W, H;
+  template <bool AUX>
+  __device__ __forceinline__ void pixel(const int px, const int py, const float T, const v2f CrCg, const v2f CbD,
+                                        const uint32_t last) const {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    out_color[pix] = CrCg.x + T * bg[0];
+    out_color[HW + pix] = CrCg.y + T * bg[1];
+    out_color[2 * HW + pix] = CbD.x + T * bg[2];
+    out_alpha[pix] = 1.0f - T;
+    out_depth[pix] = CbD.y;
+    if (AUX) n_contrib[pix] = last;
+  }
+};
+
+struct LayerOut {
+  const float* bg_layer;     // [3] background of the two layer planes (the reference renders them on white)
+  float* color_bg; float* alpha_bg; float* color_obj; float* alpha_obj;
+};
+
+struct LayersOut {
+  const float* bg; float* out_color; float* out_depth; float* out_alpha;
+  int W, H;
+  LayerOut lo;
+  // the composition's planes / the background layer's / the object layer's, from that layer's final state
+  __device__ __forceinline__ void pixel_a(const int px, const int py, const float T, const v2f CrCg, const v2f CbD) const {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    out_color[pix] = CrCg.x + T * bg[0];
+    out_color[HW + pix] = CrCg.y + T * bg[1];
+    out_color[2 * HW + pix] = CbD.x + T * bg[2];
+    out_alpha[pix] = 1.0f - T;
+    out_depth[pix] = CbD.y;
+  }
+  __device__ __forceinline__ void pixel_layer(float* __restrict__ color, float* __restrict__ alpha, const int px,
+                                              const int py, const float T, const v2f CrCg, const v2f CbD) const {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    color[pix] = CrCg.x + T * lo.bg_layer[0];
+    color[HW + pix] = CrCg.y + T * lo.bg_layer[1];
+    color[2 * HW + pix] = CbD.x + T * lo.bg_layer[2];
+    alpha[pix] = 1.0f - T;
+  }
+  __device__ __forceinline__ void pixel_b(const int px, const int py, const float T, const v2f CrCg, const v2f CbD) const {
+    pixel_layer(lo.color_bg, lo.alpha_bg, px, py, T, CrCg, CbD);
+  }
+  __device__ __forceinline__ void pixel_o(const int px, const int py, const float T, const v2f CrCg, const v2f CbD) const {
+    pixel_layer(lo.color_obj, lo.alpha_obj, px, py, T, CrCg, CbD);
+  }
+  __device__ __forceinline__ void pixel3(const int px, const int py, const float Ta, const v2f CrCga, const v2f CbDa,
+                                         const float Tb, const v2f CrCgb, const v2f CbDb,
+                                         const float To, const v2f CrCgo, const v2f CbDo) const {
+    pixel_a(px, py, Ta, CrCga, CbDa);
+    pixel_b(px, py, Tb, CrCgb, CbDb);
+    pixel_o(px, py, To, CrCgo, CbDo);
+  }
+  template <bool AUX>
+  __device__ __forceinline__ void pixel(const int px, const int py, const float T, const v2f CrCg, const v2f CbD,
+                                        const uint32_t) const {
+    pixel3(px, py, T, CrCg, CbD, T, CrCg, CbD, 1.0f, (v2f){0.f, 0.f}, (v2f){0.f, 0.f});
+  }
+};
+
 struct WaveTrace { uint32_t batches, survivors, blends, t_stage, t_loop; uint32_t it[4], cyc[4]; };
 
-template <int PX, int GPI, bool WRITE_AUX, bool TRACE = false>
+template <int PX, int GPI, bool WRITE_AUX, bool TRACE = false, class Out = PlainOut>
 __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int lane,
                                            const uint32_t r_begin, const uint32_t r_end,
                                            const int x0, const int y0, const int W, const int H,
                                            const uint32_t* __restrict__ point_list,
-                                           const RecView rec,
-                                           const float* __restrict__ bg,
-                                           float* __restrict__ out_color,
-                                           float* __restrict__ out_depth,
-                                           float* __restrict__ out_alpha,
-                                           uint32_t* __restrict__ n_contrib,
+                                           const RecView rec, const Out& out,
                                            WaveTrace* tr = nullptr, const int ablate = 0) {
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
@@ -545,20 +615,10 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     __builtin_amdgcn_wave_barrier();
   }
 
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const size_t HW = (size_t)H * W;
 #pragma unroll
   for (int k = 0; k < PX; k++) {
     const int py = py0 + k;
-    if (px < W && py < H) {
-      const size_t pix = (size_t)py * W + px;
-      out_color[pix] = st.CrCg[k].x + st.T[k] * bg0;
-      out_color[HW + pix] = st.CrCg[k].y + st.T[k] * bg1;
-      out_color[2 * HW + pix] = st.CbD[k].x + st.T[k] * bg2;
-      out_alpha[pix] = 1.0f - st.T[k];
-      out_depth[pix] = st.CbD[k].y;
-      if (WRITE_AUX) n_contrib[pix] = st.last[k];
-    }
+    if (px < W && py < H) out.template pixel<WRITE_AUX>(px, py, st.T[k], st.CrCg[k], st.CbD[k], st.last[k]);
   }
 }
 
@@ -634,15 +694,16 @@ struct ListStream {
   __device__ __forceinline__ bool exhausted() const { return wpos + 256u * q >= r_end; }
   // Appends the entries of sub-window v (first entry e0 for this lane) whose mask has `bit` to the ring, in
   // list order: lane-major, then the lane's four entries.
-  // also != 0: an entry must additionally have one of those bits (a layered frame's "objects only" phase).
+  // wmask / wval: an entry must additionally satisfy (entry & wmask) == wval -- a layered frame's "objects only"
+  // (LAYER_BIT, LAYER_BIT) and "no objects" (LAYER_BIT, 0) phases; (0, 0) keeps everything.
   __device__ __forceinline__ void append(const uint4 v, const uint32_t e0, uint32_t* __restrict__ qid,
                                          uint32_t* __restrict__ qpos, const uint32_t bit, const uint32_t head,
-                                         uint32_t& count, const uint64_t lt, const uint32_t also) const {
-    const uint32_t any = also ? also : ~0u;
-    const bool k0 = (e0 >= r_begin) && (e0 < r_end) && (v.x & bit) && (v.x & any);
-    const bool k1 = (e0 + 1u >= r_begin) && (e0 + 1u < r_end) && (v.y & bit) && (v.y & any);
-    const bool k2 = (e0 + 2u >= r_begin) && (e0 + 2u < r_end) && (v.z & bit) && (v.z & any);
-    const bool k3 = (e0 + 3u >= r_begin) && (e0 + 3u < r_end) && (v.w & bit) && (v.w & any);
+                                         uint32_t& count, const uint64_t lt, const uint32_t wmask,
+                                         const uint32_t wval) const {
+    const bool k0 = (e0 >= r_begin) && (e0 < r_end) && (v.x & bit) && ((v.x & wmask) == wval);
+    const bool k1 = (e0 + 1u >= r_begin) && (e0 + 1u < r_end) && (v.y & bit) && ((v.y & wmask) == wval);
+    const bool k2 = (e0 + 2u >= r_begin) && (e0 + 2u < r_end) && (v.z & bit) && ((v.z & wmask) == wval);
+    const bool k3 = (e0 + 3u >= r_begin) && (e0 + 3u < r_end) && (v.w & bit) && ((v.w & wmask) == wval);
     const uint64_t m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
     uint32_t sl = head + count + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt) +
                   (uint32_t)__popcll(m2 & lt) + (uint32_t)__popcll(m3 & lt);
@@ -657,17 +718,17 @@ struct ListStream {
   // room for 256 entries.  q is wave-uniform: scalar branches, each naming its register.
   __device__ __forceinline__ void fill(uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos, const uint32_t bit,
                                        const uint32_t head, uint32_t& count, const int lane, const uint64_t lt,
-                                       const uint32_t also = 0u) {
+                                       const uint32_t wmask = 0u, const uint32_t wval = 0u) {
     const uint32_t e0 = wpos + 256u * q + 4u * (uint32_t)lane;
     switch (q) {
-      case 0u: append(c0, e0, qid, qpos, bit, head, count, lt, also); break;
-      case 1u: append(c1, e0, qid, qpos, bit, head, count, lt, also); break;
-      case 2u: append(c2, e0, qid, qpos, bit, head, count, lt, also); break;
-      case 3u: append(c3, e0, qid, qpos, bit, head, count, lt, also); break;
-      case 4u: append(c4, e0, qid, qpos, bit, head, count, lt, also); break;
-      case 5u: append(c5, e0, qid, qpos, bit, head, count, lt, also); break;
-      case 6u: append(c6, e0, qid, qpos, bit, head, count, lt, also); break;
-      default: append(c7, e0, qid, qpos, bit, head, count, lt, also); break;
+      case 0u: append(c0, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      case 1u: append(c1, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      case 2u: append(c2, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      case 3u: append(c3, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      case 4u: append(c4, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      case 5u: append(c5, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      case 6u: append(c6, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
+      default: append(c7, e0, qid, qpos, bit, head, count, lt, wmask, wval); break;
     }
     if (++q == (uint32_t)SUB) { q = 0; wpos += SPAN; if (wpos < r_end) refill(lane); }
   }
@@ -747,19 +808,14 @@ __device__ __forceinline__ void sem_write(const SemAcc<NSEM>& sa, const int S, f
     if (c < S && inside) out_semantic[(size_t)c * HW + pix] = (c < 8 ? t_lo : t_hi)[(c & 7) * WAVE + lane];
 }
 
-template <bool TRACE, bool AUX = true, int NSEM = 0>
+template <bool TRACE, bool AUX = true, int NSEM = 0, class Out = PlainOut>
 __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
                                             uint32_t* __restrict__ qpos, const int lane,
                                             const int quarter, const uint32_t r_begin,
                                             const uint32_t r_end, const int x0, const int y0,
                                             const int W, const int H,
                                             const uint32_t* __restrict__ point_list,
-                                            const RecView rec,
-                                            const float* __restrict__ bg,
-                                            float* __restrict__ out_color,
-                                            float* __restrict__ out_depth,
-                                            float* __restrict__ out_alpha,
-                                            uint32_t* __restrict__ n_contrib, WaveTrace* tr,
+                                            const RecView rec, const Out& out, WaveTrace* tr,
                                             CkptWriter ckw, const SemSrc sem = SemSrc{nullptr, 0, nullptr},
                                             float* __restrict__ out_semantic = nullptr,
                                             float* __restrict__ semrows = nullptr /* LDS: WAVE x SEM_ROW */) {
@@ -894,19 +950,9 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   }
   if (AUX) ckpt_finish(ckw, lane, st, r_end - r_begin);
 
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const size_t HW = (size_t)H * W;
-  if (px < W && py < H) {
-    const size_t pix = (size_t)py * W + px;
-    out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
-    out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
-    out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
-    out_alpha[pix] = 1.0f - st.T[0];
-    out_depth[pix] = st.CbD[0].y;
-    if (AUX) n_contrib[pix] = st.last[0];
-  }
+  if (px < W && py < H) out.template pixel<AUX>(px, py, st.T[0], st.CrCg[0], st.CbD[0], st.last[0]);
   if (NSEM > 0)   // (all lanes: the accumulators are spread over the wave; the ring is dead by now)
-    sem_write<NSEM>(sa, sem.S, out_semantic, HW, (size_t)py * W + px, px < W && py < H, lane,
+    sem_write<NSEM>(sa, sem.S, out_semantic, (size_t)H * W, (size_t)py * W + px, px < W && py < H, lane,
                     reinterpret_cast<float*>(qid), reinterpret_cast<float*>(qpos));
 }
 
@@ -1121,16 +1167,12 @@ __device__ __forceinline__ void pc_blend_batch(WavePix<1>& st, const float4* __r
   }
 }
 
-template <bool AUX = true, int NSEM = 0>
+template <bool AUX = true, int NSEM = 0, class Out = PlainOut>
 __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
                                             const float4* __restrict__ buf1,
                                             PCCtrl* __restrict__ ctl, const int lane,
                                             const int x0, const int y0, const int W, const int H,
-                                            const float* __restrict__ bg,
-                                            float* __restrict__ out_color,
-                                            float* __restrict__ out_depth,
-                                            float* __restrict__ out_alpha,
-                                            uint32_t* __restrict__ n_contrib, CkptWriter ckw,
+                                            const Out& out, CkptWriter ckw,
                                             const uint32_t len, const PCErr err,
                                             const SemSrc sem = SemSrc{nullptr, 0, nullptr},
                                             float* __restrict__ out_semantic = nullptr, WaveTrace* tr = nullptr,
@@ -1178,19 +1220,449 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
     }
   }
   if (AUX) ckpt_finish(ckw, lane, st, len);
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const size_t HW = (size_t)H * W;
-  if (px < W && py < H) {
-    const size_t pix = (size_t)py * W + px;
-    out_color[pix] = st.CrCg[0].x + st.T[0] * bg0;
-    out_color[HW + pix] = st.CrCg[0].y + st.T[0] * bg1;
-    out_color[2 * HW + pix] = st.CbD[0].x + st.T[0] * bg2;
-    out_alpha[pix] = 1.0f - st.T[0];
-    out_depth[pix] = st.CbD[0].y;
-    if (AUX) n_contrib[pix] = st.last[0];
-  }
+  if (px < W && py < H) out.template pixel<AUX>(px, py, st.T[0], st.CrCg[0], st.CbD[0], st.last[0]);
   if (NSEM > 0)
-    sem_write<NSEM>(sa, sem.S, out_semantic, HW, (size_t)py * W + px, px < W && py < H, lane, t_lo, t_hi);
+    sem_write<NSEM>(sa, sem.S, out_semantic, (size_t)H * W, (size_t)py * W + px, px < W && py < H, lane, t_lo, t_hi);
+}
+
+// ------------------------------------------------------------------------------------------
+// LAYERED frames (additive: grpg_forward_layers).  The reference's evaluation path renders every frame three
+// times -- all models, the background model alone, the object models alone
+// (lib/models/street_gaussian_renderer.py:13-40: render_all) -- i.e. three preprocess + binning chains and three
+// walks for what is ONE list walk with up to three blend states: a (pixel, splat) pair has one alpha; the
+// composition takes every splat, a layer the splats of its class.  A layer's transmittance chain sees alpha = 0
+// for the other class (T x 1, C + c x 0: exact no-ops), so each plane carries the very bits the op returns
+// for that subset of the scene.
+//   * every entry of the point list carries its Gaussian's class in bit 27 (set by the fill from the record, where
+//     preprocess parked it: common.h REC_CLASS_BIT; ids < 2^27);
+//   * preprocess leaves one flag per tile: does its list hold an OBJECT entry at all (common.h TileObjBits).
+//     Where it does not -- most of a street frame -- the background layer's chain IS the composition's and the
+//     object layer stays empty: the tile is walked with ONE state by the plain frame's own paths (wave pairs for
+//     the longest lists, quarter waves, four-pixel light waves: round 6; round 5 walked every tile with three
+//     states on quarter waves, 0.46 ms against the plain frame's 0.21) and LayersOut::pixel derives the planes;
+//   * a tile WITH object entries carries three states, one pixel per lane.  Short lists: one quarter wave holds
+//     all three (blend_heavy_layers), and even there the states FORK LATE: until the first object entry survives a
+//     batch's cull the background layer equals the composition bit for bit and is not computed, the object layer
+//     is empty -- a wave whose quarter no object reaches never forks.  Long lists (>= LAYERS_PC_MIN entries): a
+//     producer wave feeds THREE consumer waves, one per layer (pc3_* below);
+//   * a pixel is finished when all three states are: where no object ever saturates the walk goes on to the
+//     end of the list -- but once the composition and the background are through, FILL keeps OBJECT entries
+//     only (a dead entry costs 1/256 of a FILL step), and the cull box of the non-object entries is that of
+//     the pixels still live in the composition or the background.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t LAYER_BIT = POINT_CLASS_BIT;
+constexpr uint32_t LAYER_ID_MASK = LAYER_BIT - 1u;
+static_assert((ID_MASK & LAYER_BIT) != 0u, "the ring entries (id & ID_MASK) must keep the class bit");
+
+__device__ __forceinline__ void fresh_state(WavePix<1>& s, const uint64_t outside) {
+  s.T[0] = 1.0f; s.CrCg[0] = (v2f){0.f, 0.f}; s.CbD[0] = (v2f){0.f, 0.f}; s.last[0] = 0; s.done[0] = outside;
+}
+
+// class word of slot `slot` of a compacted batch: the spare words of its pair block's position float4
+__device__ __forceinline__ void store_slot_class(float4* __restrict__ my, const int slot, const uint32_t cls) {
+  reinterpret_cast<uint32_t*>(my + (slot >> 1) * PAIR_F4)[22 + (slot & 1)] = cls;
+}
+
+// one quad into the three states: alpha once, then the blend half per state with its own accept masks
+__device__ __forceinline__ void blend_quad_layers(WavePix<1>& sa, WavePix<1>& sb, WavePix<1>& so,
+                                                  const float4* __restrict__ my, const int j0,
+                                                  const float pxf, const float pyf, const int lane) {
+  const float4* blk = my + (j0 >> 1) * PAIR_F4;
+  QuadGeom g;
+  g.load(blk);
+  QuadColsReg<false> cols;
+  cols.load(blk);
+  const float4 p0 = blk[5], p1 = blk[PAIR_F4 + 5];
+  float alpha[4];
+  uint64_t ok[4];
+  eval_quad(g, pxf, pyf, alpha, ok);   // (the batch-level SAFE form costs this path 18 registers)
+  const uint32_t cls[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.z)),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.w)),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.z)),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.w))};
+  uint64_t okb[4], oko[4];
+  uint64_t anyb = 0ull, anyo = 0ull;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint64_t m = cls[i] ? ~0ull : 0ull;   // the slot's class, as a lane mask (wave-uniform)
+    okb[i] = ok[i] & ~m; oko[i] = ok[i] & m;
+    anyb |= okb[i]; anyo |= oko[i];
+  }
+  const SemSrc nosem = {nullptr, 0, nullptr};
+  SemAcc<0>* nosa = nullptr;
+  blend_quad_tail<false, 0>(sa, cols, alpha, ok, nosa, nosem, j0, lane);
+#if !(GRPG_LAYERS_ABLATE & 2)   // experiment builds (wrong images): what does a state cost?
+  if (anyb & ~sb.done[0]) blend_quad_tail<false, 0>(sb, cols, alpha, okb, nosa, nosem, j0, lane);
+#endif
+#if !(GRPG_LAYERS_ABLATE & 1)
+  if (anyo & ~so.done[0]) blend_quad_tail<false, 0>(so, cols, alpha, oko, nosa, nosem, j0, lane);
+#endif
+}
+
+// the three states of a quarter wave and what the walk needs to know about them
+struct Layers3 {
+  WavePix<1> a, b, o;   // composition, background layer, object layer; b and o are only kept once `forked`
+  bool forked;          // wave-uniform
+  uint64_t outside;
+  __device__ __forceinline__ void init(const uint64_t out_m) {
+    outside = out_m; forked = false;
+    fresh_state(a, out_m); b = a; o = a;
+  }
+  // an object entry is about to be blended for the first time: up to here the background layer has seen every
+  // splat the composition has (same bits), the object layer none
+  __device__ __forceinline__ void fork() { if (!forked) { b = a; forked = true; } }
+  __device__ __forceinline__ uint64_t live_ab() const { return forked ? ~(a.done[0] & b.done[0]) : ~a.done[0]; }
+#if GRPG_LAYERS_ABLATE & 1   // experiment build (wrong images): the object layer never keeps a walk alive
+  __device__ __forceinline__ uint64_t live_all() const { return live_ab(); }
+#else
+  __device__ __forceinline__ uint64_t live_all() const { return forked ? (live_ab() | ~o.done[0]) : ~outside; }
+#endif
+  template <class Out>
+  __device__ __forceinline__ void write(const Out& out, const int px, const int py, const int W, const int H) {
+    if (!forked) b = a;
+    if (px < W && py < H)
+      out.pixel3(px, py, a.T[0], a.CrCg[0], a.CbD[0], b.T[0], b.CrCg[0], b.CbD[0], o.T[0], o.CrCg[0], o.CbD[0]);
+  }
+};
+
+// quarter wave of a tile WITH object entries (no wave pair: lists below RENDER_PC_MIN)
+template <class Out>
+__device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint32_t* __restrict__ qid,
+                                                   uint32_t* __restrict__ qpos, const int lane, const int quarter,
+                                                   const uint32_t r_begin, const uint32_t r_end, const int x0,
+                                                   const int y0, const int W, const int H,
+                                                   const uint32_t* __restrict__ point_list, const RecView rec,
+                                                   const Out& out) {
+  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
+  const float pxf = (float)px;
+  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
+  const uint64_t lt = lanemask_lt();
+  Layers3 L;
+  L.init(lanes(!(px < W && py < H)));
+  // cull boxes: non-object entries against the pixels live in the composition or the background,
+  // object entries against those live in any state
+  float ax0 = (float)x0, ax1 = (float)(x0 + 15), ay0 = (float)y0, ay1 = (float)(y0 + 3);
+  float ox0 = ax0, ox1 = ax1, oy0 = ay0, oy1 = ay1;
+  uint64_t prev_ab = ~0ull, prev_all = ~0ull;
+
+  uint32_t head = 0, count = 0;
+  ListStream<4> ls;
+  ls.open(point_list, r_begin, r_end, lane);
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+  uint32_t pos = 0, idc = 0, ncur = 0;
+
+  for (;;) {
+    const uint64_t live_ab = L.live_ab();
+    const uint64_t live_all = L.live_all();
+    if (live_all == 0ull) break;
+    const bool need_ab = live_ab != 0ull;   // wave-uniform: the composition or the background still blends
+    if (live_ab != prev_ab && need_ab) {
+      prev_ab = live_ab;
+      const MaskBox m = mask_box(live_ab);
+      ax0 = (float)(x0 + m.c0); ax1 = (float)(x0 + m.c1); ay0 = (float)(y0 + m.r0); ay1 = (float)(y0 + m.r1);
+    }
+    if (live_all != prev_all) {
+      prev_all = live_all;
+      const MaskBox m = mask_box(live_all);
+      ox0 = (float)(x0 + m.c0); ox1 = (float)(x0 + m.c1); oy0 = (float)(y0 + m.r0); oy1 = (float)(y0 + m.r1);
+    }
+    // ---- FILL (the ring entry keeps the class bit: ID_MASK covers bit 27) ----
+    while (count < (uint32_t)WAVE && !ls.exhausted())
+      ls.fill(qid, qpos, bit, head, count, lane, lt, need_ab ? 0u : LAYER_BIT, need_ab ? 0u : LAYER_BIT);
+    __builtin_amdgcn_wave_barrier();
+    // ---- POP ----
+    const uint32_t nn = min(count, (uint32_t)WAVE);
+    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
+    uint32_t pos_n = 0, id_n = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (QCAP - 1);
+      id_n = qid[slot];
+      pos_n = qpos[slot];
+      rec.load(id_n & LAYER_ID_MASK, a_n, b_n, c_n);
+    }
+    head = (head + nn) & (QCAP - 1);
+    count -= nn;
+    // ---- BLEND the previous batch ----
+    if (ncur > 0) {
+      const bool is_obj = (idc & LAYER_BIT) != 0u;
+      const bool keep = ((uint32_t)lane < ncur) && (need_ab || is_obj) &&
+                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, is_obj ? ox0 : ax0, is_obj ? ox1 : ax1,
+                                           is_obj ? oy0 : ay0, is_obj ? oy1 : ay1);
+      const uint64_t mask = __ballot(keep);
+      const int cnt = (int)__popcll(mask);
+      if (__ballot(keep && is_obj) != 0ull) L.fork();
+      if (keep) {
+        const int slot = (int)__popcll(mask & lt);
+        store_pair_half(my, slot, a.x, a.y, splat_q(b.x, b.y, b.z), a.w, make_float4(b.w, c.x, c.y, a.z), pos);
+        store_slot_class(my, slot, is_obj ? 1u : 0u);
+      }
+      if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
+        const SplatQ zq = {0.f, 0.f, 0.f};
+        store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+        store_slot_class(my, cnt + lane, 0u);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (L.forked) {
+        for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad_layers(L.a, L.b, L.o, my, j0, pxf, (float)py, lane);
+      } else {   // one state: the plain quarter wave's quad
+        for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad<false, 0, false>(L.a, my, j0, pxf, (float)py);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
+    if (ncur == 0 && ls.exhausted()) break;
+  }
+  L.write(out, px, py, W, H);
+}
+
+// ------------------------------------------------------------------------------------------
+// Long tiles WITH object entries: ONE PRODUCER, THREE CONSUMERS (round 6).
+//
+// Three states on one consumer wave made its chain twice the plain consumer's (eval + three blend halves per
+// quad, the colour / class blocks fetched inside the quad: 0.41 ms for the class-0 tiles of a frame with ten
+// car-sized actors against 0.19 ms plain) -- and that chain is the launch.  A layer's chain depends on nothing but
+// the compacted batches, so each layer gets a consumer wave of its own: a quarter of such a tile is one workgroup,
+// wave 3 the producer (FILL / POP / cull / compaction into two LDS buffers, as pc_producer), waves 0 / 1 / 2 the
+// consumers of the composition, the background layer and the object layer.  Every consumer evaluates the quads
+// it needs itself (at the end of a launch the SIMDs are idle: recomputing alpha costs nothing that matters) and
+// blends with its class's accept masks -- the same arithmetic on the same operands as blend_quad_layers: the
+// same bits.  The object layer's consumer only touches quads that hold an object slot (a per-batch slot mask
+// from the producer), so it mostly sleeps.  Hand-over: per consumer a flag per buffer (as PCCtrl.flag), the
+// producer refills a buffer when every consumer that has not stopped has released it; every consumer keeps its
+// own live box (inverted once it stops), the producer culls non-object survivors against the union of the
+// composition's and the background's, object survivors against the composition's and the object layer's, and
+// drops a class altogether once nobody wants it.
+// ------------------------------------------------------------------------------------------
+struct PC3Ctrl {
+  uint32_t flag[3][2];      // [consumer][buffer]
+  uint32_t stop[3];
+  uint32_t pad;
+  uint32_t objmask[2][2];   // per buffer: which compacted slots hold an object-class splat (low / high word)
+  float box[3][4];
+};
+
+template <class Cond, class Stop>
+__device__ __forceinline__ bool pc_wait_until(const PCErr err, const int lane, Cond ready, Stop stopped) {
+  uint32_t spins = 0;
+  while (!ready()) {
+    if (stopped()) return false;
+    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+__device__ __forceinline__ void pc3_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
+                                             uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
+                                             PC3Ctrl* __restrict__ ctl, const int lane, const int quarter,
+                                             const uint32_t r_begin, const uint32_t r_end,
+                                             const uint32_t* __restrict__ point_list, const RecView rec,
+                                             const PCErr err) {
+  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
+  const uint64_t lt = lanemask_lt();
+  uint32_t head = 0, count = 0;
+  ListStream<8> ls;
+  ls.open(point_list, r_begin, r_end, lane);
+  float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, c0 = a0, a1 = a0, b1 = a0, c1 = a0;
+  uint32_t pos0 = 0, id0 = 0, pos1 = 0, id1 = 0, ncur = 0;
+  int cur = 0;
+  const auto put = [&](float4* __restrict__ my, const bool keep, const uint64_t mask, const int base,
+                       const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc) {
+    if (keep) {
+      const int slot = base + (int)__popcll(mask & lt);
+      store_pair_half(my, slot, a.x, a.y, splat_q(b.x, b.y, b.z), a.w, make_float4(b.w, c.x, c.y, a.z), pos);
+      store_slot_class(my, slot, (idc & LAYER_BIT) ? 1u : 0u);
+    }
+  };
+  const auto publish = [&](float4* __restrict__ my, const int cnt, const bool safe) {
+    if (lane < ((4 - (cnt & 3)) & 3)) {
+      const SplatQ zq = {0.f, 0.f, 0.f};
+      store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
+      store_slot_class(my, cnt + lane, 0u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the batch's object slots, in slot order: lane j reads the class word of slot j back
+    const uint32_t cw = lane < cnt ? reinterpret_cast<const uint32_t*>(my + (lane >> 1) * PAIR_F4)[22 + (lane & 1)] : 0u;
+    const uint64_t om = __ballot(cw != 0u);
+    if (lane == 0) { ctl->objmask[cur][0] = (uint32_t)om; ctl->objmask[cur][1] = (uint32_t)(om >> 32); }
+    const uint32_t f = ((uint32_t)cnt + 1u) | (safe ? PC_SAFE : 0u);
+    pc_store(&ctl->flag[0][cur], f);
+    pc_store(&ctl->flag[1][cur], f);
+    pc_store(&ctl->flag[2][cur], f);
+    cur ^= 1;
+  };
+  const auto all_stopped = [&]() {
+    return pc_load(&ctl->stop[0]) != 0u && pc_load(&ctl->stop[1]) != 0u && pc_load(&ctl->stop[2]) != 0u;
+  };
+  // buffer `cur` is free once every consumer still running has handed it back
+  const auto buffer_free = [&]() {
+    return (pc_load(&ctl->flag[0][cur]) == 0u || pc_load(&ctl->stop[0]) != 0u) &&
+           (pc_load(&ctl->flag[1][cur]) == 0u || pc_load(&ctl->stop[1]) != 0u) &&
+           (pc_load(&ctl->flag[2][cur]) == 0u || pc_load(&ctl->stop[2]) != 0u);
+  };
+  for (;;) {
+    const bool sA = pc_load(&ctl->stop[0]) != 0u, sB = pc_load(&ctl->stop[1]) != 0u, sO = pc_load(&ctl->stop[2]) != 0u;
+    if (sA && sB && sO) return;
+    // non-object entries feed the composition and the background layer, object entries the composition and
+    // the object layer (a stale "still running" only passes on entries nobody takes any more)
+    const bool need_n = !sA || !sB, need_o = !sA || !sO;
+    const uint32_t wmask = (need_n && need_o) ? 0u : LAYER_BIT, wval = need_n ? 0u : LAYER_BIT;
+    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt, wmask, wval);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nn = min(count, 2u * WAVE);
+    float4 a0n = make_float4(0, 0, 0, 0), b0n = a0n, c0n = a0n, a1n = a0n, b1n = a0n, c1n = a0n;
+    uint32_t pos0n = 0, id0n = 0, pos1n = 0, id1n = 0;
+    if ((uint32_t)lane < nn) {
+      const uint32_t slot = (head + lane) & (QCAP - 1);
+      id0n = qid[slot];
+      pos0n = qpos[slot];
+      rec.load(id0n & LAYER_ID_MASK, a0n, b0n, c0n);
+    }
+    if ((uint32_t)lane + WAVE < nn) {
+      const uint32_t slot = (head + WAVE + lane) & (QCAP - 1);
+      id1n = qid[slot];
+      pos1n = qpos[slot];
+      rec.load(id1n & LAYER_ID_MASK, a1n, b1n, c1n);
+    }
+    head = (head + nn) & (QCAP - 1);
+    count -= nn;
+    if (ncur > 0) {
+      // cull boxes: unions of the consumers' live boxes (a stopped consumer's box is inverted: contributes nothing)
+      const float nx0 = fminf(ctl->box[0][0], ctl->box[1][0]), nx1 = fmaxf(ctl->box[0][1], ctl->box[1][1]);
+      const float ny0 = fminf(ctl->box[0][2], ctl->box[1][2]), ny1 = fmaxf(ctl->box[0][3], ctl->box[1][3]);
+      const float ox0 = fminf(ctl->box[0][0], ctl->box[2][0]), ox1 = fmaxf(ctl->box[0][1], ctl->box[2][1]);
+      const float oy0 = fminf(ctl->box[0][2], ctl->box[2][2]), oy1 = fmaxf(ctl->box[0][3], ctl->box[2][3]);
+      const bool o0 = (id0 & LAYER_BIT) != 0u, o1 = (id1 & LAYER_BIT) != 0u;
+      const bool k0 = ((uint32_t)lane < ncur) && (o0 ? need_o : need_n) &&
+                      !splat_misses_rect(a0.x, a0.y, b0.x, b0.y, b0.z, a0.w, o0 ? ox0 : nx0, o0 ? ox1 : nx1,
+                                         o0 ? oy0 : ny0, o0 ? oy1 : ny1);
+      const bool k1 = ((uint32_t)lane + WAVE < ncur) && (o1 ? need_o : need_n) &&
+                      !splat_misses_rect(a1.x, a1.y, b1.x, b1.y, b1.z, a1.w, o1 ? ox0 : nx0, o1 ? ox1 : nx1,
+                                         o1 ? oy0 : ny0, o1 ? oy1 : ny1);
+      const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
+      const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1);
+      const bool safe0 = __ballot(k0 && !splat_power_never_positive(splat_q(b0.x, b0.y, b0.z))) == 0ull;
+      const bool safe1 = __ballot(k1 && !splat_power_never_positive(splat_q(b1.x, b1.y, b1.z))) == 0ull;
+      if (n0 + n1 > 0) {
+        if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;
+        float4* my = cur ? buf1 : buf0;
+        if (n0 + n1 <= WAVE) {
+          put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
+          put(my, k1, m1, n0, a1, b1, c1, pos1, id1);
+          publish(my, n0 + n1, safe0 && safe1);
+        } else {
+          put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
+          publish(my, n0, safe0);
+          if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;
+          my = cur ? buf1 : buf0;
+          put(my, k1, m1, 0, a1, b1, c1, pos1, id1);
+          publish(my, n1, safe1);
+        }
+      }
+    }
+    a0 = a0n; b0 = b0n; c0 = c0n; pos0 = pos0n; id0 = id0n;
+    a1 = a1n; b1 = b1n; c1 = c1n; pos1 = pos1n; id1 = id1n;
+    ncur = nn;
+    if (ncur == 0 && ls.exhausted()) break;
+  }
+  if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;   // end-of-list marker
+  pc_store(&ctl->flag[0][cur], PC_DONE);
+  pc_store(&ctl->flag[1][cur], PC_DONE);
+  pc_store(&ctl->flag[2][cur], PC_DONE);
+}
+
+// one handed-over batch for the consumer of layer ROLE (0 composition, 1 background layer, 2 object layer); om = the
+// batch's object slots.  ROLE 0 / 1: the plain consumer's pipelined loop (pc_blend_batch), the background layer
+// with the object slots' accept masks cleared; ROLE 2: only the quads that hold an object slot.
+template <int ROLE, bool SAFE>
+__device__ __forceinline__ void pc3_blend_batch(WavePix<1>& st, const float4* __restrict__ my, const int cnt,
+                                                const uint64_t om, const float pxf, const float pyf, const int lane) {
+  const SemSrc nosem = {nullptr, 0, nullptr};
+  SemAcc<0>* nosa = nullptr;
+  if (ROLE == 0) {
+    pc_blend_batch<false, 0, SAFE>(st, my, cnt, pxf, pyf, nosa, nosem, lane);
+  } else if (ROLE == 1) {
+    QuadGeom g_n;
+    g_n.load(my);
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+      const float4* blk = my + (j0 >> 1) * PAIR_F4;
+      const QuadGeom g = g_n;
+      QuadColsReg<false> col;
+      col.load(blk);
+      g_n.load(my + (min(j0 + 4, cnt - 1) >> 1) * PAIR_F4);
+      float alpha[4];
+      uint64_t ok[4];
+      eval_quad<SAFE>(g, pxf, pyf, alpha, ok);
+      const uint32_t cm = (uint32_t)(om >> j0) & 0xFu;   // (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < 4; i++) ok[i] = ((cm >> i) & 1u) ? 0ull : ok[i];
+      blend_quad_tail<false, 0>(st, col, alpha, ok, nosa, nosem, j0, lane);
+    }
+  } else {
+    for (uint64_t m = om; m != 0ull;) {
+      const int j0 = (int)__builtin_ctzll(m) & ~3;
+      const uint32_t cm = (uint32_t)(m >> j0) & 0xFu;
+      m &= ~(0xFull << j0);
+      const float4* blk = my + (j0 >> 1) * PAIR_F4;
+      QuadGeom g;
+      g.load(blk);
+      QuadColsReg<false> col;
+      col.load(blk);
+      float alpha[4];
+      uint64_t ok[4];
+      eval_quad<SAFE>(g, pxf, pyf, alpha, ok);
+#pragma unroll
+      for (int i = 0; i < 4; i++) ok[i] = ((cm >> i) & 1u) ? ok[i] : 0ull;
+      blend_quad_tail<false, 0>(st, col, alpha, ok, nosa, nosem, j0, lane);
+    }
+  }
+}
+
+template <int ROLE, class Out>
+__device__ __forceinline__ void pc3_consumer(const float4* __restrict__ buf0, const float4* __restrict__ buf1,
+                                             PC3Ctrl* __restrict__ ctl, const int lane, const int x0, const int y0,
+                                             const int W, const int H, const Out& out, const PCErr err) {
+  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
+  const float pxf = (float)px, pyf = (float)py;
+  WavePix<1> st;
+  fresh_state(st, lanes(!(px < W && py < H)));
+  uint64_t prev_alive = ~0ull;
+  int cur = 0;
+  const auto quit = [&]() {   // nothing left to blend here: take the box out of the producer's unions, then say so
+    if (lane == 0) { ctl->box[ROLE][0] = 3e38f; ctl->box[ROLE][1] = -3e38f; ctl->box[ROLE][2] = 3e38f; ctl->box[ROLE][3] = -3e38f; }
+    pc_store(&ctl->stop[ROLE], 1u);
+  };
+  if (~st.done[0] == 0ull) quit();   // quarter outside the image
+  else for (;;) {
+    uint32_t f = 0;
+    if (!pc_wait_until(err, lane, [&]() { f = pc_load(&ctl->flag[ROLE][cur]); return f != 0u; }, []() { return false; })) break;
+    if (f == PC_DONE) break;
+    const int cnt = (int)((f & (PC_SAFE - 1u)) - 1u);
+    const float4* my = cur ? buf1 : buf0;
+    uint64_t om = 0ull;
+    if (ROLE != 0)
+      om = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->objmask[cur][0]) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->objmask[cur][1]) << 32);
+    if (f & PC_SAFE) pc3_blend_batch<ROLE, true>(st, my, cnt, om, pxf, pyf, lane);
+    else pc3_blend_batch<ROLE, false>(st, my, cnt, om, pxf, pyf, lane);
+    pc_store(&ctl->flag[ROLE][cur], 0u);   // hand the buffer back
+    cur ^= 1;
+    const uint64_t alive = ~st.done[0];
+    if (alive == 0ull) { quit(); break; }
+    if (alive != prev_alive) {
+      prev_alive = alive;
+      const MaskBox b = mask_box(alive);
+      if (lane == 0) {
+        ctl->box[ROLE][0] = (float)(x0 + b.c0); ctl->box[ROLE][1] = (float)(x0 + b.c1);
+        ctl->box[ROLE][2] = (float)(y0 + b.r0); ctl->box[ROLE][3] = (float)(y0 + b.r1);
+      }
+    }
+  }
+  if (px < W && py < H) {
+    if (ROLE == 0) out.pixel_a(px, py, st.T[0], st.CrCg[0], st.CbD[0]);
+    else if (ROLE == 1) out.pixel_b(px, py, st.T[0], st.CrCg[0], st.CbD[0]);
+    else out.pixel_o(px, py, st.T[0], st.CrCg[0], st.CbD[0]);
+  }
 }
 
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
@@ -1200,11 +1672,22 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
 // staged rows per wave: 3 waves per SIMD / 3 workgroups per CU.
 constexpr int RENDER_MIN_WAVES = 4;
 
+template <bool LAYERS> struct FrameOut { typedef PlainOut type; };
+template <> struct FrameOut<true> { typedef LayersOut type; };
+__device__ __forceinline__ PlainOut make_out(const PlainOut& p, const LayerOut&, PlainOut*) { return p; }
+__device__ __forceinline__ LayersOut make_out(const PlainOut& p, const LayerOut& lo, LayersOut*) {
+  return LayersOut{p.bg, p.out_color, p.out_depth, p.out_alpha, p.W, p.H, lo};
+}
+
 // Measured and removed: XCD-contiguous work assignment (0.248 vs 0.232 ms:
 // neighbouring tiles are similarly long, contiguous eighths unbalance the XCDs), occupancy capped
 // with unused LDS, one splat per iteration in the light path, persistent waves.
-template <bool WRITE_AUX, int GPI_L, bool TRACE = false, int NSEM = 0>
-__global__ void __launch_bounds__(256, NSEM > 0 ? 3 : RENDER_MIN_WAVES)
+// LAYERS: a layered frame (above) -- the same launch structure, one state where the tile holds no object entry
+#ifndef GRPG_LAYERS_MIN_WAVES   // experiment builds: waves per SIMD the layered kernel is allocated for
+#define GRPG_LAYERS_MIN_WAVES 4
+#endif
+template <bool WRITE_AUX, int GPI_L, bool TRACE = false, int NSEM = 0, bool LAYERS = false>
+__global__ void __launch_bounds__(256, NSEM > 0 ? 3 : (LAYERS ? GRPG_LAYERS_MIN_WAVES : RENDER_MIN_WAVES))
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RecView rec, const int W, const int H, const int gx,
                       const uint32_t T, const uint32_t* __restrict__ work,
@@ -1213,7 +1696,12 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                       const uint32_t pc_slots, const CkptArgs ck, const PCErr pc_err,
                       const SemSrc sem, float* __restrict__ out_semantic,
-                      uint32_t* __restrict__ trace = nullptr, const int ablate = 0) {
+                      uint32_t* __restrict__ trace = nullptr, const int ablate = 0,
+                      const LayerOut lo = LayerOut{nullptr, nullptr, nullptr, nullptr, nullptr},
+                      const TileObjBits ob = TileObjBits{nullptr, 0}) {
+  static_assert(!LAYERS || (!WRITE_AUX && NSEM == 0 && !TRACE), "layered frames: evaluation only, no semantic planes");
+  typedef typename FrameOut<LAYERS>::type Out;
+  const Out out = make_out(PlainOut{bg, out_color, out_depth, out_alpha, n_contrib, W, H}, lo, (Out*)nullptr);
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
@@ -1245,14 +1733,42 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   if (blockIdx.x < pc_slots) return;
 #endif
   if (blockIdx.x < pc_slots) {
-    if (blockIdx.x >= 2u * n0) return;
-    const uint32_t tile = lists[blockIdx.x >> 1];
+    // a layered frame reserves FOUR workgroups per class-0 tile: one per quarter where the tile holds object
+    // entries (producer + three consumers, pc3_* above), the first two as half tiles otherwise
+    const uint32_t pc_ti = LAYERS ? blockIdx.x >> 2 : blockIdx.x >> 1;
+    const uint32_t pc_sub = LAYERS ? blockIdx.x & 3u : blockIdx.x & 1u;
+    if (pc_ti >= n0) return;
+    const uint32_t tile = lists[pc_ti];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    if constexpr (LAYERS) {
+      if (ob.tile(tile)) {   // (workgroup-uniform)
+        __shared__ PC3Ctrl s_ctl3;
+        const int q3 = (int)pc_sub, x03 = tx * TILE, y03 = ty * TILE + q3 * 4;
+        if (threadIdx.x == 0) {
+          for (int c = 0; c < 3; c++) {
+            s_ctl3.flag[c][0] = 0u; s_ctl3.flag[c][1] = 0u; s_ctl3.stop[c] = 0u;
+            s_ctl3.box[c][0] = (float)x03; s_ctl3.box[c][1] = (float)(x03 + 15);
+            s_ctl3.box[c][2] = (float)y03; s_ctl3.box[c][3] = (float)(y03 + 3);
+          }
+        }
+        __syncthreads();
+        if (wave == 3)
+          pc3_producer(s_rec[0], s_rec[1], s_qid[3], s_qpos[3], &s_ctl3, lane, q3, rb, re, point_list, rec, pc_err);
+        else if (wave == 0)
+          pc3_consumer<0>(s_rec[0], s_rec[1], &s_ctl3, lane, x03, y03, W, H, out, pc_err);
+        else if (wave == 1)
+          pc3_consumer<1>(s_rec[0], s_rec[1], &s_ctl3, lane, x03, y03, W, H, out, pc_err);
+        else
+          pc3_consumer<2>(s_rec[0], s_rec[1], &s_ctl3, lane, x03, y03, W, H, out, pc_err);
+        return;
+      }
+      if (pc_sub >= 2u) return;
+    }
     const int slot = wave & 1;                                   // quarter slot inside this workgroup
-    const int q = (int)(blockIdx.x & 1u) * 2 + slot;            // quarter of the tile
+    const int q = (int)pc_sub * 2 + slot;                        // quarter of the tile
     const int x0 = tx * TILE, y0 = ty * TILE + q * 4;
     if (wave < 2 && lane == 0) {   // the consumer initialises its quarter's control block
       s_ctl[slot].flag[0] = 0u; s_ctl[slot].flag[1] = 0u; s_ctl[slot].stop = 0u; s_ctl[slot].pad = 0u;
@@ -1262,8 +1778,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
     WaveTrace* const trp = TRACE ? &tr : nullptr;
     if (wave < 2) {
-      pc_consumer<WRITE_AUX, NSEM>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, bg, out_color,
-                  out_depth, out_alpha, n_contrib, ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err, sem,
+      pc_consumer<WRITE_AUX, NSEM>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, out,
+                  ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err, sem,
                   out_semantic, trp, s_sem[NSEM > 0 ? slot : 0], s_sem[NSEM > 0 ? slot + 2 : 0],
                   reinterpret_cast<float*>(s_qid[wave]), reinterpret_cast<float*>(s_qpos[wave]));
       if (WRITE_AUX && q == 0) ckpt_publish_items(ck, lane, tile, re - rb);
@@ -1296,10 +1812,16 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
     tr_tile = tile; tr_len = re - rb;
+    if constexpr (LAYERS) {
+      if (ob.tile(tile)) {   // object entries in the list: three states (forked late)
+        blend_heavy_layers(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE, ty * TILE + wave * 4,
+                           W, H, point_list, rec, out);
+        return;
+      }
+    }
     blend_heavy<TRACE, WRITE_AUX, NSEM>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,
-                       ty * TILE + wave * 4, W, H, point_list, rec, bg, out_color, out_depth,
-                       out_alpha, n_contrib, &tr, ckpt_writer(ck, tile, wave, rb, re), sem, out_semantic,
-                       s_sem[NSEM > 0 ? wave : 0]);
+                       ty * TILE + wave * 4, W, H, point_list, rec, out, &tr, ckpt_writer(ck, tile, wave, rb, re),
+                       sem, out_semantic, s_sem[NSEM > 0 ? wave : 0]);
     if (WRITE_AUX && wave == 0) ckpt_publish_items(ck, lane, tile, re - rb);
   } else {
     if (b >= nlwg) return;
@@ -1311,9 +1833,9 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
     tr_tile = tile | 0x80000000u; tr_len = re - rb;
+    // (a layered frame: light tiles hold no object entry -- the tile scan sends the others down the heavy path)
     blend_rect<4, GPI_L, WRITE_AUX, TRACE>(s_rec[wave], lane, rb, re, tx * TILE, ty * TILE, W, H,
-                                           point_list, rec, bg, out_color, out_depth, out_alpha,
-                                           n_contrib, &tr, ablate);
+                                           point_list, rec, out, &tr, ablate);
     if (NSEM > 0) {
       // a semantic frame sends every non-empty tile down the heavy path (tile_classes): what arrives
       // here holds no splat at all -- its semantic planes are zero (they get no background)
@@ -1337,268 +1859,43 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// LAYERED frames (round 5, additive: grpg_forward_layers).  The reference's evaluation path renders every
-// frame three times -- all models, the background model alone, the object models alone
-// (lib/models/street_gaussian_renderer.py:13-40: render_all) -- i.e. three preprocess + binning chains
-// and three walks for what is ONE list walk with three blend states: a (pixel, splat) pair has one alpha;
-// the composition takes every splat, a layer the splats of its class.  A layer's transmittance chain sees
-// alpha = 0 for the other class (T x 1, C + c x 0: exact no-ops), so each plane carries the very bits
-// the op returns for that subset of the scene.
-//   * every entry of the point list carries its Gaussian's class in bit 27 (layer_mark_kernel; ids < 2^27);
-//   * all non-empty tiles take the quarter-wave path (one pixel per lane has the registers for three
-//     states; no producer / consumer pairs: the longest tiles are plain heavy waves here);
-//   * a pixel is finished when all three states are: where no object ever saturates the walk goes on to
-//     the end of the list -- but once the composition and the background are through, FILL keeps OBJECT
-//     entries only (a dead entry costs 1/256 of a FILL step), and the cull box of the non-object
-//     entries is that of the pixels still live in the composition or the background.
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t LAYER_BIT = 1u << 27;
-constexpr uint32_t LAYER_ID_MASK = LAYER_BIT - 1u;
-static_assert((ID_MASK & LAYER_BIT) != 0u, "the ring entries (id & ID_MASK) must keep the class bit");
-
 __global__ void __launch_bounds__(256)
-layer_mark_kernel(uint32_t* __restrict__ point_list, const uint32_t* __restrict__ R_dev, const uint32_t cap,
-                  const uint8_t* __restrict__ layer_class) {
-  const uint32_t n = min(*R_dev, cap);
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const uint32_t v = point_list[i];
-    if (layer_class[v & LAYER_ID_MASK] != 0) point_list[i] = v | LAYER_BIT;
+fill_layer_planes_kernel(const size_t N, const float* __restrict__ layer_background, float* __restrict__ color_bg,
+                         float* __restrict__ alpha_bg, float* __restrict__ color_obj, float* __restrict__ alpha_obj) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+    for (int c = 0; c < 3; c++) { color_bg[c * N + i] = layer_background[c]; color_obj[c * N + i] = layer_background[c]; }
+    alpha_bg[i] = 0.f; alpha_obj[i] = 0.f;
   }
 }
-
-// composed frames: the class of a Gaussian is its model's (segment table in the geometry blob: start, count,
-// class in the low bits of pad1)
-__global__ void __launch_bounds__(256)
-layer_mark_segments_kernel(uint32_t* __restrict__ point_list, const uint32_t* __restrict__ R_dev, const uint32_t cap,
-                           const SegmentDev* __restrict__ segs, const int nseg) {
-  __shared__ uint32_t s_end[MAX_SEGMENTS];
-  __shared__ uint32_t s_cls[MAX_SEGMENTS];
-  for (int i = (int)threadIdx.x; i < nseg; i += 256) {
-    s_end[i] = segs[i].start + segs[i].count;
-    s_cls[i] = (uint32_t)(uintptr_t)segs[i].pad1 & 1u;
-  }
-  __syncthreads();
-  const uint32_t n = min(*R_dev, cap);
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const uint32_t v = point_list[i];
-    const uint32_t id = v & LAYER_ID_MASK;
-    int lo = 0, hi = nseg - 1;           // first segment whose end lies behind id
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (id < s_end[mid]) hi = mid; else lo = mid + 1;
-    }
-    if (s_cls[lo]) point_list[i] = v | LAYER_BIT;
-  }
+void launch_fill_layer_planes(hipStream_t s, size_t N, const float* layer_background, float* color_bg, float* alpha_bg,
+                              float* color_obj, float* alpha_obj) {
+  if (N == 0) return;
+  const size_t nb = (N + 255) / 256;
+  fill_layer_planes_kernel<<<(unsigned)(nb < 2048 ? nb : 2048), 256, 0, s>>>(N, layer_background, color_bg, alpha_bg,
+                                                                               color_obj, alpha_obj);
 }
 
-struct LayerOut {
-  const float* bg_layer;     // [3] background of the two layer planes (the reference renders them on white)
-  float* color_bg; float* alpha_bg; float* color_obj; float* alpha_obj;
-};
-
-// one quad into the three states: alpha once, then the blend half per state with its own accept masks
-__device__ __forceinline__ void blend_quad_layers(WavePix<1>& sa, WavePix<1>& sb, WavePix<1>& so,
-                                                  const float4* __restrict__ my, const int j0,
-                                                  const float pxf, const float pyf, const int lane) {
-  const float4* blk = my + (j0 >> 1) * PAIR_F4;
-  QuadGeom g;
-  g.load(blk);
-  QuadColsReg<false> cols;
-  cols.load(blk);
-  const float4 p0 = blk[5], p1 = blk[PAIR_F4 + 5];
-  float alpha[4];
-  uint64_t ok[4];
-  eval_quad(g, pxf, pyf, alpha, ok);   // (the batch-level SAFE form costs this kernel 18 registers: 0.45 -> 0.49 ms)
-  const uint32_t cls[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.z)),
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p0.w)),
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.z)),
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p1.w))};
-  uint64_t okb[4], oko[4];
-  uint64_t anyb = 0ull, anyo = 0ull;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint64_t m = cls[i] ? ~0ull : 0ull;   // the slot's class, as a lane mask (wave-uniform)
-    okb[i] = ok[i] & ~m; oko[i] = ok[i] & m;
-    anyb |= okb[i]; anyo |= oko[i];
-  }
-  const SemSrc nosem = {nullptr, 0, nullptr};
-  SemAcc<0>* nosa = nullptr;
-  blend_quad_tail<false, 0>(sa, cols, alpha, ok, nosa, nosem, j0, lane);
-  if (anyb & ~sb.done[0]) blend_quad_tail<false, 0>(sb, cols, alpha, okb, nosa, nosem, j0, lane);
-  if (anyo & ~so.done[0]) blend_quad_tail<false, 0>(so, cols, alpha, oko, nosa, nosem, j0, lane);
-}
-
-__device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint32_t* __restrict__ qid,
-                                                   uint32_t* __restrict__ qpos, const int lane, const int quarter,
-                                                   const uint32_t r_begin, const uint32_t r_end, const int x0,
-                                                   const int y0, const int W, const int H,
-                                                   const uint32_t* __restrict__ point_list, const RecView rec,
-                                                   const float* __restrict__ bg, float* __restrict__ out_color,
-                                                   float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                   const LayerOut lo) {
-  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
-  const float pxf = (float)px;
-  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
-  const uint64_t lt = lanemask_lt();
-  WavePix<1> sa, sb, so;
-  const uint64_t outside = lanes(!(px < W && py < H));
-  sa.T[0] = 1.0f; sa.CrCg[0] = (v2f){0.f, 0.f}; sa.CbD[0] = (v2f){0.f, 0.f}; sa.last[0] = 0; sa.done[0] = outside;
-  sb = sa; so = sa;
-  // cull boxes: non-object entries against the pixels live in the composition or the background,
-  // object entries against those live in any state
-  float ax0 = (float)x0, ax1 = (float)(x0 + 15), ay0 = (float)y0, ay1 = (float)(y0 + 3);
-  float ox0 = ax0, ox1 = ax1, oy0 = ay0, oy1 = ay1;
-  uint64_t prev_ab = ~0ull, prev_all = ~0ull;
-
-  uint32_t head = 0, count = 0;
-  ListStream<4> ls;
-  ls.open(point_list, r_begin, r_end, lane);
-  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-  uint32_t pos = 0, idc = 0, ncur = 0;
-
-  for (;;) {
-    const uint64_t live_ab = ~(sa.done[0] & sb.done[0]);
-    const uint64_t live_all = live_ab | ~so.done[0];
-    if (live_all == 0ull) break;
-    const bool need_ab = live_ab != 0ull;   // wave-uniform: the composition or the background still blends
-    if (live_ab != prev_ab && need_ab) {
-      prev_ab = live_ab;
-      const MaskBox m = mask_box(live_ab);
-      ax0 = (float)(x0 + m.c0); ax1 = (float)(x0 + m.c1); ay0 = (float)(y0 + m.r0); ay1 = (float)(y0 + m.r1);
-    }
-    if (live_all != prev_all) {
-      prev_all = live_all;
-      const MaskBox m = mask_box(live_all);
-      ox0 = (float)(x0 + m.c0); ox1 = (float)(x0 + m.c1); oy0 = (float)(y0 + m.r0); oy1 = (float)(y0 + m.r1);
-    }
-    // ---- FILL (the ring entry keeps the class bit: ID_MASK covers bit 27) ----
-    while (count < (uint32_t)WAVE && !ls.exhausted())
-      ls.fill(qid, qpos, bit, head, count, lane, lt, need_ab ? 0u : LAYER_BIT);
-    __builtin_amdgcn_wave_barrier();
-    // ---- POP ----
-    const uint32_t nn = min(count, (uint32_t)WAVE);
-    float4 a_n = make_float4(0, 0, 0, 0), b_n = a_n, c_n = a_n;
-    uint32_t pos_n = 0, id_n = 0;
-    if ((uint32_t)lane < nn) {
-      const uint32_t slot = (head + lane) & (QCAP - 1);
-      id_n = qid[slot];
-      pos_n = qpos[slot];
-      rec.load(id_n & LAYER_ID_MASK, a_n, b_n, c_n);
-    }
-    head = (head + nn) & (QCAP - 1);
-    count -= nn;
-    // ---- BLEND the previous batch ----
-    if (ncur > 0) {
-      const bool is_obj = (idc & LAYER_BIT) != 0u;
-      const bool keep = ((uint32_t)lane < ncur) && (need_ab || is_obj) &&
-                        !splat_misses_rect(a.x, a.y, b.x, b.y, b.z, a.w, is_obj ? ox0 : ax0, is_obj ? ox1 : ax1,
-                                           is_obj ? oy0 : ay0, is_obj ? oy1 : ay1);
-      const uint64_t mask = __ballot(keep);
-      const int cnt = (int)__popcll(mask);
-      if (keep) {
-        const int slot = (int)__popcll(mask & lt);
-        store_pair_half(my, slot, a.x, a.y, splat_q(b.x, b.y, b.z), a.w, make_float4(b.w, c.x, c.y, a.z), pos);
-        reinterpret_cast<uint32_t*>(my + (slot >> 1) * PAIR_F4)[22 + (slot & 1)] = is_obj ? 1u : 0u;
-      }
-      if (lane < ((4 - (cnt & 3)) & 3)) {   // neutral pads up to a multiple of 4 (opacity 0)
-        const SplatQ zq = {0.f, 0.f, 0.f};
-        store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
-        reinterpret_cast<uint32_t*>(my + ((cnt + lane) >> 1) * PAIR_F4)[22 + ((cnt + lane) & 1)] = 0u;
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (int j0 = 0; j0 < cnt; j0 += 4) blend_quad_layers(sa, sb, so, my, j0, pxf, (float)py, lane);
-      __builtin_amdgcn_wave_barrier();
-    }
-    a = a_n; b = b_n; c = c_n; pos = pos_n; idc = id_n; ncur = nn;
-    if (ncur == 0 && ls.exhausted()) break;
-  }
-  const size_t HW = (size_t)H * W;
-  if (px < W && py < H) {
-    const size_t pix = (size_t)py * W + px;
-    const float l0 = lo.bg_layer[0], l1 = lo.bg_layer[1], l2 = lo.bg_layer[2];
-    out_color[pix] = sa.CrCg[0].x + sa.T[0] * bg[0];
-    out_color[HW + pix] = sa.CrCg[0].y + sa.T[0] * bg[1];
-    out_color[2 * HW + pix] = sa.CbD[0].x + sa.T[0] * bg[2];
-    out_alpha[pix] = 1.0f - sa.T[0];
-    out_depth[pix] = sa.CbD[0].y;
-    lo.color_bg[pix] = sb.CrCg[0].x + sb.T[0] * l0;
-    lo.color_bg[HW + pix] = sb.CrCg[0].y + sb.T[0] * l1;
-    lo.color_bg[2 * HW + pix] = sb.CbD[0].x + sb.T[0] * l2;
-    lo.alpha_bg[pix] = 1.0f - sb.T[0];
-    lo.color_obj[pix] = so.CrCg[0].x + so.T[0] * l0;
-    lo.color_obj[HW + pix] = so.CrCg[0].y + so.T[0] * l1;
-    lo.color_obj[2 * HW + pix] = so.CbD[0].x + so.T[0] * l2;
-    lo.alpha_obj[pix] = 1.0f - so.T[0];
-  }
-}
-
-// work lists as built for tile_classes_layers(): class 0 empty, classes 1 / 2 = the non-empty tiles, class 3 =
-// the EMPTY tiles (their planes are the backgrounds)
-__global__ void __launch_bounds__(256, 3)
-render_layers_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const RecView rec,
-                     const int W, const int H, const int gx, const uint32_t T, const uint32_t* __restrict__ work,
-                     const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-                     float* __restrict__ out_alpha, const LayerOut lo) {
-  __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
-  __shared__ uint32_t s_qid[RW_WAVES][QCAP];
-  __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t n0 = work[0], n1 = work[1], n2 = work[2], nempty = work[3];
-  const uint32_t* lists = work + NUM_CLASSES;
-  const uint32_t nheavy = n0 + n1 + n2;
-  if (blockIdx.x < nheavy) {
-    const uint32_t b = blockIdx.x;
-    const uint32_t tile = b < n0 ? lists[b] : (b < n0 + n1 ? lists[T + (b - n0)] : lists[2 * T + (b - n0 - n1)]);
-    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
-    const uint2 range = ranges[tile];
-    const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
-    const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
-    blend_heavy_layers(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE, ty * TILE + wave * 4, W,
-                       H, point_list, rec, bg, out_color, out_depth, out_alpha, lo);
-    return;
-  }
-  const uint32_t li = (blockIdx.x - nheavy) * RW_WAVES + (uint32_t)wave;
-  if (li >= nempty) return;
-  const uint32_t tile = lists[3 * (size_t)T + li];
-  const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
-  const int px = tx * TILE + (lane & 15), py0 = ty * TILE + (lane >> 4) * 4;
-  const size_t HW = (size_t)H * W;
-  for (int k = 0; k < 4; k++) {
-    if (px < W && py0 + k < H) {
-      const size_t pix = (size_t)(py0 + k) * W + px;
-      for (int ch = 0; ch < 3; ch++) {
-        out_color[ch * HW + pix] = bg[ch];
-        lo.color_bg[ch * HW + pix] = lo.bg_layer[ch];
-        lo.color_obj[ch * HW + pix] = lo.bg_layer[ch];
-      }
-      out_alpha[pix] = 0.f; out_depth[pix] = 0.f; lo.alpha_bg[pix] = 0.f; lo.alpha_obj[pix] = 0.f;
-    }
-  }
-}
+uint32_t render_pc_slots(uint32_t R);
 
 void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_list, const RecView rec, int W, int H,
                           int gx, int gy, const float* bg, float* out_color, float* out_depth, float* out_alpha,
-                          uint32_t* work, const TileClasses cls, const uint32_t* R_dev, uint32_t cap, bool classified,
-                          const unsigned char* layer_class, const float* layer_background, float* out_color_bg,
-                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj,
-                          const SegmentDev* seg_table, int nseg) {
+                          uint32_t* work, const TileClasses cls, uint32_t cap, bool classified,
+                          const float* layer_background, float* out_color_bg,
+                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj, const PCErr pc_err) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
-  if (cap > 0) {
-    const size_t nb = ((size_t)cap + 255) / 256;
-    const unsigned grid = (unsigned)(nb < 4096 ? nb : 4096);
-    if (seg_table)
-      layer_mark_segments_kernel<<<grid, 256, 0, s>>>(point_list, R_dev, cap, seg_table, nseg);
-    else
-      layer_mark_kernel<<<grid, 256, 0, s>>>(point_list, R_dev, cap, (const uint8_t*)layer_class);
-  }
+  // (the class of every list entry is already there: bit 27, from the record -- hier_binning.hip / binning.hip)
   if (!classified)
     classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, cls, work);
   const LayerOut lo = {layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
-  // non-empty tiles + ceil(empty / 4) <= ntiles workgroups; surplus ones exit at once
-  render_layers_kernel<<<ntiles, 256, 0, s>>>(ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg,
-                                              out_color, out_depth, out_alpha, lo);
+  // four workgroups per class-0 tile; in a layered frame a tile with object entries is class 0 from
+  // cls.c0_obj_min entries (common.h tile_class_of): at most cap / c0_obj_min tiles
+  const uint32_t pc_slots = 4u * (uint32_t)((size_t)cap / (cls.c0_obj_min < cls.c0_min ? cls.c0_obj_min : cls.c0_min) + 1);
+  const CkptArgs ck = CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+  const SemSrc sem = {nullptr, 0, nullptr};
+  render_forward_kernel<false, 2, false, 0, true><<<ntiles + pc_slots, 256, 0, s>>>(
+      ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, out_alpha, nullptr,
+      pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj);
 }
 
 // N-channel "semantic" planes (forward.cu:442-444): same traversal and the same accept/reject

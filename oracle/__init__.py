@@ -170,10 +170,14 @@ def forward(means3D, opacities, *, image_height, image_width, tanfovx, tanfovy, 
     return o
 
 
-def backward(fwd, grad_color, grad_depth, grad_alpha, grad_semantic=None):
+def backward(fwd, grad_color, grad_depth, grad_alpha, grad_semantic=None, blend_f64=False):
     """Backward of the reference algorithm given a forward() result and the four
     pixel-plane gradients.  Returns the 9 gradients the binding returns
-    (rasterize_points.cu:219) plus the internal dL_dconic / dL_ddepths."""
+    (rasterize_points.cu:219) plus the internal dL_dconic / dL_ddepths.
+
+    blend_f64=True: the ARBITER (gs_oracle.c gso_render_backward_f64) -- the blend stage's gradient in float64
+    from the exact final transmittance, same accept decisions; the preprocess backward behind it is the same
+    float32 restatement.  For settling HIP-vs-oracle disagreements at sizes float64 autograd does not reach."""
     lib = _load()
     i = fwd["_inputs"]
     P, W, H, S, M = fwd["P"], fwd["W"], fwd["H"], fwd["S"], fwd["M"]
@@ -195,12 +199,20 @@ def backward(fwd, grad_color, grad_depth, grad_alpha, grad_semantic=None):
     g["dL_drotations"] = np.zeros((P, 4), np.float32)
     if P == 0:
         return g
-    lib.gso_render_backward(
-        P, W, H, S, _p(fwd["ranges"]), _p(fwd["point_list"]), _p(i["bg"]), _p(fwd["means2D"]),
-        _p(fwd["conic_opacity"]), _p(fwd["features"]), _p(fwd["depths"]), _p(i["semantics"]),
-        _p(fwd["alpha"]), _p(fwd["n_contrib"]), _p(gc), _p(gd), _p(ga), _p(gs),
-        _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]),
-        _p(g["dL_ddepths"]), _p(g["dL_dsemantic"]))
+    if blend_f64:
+        lib.gso_render_backward_f64(
+            P, W, H, S, _p(fwd["ranges"]), _p(fwd["point_list"]), _p(i["bg"]), _p(fwd["means2D"]),
+            _p(fwd["conic_opacity"]), _p(fwd["features"]), _p(fwd["depths"]), _p(i["semantics"]),
+            _p(fwd["n_contrib"]), _p(gc), _p(gd), _p(ga), _p(gs),
+            _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]),
+            _p(g["dL_ddepths"]), _p(g["dL_dsemantic"]))
+    else:
+        lib.gso_render_backward(
+            P, W, H, S, _p(fwd["ranges"]), _p(fwd["point_list"]), _p(i["bg"]), _p(fwd["means2D"]),
+            _p(fwd["conic_opacity"]), _p(fwd["features"]), _p(fwd["depths"]), _p(i["semantics"]),
+            _p(fwd["alpha"]), _p(fwd["n_contrib"]), _p(gc), _p(gd), _p(ga), _p(gs),
+            _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]),
+            _p(g["dL_ddepths"]), _p(g["dL_dsemantic"]))
     cov3Ds = i["cov3D_precomp"] if i["cov3D_precomp"] is not None else fwd["cov3D"]
     lib.gso_preprocess_backward(
         P, i["sh_degree"], M, _p(i["means3D"]), _p(fwd["radii"]), _p(i["shs"]), _p(fwd["clamped"]),

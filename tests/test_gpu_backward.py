@@ -105,7 +105,7 @@ def _grad_close(name, got, ref, rel_l2=1e-3, elem_tol=2e-3, frac=0.995, exempt=N
 
 
 def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_frac=STRICT_MISS_FRAC,
-         with_truth=False):
+         with_truth=False, with_arbiter=False):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     g = torch.Generator().manual_seed(100 + seed)
     P = sc.means3D.shape[0]
@@ -132,6 +132,13 @@ def _run(dev, sc, cam, bg, S=0, use_colors=False, use_cov=False, seed=0, miss_fr
     if with_truth:      # small draws only: float64 autograd through the pure-PyTorch splat
         from helpers import float64_truth_gradients
         tr = float64_truth_gradients(sc, okw, gc, gd, ga, gs, semantics=sem, colors=colors, cov=cov)
+    elif with_arbiter:  # any size: the blend stage's gradient in float64 from the exact final transmittance
+        # (gs_oracle.c gso_render_backward_f64; agrees with the float64 autograd above to 1e-6, tests/test_oracle_golden.py)
+        r64 = oracle.backward(o, gc, gd, ga, gs, blend_f64=True)
+        tr = {k: r64[k] for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dcolors", "dL_dcov3D", "dL_dscales",
+                                  "dL_drotations", "dL_dsemantic")}
+        tr["dL_dmeans2D_xy"] = np.asarray(r64["dL_dmeans2D"])[:, :2]
+        with_truth = True
 
     camd = hz.CameraTensors(H, W, cam.tanfovx, cam.tanfovy, cam.viewmatrix.to(dev),
                             cam.projmatrix.to(dev), cam.campos.to(dev))

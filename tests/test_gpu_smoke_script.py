@@ -61,7 +61,15 @@ def test_smoke_script_forward_true_size(dev, S):
 
 def test_smoke_script_backward_true_size_S15(dev):
     """The S = 15 call of the script with a backward behind it: every gradient array (incl. dL_dsemantic) against
-    oracle.backward at 13.3 M tile instances."""
+    oracle.backward at 13.3 M tile instances.
+
+    Every pixel of this frame is nearly opaque behind 5-10 k splats, the worst case for the reference's
+    T_final = 1 - alphas[pix] (backward.cu:468: float32 cancellation), which the oracle
+    restates: measured here, dL_dmeans3D sits 1.6e-3 (relative L2) from the oracle where the suite's array bar is
+    1e-3.  An array beyond the bars is settled like in tests/test_gpu_sweep.py -- against the float64 gradient of
+    the same formulas -- except that float64 AUTOGRAD does not fit at this size: the arbiter is
+    oracle.backward(blend_f64=True) (gs_oracle.c gso_render_backward_f64; pinned to the autograd truth on a small
+    scene by tests/test_oracle_golden.py)."""
     from test_gpu_backward import STRICT_MISS_FRAC_LONG_LISTS, _run
     sc, cam = hz.smoke_scene(P, seed=0), hz.smoke_camera(W, H)
-    _run(dev, sc, cam, torch.zeros(3), S=15, seed=77, miss_frac=STRICT_MISS_FRAC_LONG_LISTS)
+    _run(dev, sc, cam, torch.zeros(3), S=15, seed=77, miss_frac=STRICT_MISS_FRAC_LONG_LISTS, with_arbiter=True)

@@ -44,9 +44,55 @@ def stages(fn):
 with torch.no_grad():
     plain = lambda: rast(means3D=sc.means3D, means2D=None, opacities=sc.opacity, **kw)      # noqa: E731
     layered = lambda: rast.forward_layers(sc.means3D, sc.opacity, obj, **kw)                # noqa: E731
+    none = torch.zeros_like(obj)
+    layered_none = lambda: rast.forward_layers(sc.means3D, sc.opacity, none, **kw)          # noqa: E731
+    o = layered()
+    # share of the 16x16 tiles some object pixel lands in (a lower bound of the tiles whose LIST holds an object entry)
+    H, W = o["alpha_object"].shape[-2:]
+    a = torch.nn.functional.pad(o["alpha_object"][0], (0, (-W) % 16, 0, (-H) % 16))
+    tiles_hit = (a.reshape(a.shape[0] // 16, 16, a.shape[1] // 16, 16).amax(dim=(1, 3)) > 0)
     out = {"case": "bench P=2000000 @1920x1280, %d object Gaussians" % int(obj.sum()),
            "forward_ms": timed(plain), "forward_layers_ms": timed(layered),
+           "forward_layers_no_objects_ms": timed(layered_none),
+           "tiles_with_object_pixels_share": float(tiles_hit.float().mean()),
            "stage_ms_forward": stages(plain), "stage_ms_layers": stages(layered),
+           "stage_ms_layers_no_objects": stages(layered_none),
            "stages": "preprocess, depth sort, coarse scan, coarse emit, coarse partition, counts+fill, render "
                      "(layers: class marks + three-state render), semantic render"}
+
+# Second case: ACTOR-like objects -- ten car-sized boxes (4.5 x 1.6 x 2 m) of 10 k small Gaussians (sigma ~ 5 cm) standing
+# on the road ahead, the shape tools/bench_compose.py poses its actor models in ("10 actors of
+# 10 k"), appended to a 1.9 M background.  The first case marks the 10 k scene Gaussians NEAREST to ten road points
+# as objects, which sweeps up metre-sized ground splats: two thirds of the frame's tiles then hold object entries.
+import math
+g = torch.Generator().manual_seed(2)
+bgs = hz.street_scene(1_900_000, seed=2)
+parts, NA, PA = [bgs], 10, 10_000
+for k in range(NA):
+    a = 0.05 * k
+    loc = (torch.rand(PA, 3, generator=g) - 0.5) * torch.tensor([4.5, 1.6, 2.0])
+    ca, sa = math.cos(a), math.sin(a)
+    rot = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]])
+    xyz = loc @ rot.T + torch.tensor([-12.0 + 2.5 * k, 0.8, 10.0 + 8.0 * k])
+    q = torch.nn.functional.normalize(torch.randn(PA, 4, generator=g), dim=1)
+    parts.append(hz.Scene(xyz, torch.sigmoid(1.0 + 2.0 * torch.randn(PA, 1, generator=g)),
+                          torch.exp(math.log(0.05) + 0.5 * torch.randn(PA, 3, generator=g)), q,
+                          torch.cat((0.5 * torch.randn(PA, 1, 3, generator=g), 0.15 * torch.randn(PA, 3, 3, generator=g)), 1), 1))
+cat = lambda k: torch.cat([getattr(p, k) for p in parts]).contiguous().to(dev)   # noqa: E731
+sc2 = hz.Scene(cat("means3D"), cat("opacity"), cat("scales"), cat("rotations"), cat("shs"), 1)
+obj2 = torch.zeros(sc2.means3D.shape[0], dtype=torch.bool, device=dev)
+obj2[1_900_000:] = True
+kw2 = dict(shs=sc2.shs, scales=sc2.scales, rotations=sc2.rotations)
+with torch.no_grad():
+    plain2 = lambda: rast(means3D=sc2.means3D, means2D=None, opacities=sc2.opacity, **kw2)   # noqa: E731
+    layered2 = lambda: rast.forward_layers(sc2.means3D, sc2.opacity, obj2, **kw2)            # noqa: E731
+    o2 = layered2()
+    a2 = torch.nn.functional.pad(o2["alpha_object"][0], (0, (-W) % 16, 0, (-H) % 16))
+    hit2 = (a2.reshape(a2.shape[0] // 16, 16, a2.shape[1] // 16, 16).amax(dim=(1, 3)) > 0)
+    st2 = stages(layered2)
+    out.update({"actors_case": "1.9 M background + 10 actor boxes of 10 k Gaussians (P = 2 000 000)",
+                "actors_forward_ms": timed(plain2), "actors_forward_layers_ms": timed(layered2),
+                "actors_tiles_with_object_pixels_share": float(hit2.float().mean()),
+                "actors_render_stage_ms": st2[6], "actors_stage_ms_layers": st2,
+                "actors_object_pixels_share": float((o2["alpha_object"] > 0).float().mean())})
 print(json.dumps(out))
