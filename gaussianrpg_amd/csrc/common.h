@@ -334,7 +334,7 @@ struct TileObjBits {
   __host__ __device__ bool tile(const uint32_t t) const { return flags[t] != 0; }
 };
 #ifndef GRPG_LAYERS_PC_MIN      // experiment builds: from how many entries a tile WITH object entries gets a producer
-#define GRPG_LAYERS_PC_MIN 2048 // wave and one consumer wave per layer (render_fwd.hip pc3_*)
+#define GRPG_LAYERS_PC_MIN 8192 // wave and one consumer wave per layer (render_fwd.hip pc3_*)
 #endif
 constexpr uint32_t LAYERS_PC_MIN = GRPG_LAYERS_PC_MIN;
 struct TileClasses { uint32_t c0_min, c1_min, heavy_min; TileObjBits obj; uint32_t c0_obj_min; };

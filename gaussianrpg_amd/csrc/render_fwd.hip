@@ -1085,7 +1085,11 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   for (;;) {
     if (pc_load(&ctl->stop) != 0u) return;
     // ---- FILL: until two batches are queued (ring: < 128 + 256 entries <= QCAP) ----
+#if GRPG_LAYERS_ABLATE & 32   // experiment build (wrong images): the plain pairs walk the non-object entries only
+    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt, POINT_CLASS_BIT, 0u);
+#else
     while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt);
+#endif
     // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
     // reordering the LDS accesses across this point (costs no instruction)
     __builtin_amdgcn_wave_barrier();
@@ -1097,12 +1101,18 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
       const uint32_t slot = (head + lane) & (QCAP - 1);
       id0n = qid[slot];
       pos0n = qpos[slot];
+#if GRPG_LAYERS_ABLATE & 16
+      id0n &= POINT_CLASS_BIT - 1u;
+#endif
       rec.load(id0n, a0n, b0n, c0n);
     }
     if ((uint32_t)lane + WAVE < nn) {
       const uint32_t slot = (head + WAVE + lane) & (QCAP - 1);
       id1n = qid[slot];
       pos1n = qpos[slot];
+#if GRPG_LAYERS_ABLATE & 16
+      id1n &= POINT_CLASS_BIT - 1u;
+#endif
       rec.load(id1n, a1n, b1n, c1n);
     }
     head = (head + nn) & (QCAP - 1);
@@ -1434,12 +1444,23 @@ __device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint
 // drops a class altogether once nobody wants it.
 // ------------------------------------------------------------------------------------------
 struct PC3Ctrl {
-  uint32_t flag[3][2];      // [consumer][buffer]
-  uint32_t stop[3];
+  // per buffer ONE word, byte c = consumer c's flag: 0 free, cnt + 1 (<= 65) | PC3_SAFE = cnt survivors wait for it,
+  // PC3_DONE end of the list.  The producer publishes a batch with one store and sees all three releases with one
+  // load; a consumer polls and clears its own byte.
+  uint32_t flag[2];
+  uint32_t stop;            // byte c = 0xFF once consumer c has nothing left to blend
   uint32_t pad;
   uint32_t objmask[2][2];   // per buffer: which compacted slots hold an object-class splat (low / high word)
   float box[3][4];
 };
+constexpr uint32_t PC3_SAFE = 0x80u, PC3_DONE = 0xFFu;
+__device__ __forceinline__ uint32_t pc_load_u8(const uint8_t* p) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void pc_store_u8(uint8_t* p, const uint8_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 template <class Cond, class Stop>
 __device__ __forceinline__ bool pc_wait_until(const PCErr err, const int lane, Cond ready, Stop stopped) {
@@ -1466,42 +1487,32 @@ __device__ __forceinline__ void pc3_producer(float4* __restrict__ buf0, float4* 
   float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, c0 = a0, a1 = a0, b1 = a0, c1 = a0;
   uint32_t pos0 = 0, id0 = 0, pos1 = 0, id1 = 0, ncur = 0;
   int cur = 0;
+  // the batch's object slots (slot order) are collected by the object lanes themselves: ds_or into the buffer's mask
+  // words, which begin_batch cleared (one wave: its LDS operations execute in order)
+  const auto begin_batch = [&]() { if (lane == 0) { ctl->objmask[cur][0] = 0u; ctl->objmask[cur][1] = 0u; } };
   const auto put = [&](float4* __restrict__ my, const bool keep, const uint64_t mask, const int base,
                        const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc) {
     if (keep) {
       const int slot = base + (int)__popcll(mask & lt);
       store_pair_half(my, slot, a.x, a.y, splat_q(b.x, b.y, b.z), a.w, make_float4(b.w, c.x, c.y, a.z), pos);
-      store_slot_class(my, slot, (idc & LAYER_BIT) ? 1u : 0u);
+      if (idc & LAYER_BIT) atomicOr(&ctl->objmask[cur][slot >> 5], 1u << (slot & 31));
     }
   };
   const auto publish = [&](float4* __restrict__ my, const int cnt, const bool safe) {
     if (lane < ((4 - (cnt & 3)) & 3)) {
       const SplatQ zq = {0.f, 0.f, 0.f};
       store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
-      store_slot_class(my, cnt + lane, 0u);
     }
-    __builtin_amdgcn_wave_barrier();
-    // the batch's object slots, in slot order: lane j reads the class word of slot j back
-    const uint32_t cw = lane < cnt ? reinterpret_cast<const uint32_t*>(my + (lane >> 1) * PAIR_F4)[22 + (lane & 1)] : 0u;
-    const uint64_t om = __ballot(cw != 0u);
-    if (lane == 0) { ctl->objmask[cur][0] = (uint32_t)om; ctl->objmask[cur][1] = (uint32_t)(om >> 32); }
-    const uint32_t f = ((uint32_t)cnt + 1u) | (safe ? PC_SAFE : 0u);
-    pc_store(&ctl->flag[0][cur], f);
-    pc_store(&ctl->flag[1][cur], f);
-    pc_store(&ctl->flag[2][cur], f);
+    const uint32_t f = ((uint32_t)cnt + 1u) | (safe ? PC3_SAFE : 0u);
+    pc_store(&ctl->flag[cur], f * 0x010101u);
     cur ^= 1;
   };
-  const auto all_stopped = [&]() {
-    return pc_load(&ctl->stop[0]) != 0u && pc_load(&ctl->stop[1]) != 0u && pc_load(&ctl->stop[2]) != 0u;
-  };
+  const auto all_stopped = [&]() { return (pc_load(&ctl->stop) & 0xFFFFFFu) == 0xFFFFFFu; };
   // buffer `cur` is free once every consumer still running has handed it back
-  const auto buffer_free = [&]() {
-    return (pc_load(&ctl->flag[0][cur]) == 0u || pc_load(&ctl->stop[0]) != 0u) &&
-           (pc_load(&ctl->flag[1][cur]) == 0u || pc_load(&ctl->stop[1]) != 0u) &&
-           (pc_load(&ctl->flag[2][cur]) == 0u || pc_load(&ctl->stop[2]) != 0u);
-  };
+  const auto buffer_free = [&]() { return (pc_load(&ctl->flag[cur]) & ~pc_load(&ctl->stop) & 0xFFFFFFu) == 0u; };
   for (;;) {
-    const bool sA = pc_load(&ctl->stop[0]) != 0u, sB = pc_load(&ctl->stop[1]) != 0u, sO = pc_load(&ctl->stop[2]) != 0u;
+    const uint32_t stops = pc_load(&ctl->stop);
+    const bool sA = (stops & 0xFFu) != 0u, sB = (stops & 0xFF00u) != 0u, sO = (stops & 0xFF0000u) != 0u;
     if (sA && sB && sO) return;
     // non-object entries feed the composition and the background layer, object entries the composition and
     // the object layer (a stale "still running" only passes on entries nobody takes any more)
@@ -1546,6 +1557,7 @@ __device__ __forceinline__ void pc3_producer(float4* __restrict__ buf0, float4* 
       if (n0 + n1 > 0) {
         if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;
         float4* my = cur ? buf1 : buf0;
+        begin_batch();
         if (n0 + n1 <= WAVE) {
           put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
           put(my, k1, m1, n0, a1, b1, c1, pos1, id1);
@@ -1555,6 +1567,7 @@ __device__ __forceinline__ void pc3_producer(float4* __restrict__ buf0, float4* 
           publish(my, n0, safe0);
           if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;
           my = cur ? buf1 : buf0;
+          begin_batch();
           put(my, k1, m1, 0, a1, b1, c1, pos1, id1);
           publish(my, n1, safe1);
         }
@@ -1566,9 +1579,7 @@ __device__ __forceinline__ void pc3_producer(float4* __restrict__ buf0, float4* 
     if (ncur == 0 && ls.exhausted()) break;
   }
   if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;   // end-of-list marker
-  pc_store(&ctl->flag[0][cur], PC_DONE);
-  pc_store(&ctl->flag[1][cur], PC_DONE);
-  pc_store(&ctl->flag[2][cur], PC_DONE);
+  pc_store(&ctl->flag[cur], PC3_DONE * 0x010101u);
 }
 
 // one handed-over batch for the consumer of layer ROLE (0 composition, 1 background layer, 2 object layer); om = the
@@ -1628,24 +1639,35 @@ __device__ __forceinline__ void pc3_consumer(const float4* __restrict__ buf0, co
   fresh_state(st, lanes(!(px < W && py < H)));
   uint64_t prev_alive = ~0ull;
   int cur = 0;
+  uint8_t* const my_stop = reinterpret_cast<uint8_t*>(&ctl->stop) + ROLE;
   const auto quit = [&]() {   // nothing left to blend here: take the box out of the producer's unions, then say so
     if (lane == 0) { ctl->box[ROLE][0] = 3e38f; ctl->box[ROLE][1] = -3e38f; ctl->box[ROLE][2] = 3e38f; ctl->box[ROLE][3] = -3e38f; }
-    pc_store(&ctl->stop[ROLE], 1u);
+    pc_store_u8(my_stop, (uint8_t)0xFF);
   };
+#if GRPG_LAYERS_ABLATE & 1   // experiment build (wrong images): the object layer's consumer gives up at once
+  if (ROLE == 2) st.done[0] = ~0ull;
+#endif
+#if GRPG_LAYERS_ABLATE & 4   // ... and the background layer's
+  if (ROLE == 1) st.done[0] = ~0ull;
+#endif
+#if GRPG_LAYERS_ABLATE & 8   // ... or the composition's
+  if (ROLE == 0) st.done[0] = ~0ull;
+#endif
   if (~st.done[0] == 0ull) quit();   // quarter outside the image
   else for (;;) {
     uint32_t f = 0;
-    if (!pc_wait_until(err, lane, [&]() { f = pc_load(&ctl->flag[ROLE][cur]); return f != 0u; }, []() { return false; })) break;
-    if (f == PC_DONE) break;
-    const int cnt = (int)((f & (PC_SAFE - 1u)) - 1u);
+    uint8_t* const my_flag = reinterpret_cast<uint8_t*>(&ctl->flag[cur]) + ROLE;
+    if (!pc_wait_until(err, lane, [&]() { f = pc_load_u8(my_flag); return f != 0u; }, []() { return false; })) break;
+    if (f == PC3_DONE) break;
+    const int cnt = (int)((f & (PC3_SAFE - 1u)) - 1u);
     const float4* my = cur ? buf1 : buf0;
     uint64_t om = 0ull;
     if (ROLE != 0)
       om = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->objmask[cur][0]) |
            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->objmask[cur][1]) << 32);
-    if (f & PC_SAFE) pc3_blend_batch<ROLE, true>(st, my, cnt, om, pxf, pyf, lane);
+    if (f & PC3_SAFE) pc3_blend_batch<ROLE, true>(st, my, cnt, om, pxf, pyf, lane);
     else pc3_blend_batch<ROLE, false>(st, my, cnt, om, pxf, pyf, lane);
-    pc_store(&ctl->flag[ROLE][cur], 0u);   // hand the buffer back
+    pc_store_u8(my_flag, (uint8_t)0);   // hand the buffer back
     cur ^= 1;
     const uint64_t alive = ~st.done[0];
     if (alive == 0ull) { quit(); break; }
@@ -1744,12 +1766,16 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
     if constexpr (LAYERS) {
+#if GRPG_LAYERS_ABLATE & 16   // experiment build (wrong images): long object tiles on the plain frame's wave pairs
+      if (false) {
+#else
       if (ob.tile(tile)) {   // (workgroup-uniform)
+#endif
         __shared__ PC3Ctrl s_ctl3;
         const int q3 = (int)pc_sub, x03 = tx * TILE, y03 = ty * TILE + q3 * 4;
         if (threadIdx.x == 0) {
+          s_ctl3.flag[0] = 0u; s_ctl3.flag[1] = 0u; s_ctl3.stop = 0u; s_ctl3.pad = 0u;
           for (int c = 0; c < 3; c++) {
-            s_ctl3.flag[c][0] = 0u; s_ctl3.flag[c][1] = 0u; s_ctl3.stop[c] = 0u;
             s_ctl3.box[c][0] = (float)x03; s_ctl3.box[c][1] = (float)(x03 + 15);
             s_ctl3.box[c][2] = (float)y03; s_ctl3.box[c][3] = (float)(y03 + 3);
           }

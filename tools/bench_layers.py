@@ -90,9 +90,17 @@ with torch.no_grad():
     a2 = torch.nn.functional.pad(o2["alpha_object"][0], (0, (-W) % 16, 0, (-H) % 16))
     hit2 = (a2.reshape(a2.shape[0] // 16, 16, a2.shape[1] // 16, 16).amax(dim=(1, 3)) > 0)
     st2 = stages(layered2)
+    # the floor of the background layer's work: the plain op on the background model alone (what the second of the
+    # reference's three calls renders)
+    NBG = 1_900_000
+    bgonly = lambda: rast(means3D=sc2.means3D[:NBG], means2D=None, opacities=sc2.opacity[:NBG], shs=sc2.shs[:NBG],   # noqa: E731
+                          scales=sc2.scales[:NBG], rotations=sc2.rotations[:NBG])
+    st_bg = stages(bgonly)
+    st_pl = stages(plain2)
     out.update({"actors_case": "1.9 M background + 10 actor boxes of 10 k Gaussians (P = 2 000 000)",
                 "actors_forward_ms": timed(plain2), "actors_forward_layers_ms": timed(layered2),
                 "actors_tiles_with_object_pixels_share": float(hit2.float().mean()),
                 "actors_render_stage_ms": st2[6], "actors_stage_ms_layers": st2,
+                "actors_plain_render_stage_ms": st_pl[6], "actors_background_only_render_stage_ms": st_bg[6],
                 "actors_object_pixels_share": float((o2["alpha_object"] > 0).float().mean())})
 print(json.dumps(out))
