@@ -219,6 +219,45 @@ class ComposedRasterizer(nn.Module):
                 "color_background": color_bg, "alpha_background": alpha_bg,
                 "color_object": color_obj, "alpha_object": alpha_obj}
 
+    def forward_frame(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]], *,
+                      sky_cube=None, ray_matrix=None, sky_fill=0.0, clamp=True, planes=False, rgb8=True,
+                      truncate=True, out=None, layers=False, object_models: Optional[Sequence[bool]] = None,
+                      layer_bg=None) -> dict:
+        """The reference's whole per-frame evaluation path as ONE call on the raw parameters (C ABI
+        ``grpg_forward_composed_frame``): scene-graph composition (street_gaussian_model.py:296-453), the op,
+        ``StreetGaussianRenderer.render``'s clamp / sky composite / clamp (street_gaussian_renderer.py:106-116,
+        236-237) and the simulator's uint8 [H,W,3] conversion (simulator.py:313-314) -- the last three inside the
+        render's epilogue.  ``layers=True`` also returns render_all's two layer renders (forward_layers); the
+        simulator reads ``result['rgb']`` only and does not need them.  Returns a dict: ``rgb8`` (uint8 [H,W,3] on the
+        device; ``out``: a preallocated one), with ``planes=True`` also ``rgb`` (the FINAL colour) / ``depth`` /
+        ``alpha``, with ``layers=True`` the four layer planes; ``radii``, ``num_rendered``."""
+        rs = self.raster_settings
+        lists, pose_t, idft_t = _pack(models, poses)
+        dev = models[0].xyz.device
+        e = torch.Tensor([])
+        if layers and layer_bg is None:
+            layer_bg = torch.ones(3, dtype=torch.float32, device=dev)
+        flags = torch.empty(0, dtype=torch.uint8) if object_models is None else \
+            torch.tensor([1 if f else 0 for f in object_models], dtype=torch.uint8)
+        with torch.no_grad():
+            (n, frame, color, depth, alpha, radii, color_bg, alpha_bg, color_obj,
+             alpha_obj) = _C.rasterize_gaussians_composed_frame(
+                rs.bg, e if layer_bg is None else layer_bg, flags, bool(layers), *lists, pose_t, idft_t,
+                rs.scale_modifier, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                rs.image_width, rs.sh_degree, rs.campos, rs.debug, e if sky_cube is None else sky_cube,
+                e if ray_matrix is None else ray_matrix, float(sky_fill), bool(clamp), bool(planes), bool(rgb8),
+                bool(truncate), out)
+        self.num_rendered = n
+        res = {"num_rendered": n, "radii": radii}
+        if rgb8:
+            res["rgb8"] = frame
+        if planes:
+            res.update(rgb=color, depth=depth, alpha=alpha)
+        if layers:
+            res.update(color_background=color_bg, alpha_background=alpha_bg, color_object=color_obj,
+                       alpha_object=alpha_obj)
+        return res
+
     def forward(self, models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]], means2D=None):
         rs = self.raster_settings
         lists, pose_t, idft_t = _pack(models, poses)

@@ -556,15 +556,21 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                  float tan_fovx, float tan_fovy, float* out_color,
                  float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug,
                  void* hip_stream, const grpg_model_segment* segs, int nseg, unsigned flags = 0u,
-                 DeferSlot* defer = nullptr, bool force_pass3 = false, const LayerArgs* layers = nullptr) {
+                 DeferSlot* defer = nullptr, bool force_pass3 = false, const LayerArgs* layers = nullptr,
+                 const FrameEpilogue* epi = nullptr) {
   g_last_error.clear();
   if (int rc = ensure_device()) return rc;
   if (P < 0 || width <= 0 || height <= 0 || S < 0 || M < 0)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "negative size");
   if (!geometry_alloc || !binning_alloc || !image_alloc)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "buffer allocators must not be NULL");
-  if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth || !out_alpha)
+  if (!background || !viewmatrix || !projmatrix || !cam_pos)
     return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL camera/background/output pointer");
+  // the float planes may be left out only when a frame epilogue delivers the bytes instead (grpg_forward_frame)
+  if ((!out_color || !out_depth || !out_alpha) && !(epi && !epi->planes && epi->rgb8))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "NULL camera/background/output pointer");
+  if (epi && ((flags & GRPG_FORWARD_NO_BACKWARD) == 0u || S != 0))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "a frame epilogue needs an evaluation frame without semantic planes");
   if ((unsigned)P > ID_MASK) return fail(GRPG_ERR_INVALID_ARGUMENT, "P must be < 2^28");
   if (P > 0 && segs == nullptr) {
     if (!means3D || !opacities) return fail(GRPG_ERR_INVALID_ARGUMENT, "means3D/opacities NULL");
@@ -773,14 +779,14 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                              background, out_color, out_depth, out_alpha, work, frame_classes, cap,
                              classified, layers->layer_background, layers->out_color_bg,
                              layers->out_alpha_bg, layers->out_color_obj, layers->out_alpha_obj,
-                             PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3});
+                             PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3}, epi);
       else
       launch_render_forward(stream, ranges, point_list, rec, width, height, cam.gx, cam.gy, background,
                             out_color, out_depth, out_alpha, n_contrib, work, frame_classes, cap,
                             (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, classified,
                             with_ckpt ? &ck : nullptr,
                             PCErr{&((BlobHeader*)img)->pc_timeout, hw->dev_ptr + 3},
-                            S > 0 ? semantics : nullptr, S, out_semantic);
+                            S > 0 ? semantics : nullptr, S, out_semantic, epi);
       STAGE_CHECK("render");
       if (debug)   // the stage check has synchronised: a hand-over timeout of THIS frame is known
         if (int rc = check_async_error(hw)) return rc;
@@ -940,7 +946,7 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
                           P, D, M, S, background, width, height, means3D, shs, colors_precomp, semantics,
                           opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
                           cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, out_semantic, radii,
-                          debug, hip_stream, segs, nseg, flags, defer, true);
+                          debug, hip_stream, segs, nseg, flags, defer, true, layers, epi);
     }
     if (!speculative || R > Rcap || (hier && Rc_seen > Ccap)) {
       // first frame of a shape / exact mode: carve for the count just read.  Capacity overflow: the
@@ -967,9 +973,10 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   } else {
     // P == 0: the reference launches nothing and its pre-zeroed planes stay zero
     // (rasterize_points.cu:85-86,123); write the zeros explicitly.
-    HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * 4, stream));
-    HIP_TRY(hipMemsetAsync(out_depth, 0, N * 4, stream));
-    HIP_TRY(hipMemsetAsync(out_alpha, 0, N * 4, stream));
+    if (out_color) HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * 4, stream));
+    if (out_depth) HIP_TRY(hipMemsetAsync(out_depth, 0, N * 4, stream));
+    if (out_alpha) HIP_TRY(hipMemsetAsync(out_alpha, 0, N * 4, stream));
+    if (epi) launch_frame_epilogue_empty(stream, width, height, *epi, out_color);   // sky over nothing, bytes
     if (S > 0 && out_semantic) HIP_TRY(hipMemsetAsync(out_semantic, 0, (size_t)S * N * 4, stream));
     HIP_TRY(hipMemsetAsync(n_contrib, 0, N * 4, stream));
     if (layers) {
@@ -1211,6 +1218,85 @@ int grpg_forward_composed_layers(grpg_alloc_fn geometry_alloc, void* geometry_us
                       nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
                       projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
                       radii, debug, hip_stream, segments, num_segments, GRPG_FORWARD_NO_BACKWARD, nullptr, false, &la);
+}
+
+// grpg_frame_epilogue -> FrameEpilogue (pointers checked); returns GRPG_OK or fails
+static int resolve_epilogue(const grpg_frame_epilogue* e, bool planes, FrameEpilogue* out) {
+  if (e->sky_cube != nullptr && (e->sky_res <= 0 || e->ray_matrix == nullptr))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "frame epilogue: the sky composite needs sky_res > 0 and a ray matrix");
+  out->sky_cube = e->sky_cube; out->sky_res = e->sky_res;
+  out->ray_m_dev = (e->sky_cube && e->ray_matrix_on_device) ? e->ray_matrix : nullptr;
+  for (int i = 0; i < 9; i++) out->ray_m[i] = (e->sky_cube && !e->ray_matrix_on_device) ? e->ray_matrix[i] : 0.f;
+  out->sky_fill = e->sky_fill; out->clamp = e->clamp; out->rgb8 = e->out_rgb8; out->truncate = e->truncate;
+  out->planes = planes ? 1 : 0;
+  return GRPG_OK;
+}
+
+// layer planes: all four or none
+static int layer_planes_given(const float* a, const float* b, const float* c, const float* d) {
+  const int n = (a != nullptr) + (b != nullptr) + (c != nullptr) + (d != nullptr);
+  return n == 4 ? 1 : (n == 0 ? 0 : -1);
+}
+
+int grpg_forward_frame(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                       void* binning_user, grpg_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                       const float* background, int width, int height, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* opacities, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                       float tan_fovy, const unsigned char* layer_class, const float* layer_background,
+                       float* out_color, float* out_depth, float* out_alpha, float* out_color_bg,
+                       float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj, int* radii, int debug,
+                       void* hip_stream, const grpg_frame_epilogue* epilogue) {
+  g_last_error.clear();
+  const int lay = layer_planes_given(out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj);
+  if (lay < 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "layer planes: give all four or none");
+  if (lay && (!layer_background || (P > 0 && !layer_class)))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs layer_class and layer_background");
+  if (lay && (unsigned)P >= (1u << 27))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs P < 2^27 (the class travels in bit 27 of the point list)");
+  const bool planes = out_color && out_depth && out_alpha;
+  FrameEpilogue fe{};
+  if (epilogue) if (int rc = resolve_epilogue(epilogue, planes, &fe)) return rc;
+  const LayerArgs la = {nullptr, layer_class, layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D,
+                      M, 0, background, width, height, means3D, shs, colors_precomp, nullptr, opacities, scales,
+                      scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                      tan_fovy, out_color, out_depth, out_alpha, nullptr, radii, debug, hip_stream, nullptr, 0,
+                      GRPG_FORWARD_NO_BACKWARD, nullptr, false, lay ? &la : nullptr, epilogue ? &fe : nullptr);
+}
+
+int grpg_forward_composed_frame(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_fn binning_alloc,
+                                void* binning_user, grpg_alloc_fn image_alloc, void* image_user,
+                                const grpg_model_segment* segments, int num_segments,
+                                const unsigned char* segment_class, int D, int M, const float* background,
+                                const float* layer_background, int width, int height, float scale_modifier,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
+                                float* out_alpha, float* out_color_bg, float* out_alpha_bg, float* out_color_obj,
+                                float* out_alpha_obj, int* radii, int debug, void* hip_stream,
+                                const grpg_frame_epilogue* epilogue) {
+  g_last_error.clear();
+  if (int rc = ensure_device()) return rc;
+  long long P = 0;
+  if (int rc = check_segments(segments, num_segments, M, &P)) return rc;
+  if (M < 1 || M > 16 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "SH degree needs (D+1)^2 <= M <= 16");
+  const int lay = layer_planes_given(out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj);
+  if (lay < 0) return fail(GRPG_ERR_INVALID_ARGUMENT, "layer planes: give all four or none");
+  if (lay && !layer_background) return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs layer_background");
+  if (lay && P >= (1ll << 27))
+    return fail(GRPG_ERR_INVALID_ARGUMENT, "a layered frame needs P < 2^27 (the class travels in bit 27 of the point list)");
+  const bool planes = out_color && out_depth && out_alpha;
+  FrameEpilogue fe{};
+  if (epilogue) if (int rc = resolve_epilogue(epilogue, planes, &fe)) return rc;
+  const LayerArgs la = {segment_class, nullptr, layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
+  return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc,
+                      image_user, (int)P, D, M, 0, background, width, height, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
+                      projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_depth, out_alpha, nullptr,
+                      radii, debug, hip_stream, segments, num_segments, GRPG_FORWARD_NO_BACKWARD, nullptr, false,
+                      lay ? &la : nullptr, epilogue ? &fe : nullptr);
 }
 
 int grpg_forward_composed(grpg_alloc_fn geometry_alloc, void* geometry_user,

@@ -647,9 +647,9 @@ pack_hwc_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, const
                 bv[4] = {bl.x, bl.y, bl.z, bl.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      b[3 * k + 0] = (unsigned char)(fminf(fmaxf(rv[k], 0.f), 1.f) * 255.0f + bias);
-      b[3 * k + 1] = (unsigned char)(fminf(fmaxf(gv[k], 0.f), 1.f) * 255.0f + bias);
-      b[3 * k + 2] = (unsigned char)(fminf(fmaxf(bv[k], 0.f), 1.f) * 255.0f + bias);
+      b[3 * k + 0] = colour_u8(rv[k], bias);
+      b[3 * k + 1] = colour_u8(gv[k], bias);
+      b[3 * k + 2] = colour_u8(bv[k], bias);
     }
     uint32_t w[3];
 #pragma unroll
@@ -662,7 +662,7 @@ pack_hwc_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, const
     for (size_t p = p0; p < npix && p < p0 + 4; p++) {
 #pragma unroll
       for (int c = 0; c < 3; c++)
-        d8[3 * p + c] = (unsigned char)(fminf(fmaxf(src[c * npix + p], 0.f), 1.f) * 255.0f + bias);
+        d8[3 * p + c] = colour_u8(src[c * npix + p], bias);
     }
   }
 }

@@ -39,6 +39,7 @@
 
 #include "blend_math.h"
 #include "common.h"
+#include "sky_math.h"
 
 #ifndef GRPG_LAYERS_ABLATE
 #define GRPG_LAYERS_ABLATE 0
@@ -441,39 +442,88 @@ __device__ __forceinline__ bool blend_quad_tail(WavePix<1>& s, const Cols& cols,
 //              saw the very same splats (same bits), the object layer saw none (T = 1, C = 0);
 //              pixel3(): a tile with object entries, three states.
 // ------------------------------------------------------------------------------------------
-struct PlainOut {
+// What the reference's callers do with the composition's colour behind the op, inside the render's own epilogue
+// (grpg_forward_frame; a frame without it: FrameEpi::on == 0 and none of this is compiled in, EPI = false):
+//   rgb = clamp(C + T bg)                           render_kernel's evaluation clamp (street_gaussian_renderer.py:236)
+//   rgb = clamp(rgb + clamp(sky) (1 - acc))         StreetGaussianRenderer.render (:106-116), acc = 1 - T
+//   bytes [H,W,3] = uint8(rgb * 255)                the simulator's frame (simulator.py:313-314)
+// The state is in registers when the walk ends: the stand-alone chain (three launches) wrote the colour and
+// alpha planes, read them back for the sky composite, wrote the colour again and read it a third time to pack.
+struct FrameEpi {
+  SkyArgs sky;              // sky.cube == NULL: no sky composite
+  int clamp;                // evaluation mode: both clamps
+  unsigned char* rgb8;      // [H,W,3] interleaved bytes, or NULL
+  float bias;               // 0 = truncate like astype(np.uint8), 0.5 = round to nearest
+  int planes;               // the float planes are written too (colour = the FINAL rgb, depth, alpha)
+};
+// final rgb of a pixel from its blended colour (background included) and T; optional byte store
+template <bool EPI>
+__device__ __forceinline__ void frame_finish(const FrameEpi& e, const int px, const int py, const int W, const int H,
+                                             const float T, float (&rgb)[3]) {
+  if constexpr (EPI) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    if (e.clamp) { rgb[0] = clamp01(rgb[0]); rgb[1] = clamp01(rgb[1]); rgb[2] = clamp01(rgb[2]); }
+    if (e.sky.cube != nullptr) {
+      const float acc = 1.0f - T, tr = 1.0f - acc;     // (the stand-alone launch reads acc from the alpha plane)
+      float sky[3];
+      sky_pixel(e.sky, px, py, pix, HW, true, tr, sky);
+      rgb[0] = sky_over(rgb[0], sky[0], tr, e.clamp);
+      rgb[1] = sky_over(rgb[1], sky[1], tr, e.clamp);
+      rgb[2] = sky_over(rgb[2], sky[2], tr, e.clamp);
+    }
+    if (e.rgb8 != nullptr) {
+      unsigned char* d = e.rgb8 + 3 * pix;
+      d[0] = colour_u8(rgb[0], e.bias); d[1] = colour_u8(rgb[1], e.bias); d[2] = colour_u8(rgb[2], e.bias);
+    }
+  }
+}
+
+template <bool EPI>
+struct PlainOutT {
   const float* bg; float* out_color; float* out_depth; float* out_alpha; uint32_t* n_contrib;
   int W, H;
+  FrameEpi epi;
   template <bool AUX>
   __device__ __forceinline__ void pixel(const int px, const int py, const float T, const v2f CrCg, const v2f CbD,
                                         const uint32_t last) const {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-    out_color[pix] = CrCg.x + T * bg[0];
-    out_color[HW + pix] = CrCg.y + T * bg[1];
-    out_color[2 * HW + pix] = CbD.x + T * bg[2];
-    out_alpha[pix] = 1.0f - T;
-    out_depth[pix] = CbD.y;
+    float rgb[3] = {CrCg.x + T * bg[0], CrCg.y + T * bg[1], CbD.x + T * bg[2]};
+    frame_finish<EPI>(epi, px, py, W, H, T, rgb);
+    if (!EPI || epi.planes) {
+      out_color[pix] = rgb[0];
+      out_color[HW + pix] = rgb[1];
+      out_color[2 * HW + pix] = rgb[2];
+      out_alpha[pix] = 1.0f - T;
+      out_depth[pix] = CbD.y;
+    }
     if (AUX) n_contrib[pix] = last;
   }
 };
+typedef PlainOutT<false> PlainOut;
 
 struct LayerOut {
   const float* bg_layer;     // [3] background of the two layer planes (the reference renders them on white)
   float* color_bg; float* alpha_bg; float* color_obj; float* alpha_obj;
 };
 
-struct LayersOut {
+template <bool EPI>
+struct LayersOutT {
   const float* bg; float* out_color; float* out_depth; float* out_alpha;
   int W, H;
   LayerOut lo;
+  FrameEpi epi;
   // the composition's planes / the background layer's / the object layer's, from that layer's final state
   __device__ __forceinline__ void pixel_a(const int px, const int py, const float T, const v2f CrCg, const v2f CbD) const {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-    out_color[pix] = CrCg.x + T * bg[0];
-    out_color[HW + pix] = CrCg.y + T * bg[1];
-    out_color[2 * HW + pix] = CbD.x + T * bg[2];
-    out_alpha[pix] = 1.0f - T;
-    out_depth[pix] = CbD.y;
+    float rgb[3] = {CrCg.x + T * bg[0], CrCg.y + T * bg[1], CbD.x + T * bg[2]};
+    frame_finish<EPI>(epi, px, py, W, H, T, rgb);
+    if (!EPI || epi.planes) {
+      out_color[pix] = rgb[0];
+      out_color[HW + pix] = rgb[1];
+      out_color[2 * HW + pix] = rgb[2];
+      out_alpha[pix] = 1.0f - T;
+      out_depth[pix] = CbD.y;
+    }
   }
   __device__ __forceinline__ void pixel_layer(float* __restrict__ color, float* __restrict__ alpha, const int px,
                                               const int py, const float T, const v2f CrCg, const v2f CbD) const {
@@ -502,6 +552,7 @@ struct LayersOut {
     pixel3(px, py, T, CrCg, CbD, T, CrCg, CbD, 1.0f, (v2f){0.f, 0.f}, (v2f){0.f, 0.f});
   }
 };
+typedef LayersOutT<false> LayersOut;
 
 struct WaveTrace { uint32_t batches, survivors, blends, t_stage, t_loop; uint32_t it[4], cyc[4]; };
 
@@ -1694,11 +1745,13 @@ __device__ __forceinline__ void pc3_consumer(const float4* __restrict__ buf0, co
 // staged rows per wave: 3 waves per SIMD / 3 workgroups per CU.
 constexpr int RENDER_MIN_WAVES = 4;
 
-template <bool LAYERS> struct FrameOut { typedef PlainOut type; };
-template <> struct FrameOut<true> { typedef LayersOut type; };
-__device__ __forceinline__ PlainOut make_out(const PlainOut& p, const LayerOut&, PlainOut*) { return p; }
-__device__ __forceinline__ LayersOut make_out(const PlainOut& p, const LayerOut& lo, LayersOut*) {
-  return LayersOut{p.bg, p.out_color, p.out_depth, p.out_alpha, p.W, p.H, lo};
+template <bool LAYERS, bool EPI> struct FrameOut { typedef PlainOutT<EPI> type; };
+template <bool EPI> struct FrameOut<true, EPI> { typedef LayersOutT<EPI> type; };
+template <bool EPI>
+__device__ __forceinline__ PlainOutT<EPI> make_out(const PlainOutT<EPI>& p, const LayerOut&, PlainOutT<EPI>*) { return p; }
+template <bool EPI>
+__device__ __forceinline__ LayersOutT<EPI> make_out(const PlainOutT<EPI>& p, const LayerOut& lo, LayersOutT<EPI>*) {
+  return LayersOutT<EPI>{p.bg, p.out_color, p.out_depth, p.out_alpha, p.W, p.H, lo, p.epi};
 }
 
 // Measured and removed: XCD-contiguous work assignment (0.248 vs 0.232 ms:
@@ -1708,7 +1761,8 @@ __device__ __forceinline__ LayersOut make_out(const PlainOut& p, const LayerOut&
 #ifndef GRPG_LAYERS_MIN_WAVES   // experiment builds: waves per SIMD the layered kernel is allocated for
 #define GRPG_LAYERS_MIN_WAVES 4
 #endif
-template <bool WRITE_AUX, int GPI_L, bool TRACE = false, int NSEM = 0, bool LAYERS = false>
+// EPI: the frame epilogue (FrameEpi above) behind the blend, evaluation frames only
+template <bool WRITE_AUX, int GPI_L, bool TRACE = false, int NSEM = 0, bool LAYERS = false, bool EPI = false>
 __global__ void __launch_bounds__(256, NSEM > 0 ? 3 : (LAYERS ? GRPG_LAYERS_MIN_WAVES : RENDER_MIN_WAVES))
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RecView rec, const int W, const int H, const int gx,
@@ -1720,10 +1774,10 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                       const SemSrc sem, float* __restrict__ out_semantic,
                       uint32_t* __restrict__ trace = nullptr, const int ablate = 0,
                       const LayerOut lo = LayerOut{nullptr, nullptr, nullptr, nullptr, nullptr},
-                      const TileObjBits ob = TileObjBits{nullptr, 0}) {
-  static_assert(!LAYERS || (!WRITE_AUX && NSEM == 0 && !TRACE), "layered frames: evaluation only, no semantic planes");
-  typedef typename FrameOut<LAYERS>::type Out;
-  const Out out = make_out(PlainOut{bg, out_color, out_depth, out_alpha, n_contrib, W, H}, lo, (Out*)nullptr);
+                      const TileObjBits ob = TileObjBits{nullptr, 0}, const FrameEpi epi = FrameEpi{}) {
+  static_assert(!(LAYERS || EPI) || (!WRITE_AUX && NSEM == 0 && !TRACE), "layered frames / frame epilogue: evaluation only, no semantic planes");
+  typedef typename FrameOut<LAYERS, EPI>::type Out;
+  const Out out = make_out(PlainOutT<EPI>{bg, out_color, out_depth, out_alpha, n_contrib, W, H, epi}, lo, (Out*)nullptr);
   __shared__ float4 s_rec[RW_WAVES][WAVE * REC_F4];
   __shared__ uint32_t s_qid[RW_WAVES][QCAP];
   __shared__ uint32_t s_qpos[RW_WAVES][QCAP];
@@ -1885,6 +1939,34 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   }
 }
 
+static FrameEpi make_frame_epi(const FrameEpilogue* e) {
+  FrameEpi d{};
+  if (e == nullptr) return d;
+  d.sky.cube = e->sky_cube; d.sky.res = e->sky_res; d.sky.fill = e->sky_fill; d.sky.clamp_out = e->clamp;
+  d.sky.m_dev = e->ray_m_dev; d.sky.mask = nullptr; d.sky.jitter = nullptr;
+  for (int i = 0; i < 9; i++) d.sky.m[i] = e->ray_m_dev ? 0.f : e->ray_m[i];
+  d.clamp = e->clamp; d.rgb8 = e->rgb8; d.bias = e->truncate ? 0.0f : 0.5f; d.planes = e->planes;
+  return d;
+}
+
+// a frame without Gaussians through the same epilogue: blended colour 0 (NOT the background: the reference's
+// pre-zeroed planes stay zero when nothing is launched, rasterize_points.cu:85-86,123), T = 1
+__global__ void __launch_bounds__(256)
+frame_epilogue_empty_kernel(const int W, const int H, const FrameEpi epi, float* __restrict__ out_color) {
+  const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (px >= W || py >= H) return;
+  float rgb[3] = {0.f, 0.f, 0.f};
+  frame_finish<true>(epi, px, py, W, H, 1.0f, rgb);
+  if (epi.planes && out_color != nullptr) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    out_color[pix] = rgb[0]; out_color[HW + pix] = rgb[1]; out_color[2 * HW + pix] = rgb[2];
+  }
+}
+void launch_frame_epilogue_empty(hipStream_t s, int W, int H, const FrameEpilogue& epi, float* out_color) {
+  const dim3 grid((W + 63) / 64, (H + 3) / 4);
+  frame_epilogue_empty_kernel<<<grid, 256, 0, s>>>(W, H, make_frame_epi(&epi), out_color);
+}
+
 __global__ void __launch_bounds__(256)
 fill_layer_planes_kernel(const size_t N, const float* __restrict__ layer_background, float* __restrict__ color_bg,
                          float* __restrict__ alpha_bg, float* __restrict__ color_obj, float* __restrict__ alpha_obj) {
@@ -1907,7 +1989,8 @@ void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_li
                           int gx, int gy, const float* bg, float* out_color, float* out_depth, float* out_alpha,
                           uint32_t* work, const TileClasses cls, uint32_t cap, bool classified,
                           const float* layer_background, float* out_color_bg,
-                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj, const PCErr pc_err) {
+                          float* out_alpha_bg, float* out_color_obj, float* out_alpha_obj, const PCErr pc_err,
+                          const FrameEpilogue* epi) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   // (the class of every list entry is already there: bit 27, from the record -- hier_binning.hip / binning.hip)
@@ -1919,9 +2002,14 @@ void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_li
   const uint32_t pc_slots = 4u * (uint32_t)((size_t)cap / (cls.c0_obj_min < cls.c0_min ? cls.c0_obj_min : cls.c0_min) + 1);
   const CkptArgs ck = CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
   const SemSrc sem = {nullptr, 0, nullptr};
-  render_forward_kernel<false, 2, false, 0, true><<<ntiles + pc_slots, 256, 0, s>>>(
-      ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, out_alpha, nullptr,
-      pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj);
+  if (epi)
+    render_forward_kernel<false, 2, false, 0, true, true><<<ntiles + pc_slots, 256, 0, s>>>(
+        ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, out_alpha, nullptr,
+        pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj, make_frame_epi(epi));
+  else
+    render_forward_kernel<false, 2, false, 0, true><<<ntiles + pc_slots, 256, 0, s>>>(
+        ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, out_alpha, nullptr,
+        pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj);
 }
 
 // N-channel "semantic" planes (forward.cu:442-444): same traversal and the same accept/reject
@@ -2018,7 +2106,7 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
                            uint32_t* n_contrib, uint32_t* work /* [4 + 4T] scratch */,
                            const TileClasses cls, uint32_t R, bool aux, bool classified,
                            const CkptArgs* ckp, const PCErr pc_err, const float* semantics, int S,
-                           float* out_semantic) {
+                           float* out_semantic, const FrameEpilogue* epi) {
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   const CkptArgs ck = (aux && ckp) ? *ckp : CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
@@ -2052,7 +2140,11 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
 #endif
   // the light (4 pixels per lane) path evaluates two splats per inner iteration (one: measured
   // slower); the heavy path always evaluates quads
-  if (S > 0) {
+  if (epi != nullptr && !aux && S == 0) {   // evaluation frame with the callers' epilogue fused in (grpg_forward_frame)
+    render_forward_kernel<false, 2, false, 0, false, true><<<ntiles + pc_slots, 256, 0, s>>>(
+        RF_ARGS, nullptr, 0, LayerOut{nullptr, nullptr, nullptr, nullptr, nullptr}, TileObjBits{nullptr, 0},
+        make_frame_epi(epi));
+  } else if (S > 0) {
     // semantic planes ride in the heavy path: up to RENDER_NSEM channels in this launch, the rest
     // (S > RENDER_NSEM) in the stand-alone kernel below
     if (aux) render_forward_kernel<true, 2, false, RENDER_NSEM><<<ntiles + pc_slots, 256, 0, s>>>(RF_ARGS);

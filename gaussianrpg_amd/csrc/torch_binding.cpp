@@ -231,6 +231,126 @@ RasterizeGaussiansLayers(const torch::Tensor& background, const torch::Tensor& l
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj);
 }
 
+// ---- the frame epilogue (grpg_forward_frame / grpg_forward_composed_frame, ABI 6) ----
+// sky_cube: [6,res,res,3] float32 on the device, or an empty tensor (no sky composite); ray_matrix: 9 floats, CPU
+// (taken by value) or device (read by the kernel: no host round trip).
+struct EpilogueArgs {
+  grpg_frame_epilogue e;
+  torch::Tensor k_cube, k_rm, rgb8;
+};
+static void make_epilogue(EpilogueArgs& a, const torch::Tensor& like, const torch::Tensor& sky_cube,
+                          const torch::Tensor& ray_matrix, const float sky_fill, const bool clamp, const bool want_rgb8,
+                          const bool truncate, const c10::optional<torch::Tensor>& out_rgb8, const int H, const int W) {
+  a.e = grpg_frame_epilogue{nullptr, 0, nullptr, 0, sky_fill, clamp ? 1 : 0, nullptr, truncate ? 1 : 0};
+  if (sky_cube.defined() && sky_cube.numel() != 0) {
+    TORCH_CHECK(sky_cube.dim() == 4 && sky_cube.size(0) == 6 && sky_cube.size(1) == sky_cube.size(2) &&
+                    sky_cube.size(3) == 3 && sky_cube.scalar_type() == torch::kFloat32 && sky_cube.device() == like.device(),
+                "sky_cube must be a float32 [6,res,res,3] tensor on the frame's device");
+    TORCH_CHECK(ray_matrix.defined() && ray_matrix.numel() == 9 && ray_matrix.scalar_type() == torch::kFloat32,
+                "ray_matrix must hold 9 float32 values (row-major R^T K^-1)");
+    a.k_cube = sky_cube.contiguous();
+    a.k_rm = ray_matrix.contiguous();
+    if (a.k_rm.is_cuda()) TORCH_CHECK(a.k_rm.device() == like.device(), "ray_matrix on another device");
+    a.e.sky_cube = a.k_cube.data_ptr<float>();
+    a.e.sky_res = (int)a.k_cube.size(1);
+    a.e.ray_matrix = a.k_rm.data_ptr<float>();
+    a.e.ray_matrix_on_device = a.k_rm.is_cuda() ? 1 : 0;
+  }
+  if (want_rgb8) {
+    if (out_rgb8.has_value() && out_rgb8->defined()) {
+      TORCH_CHECK(out_rgb8->scalar_type() == torch::kByte && out_rgb8->numel() == (int64_t)3 * H * W &&
+                      out_rgb8->is_contiguous() && out_rgb8->device() == like.device(),
+                  "out must be a contiguous uint8 tensor of H*W*3 elements on the frame's device");
+      a.rgb8 = *out_rgb8;
+    } else {
+      a.rgb8 = torch::empty({H, W, 3}, like.options().dtype(torch::kByte));
+    }
+    a.e.out_rgb8 = a.rgb8.data_ptr<unsigned char>();
+  } else {
+    a.rgb8 = torch::empty({0}, like.options().dtype(torch::kByte));
+  }
+}
+
+// returns (num_rendered, rgb8, color, depth, alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj); tensors that
+// were not asked for are empty
+typedef std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+                   torch::Tensor, torch::Tensor, torch::Tensor> FrameResult;
+
+FrameResult RasterizeGaussiansFrame(
+    const torch::Tensor& background, const torch::Tensor& layer_background, const torch::Tensor& layer_class,
+    const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
+    const torch::Tensor& scales, const torch::Tensor& rotations, const float scale_modifier,
+    const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+    const float tan_fovx, const float tan_fovy, const int image_height, const int image_width,
+    const torch::Tensor& sh, const int degree, const torch::Tensor& campos, const bool debug,
+    const torch::Tensor& sky_cube, const torch::Tensor& ray_matrix, const float sky_fill, const bool clamp,
+    const bool want_planes, const bool want_rgb8, const bool truncate, const c10::optional<torch::Tensor>& out_rgb8) {
+  if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
+  require_device(means3D);
+  TORCH_CHECK(means3D.scalar_type() == torch::kFloat32, "means3D must be float32");
+  TORCH_CHECK(want_planes || want_rgb8, "forward_frame: ask for the float planes, the rgb8 frame, or both");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+  const int P = means3D.size(0);
+  const int H = image_height, W = image_width;
+  const bool layered = layer_class.defined() && layer_class.numel() != 0;
+  torch::Tensor k_cls;
+  if (layered) {
+    TORCH_CHECK(layer_class.numel() == P && layer_class.device() == means3D.device() &&
+                    (layer_class.scalar_type() == torch::kUInt8 || layer_class.scalar_type() == torch::kBool),
+                "layer_class must be a uint8 / bool tensor of P elements on the device of means3D");
+    k_cls = layer_class.contiguous();
+  }
+  auto fo = means3D.options().dtype(torch::kFloat32);
+  auto none = [&]() { return torch::empty({0}, fo); };
+  torch::Tensor out_color = want_planes ? torch::empty({GRPG_NUM_CHANNELS, H, W}, fo) : none();
+  torch::Tensor out_depth = want_planes ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor out_alpha = want_planes ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor color_bg = layered ? torch::empty({GRPG_NUM_CHANNELS, H, W}, fo) : none();
+  torch::Tensor alpha_bg = layered ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor color_obj = layered ? torch::empty({GRPG_NUM_CHANNELS, H, W}, fo) : none();
+  torch::Tensor alpha_obj = layered ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
+  auto byte_opts = means3D.options().dtype(torch::kByte);
+  torch::Tensor geomBuffer = torch::empty({0}, byte_opts), binningBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+  int M = 0;
+  if (sh.size(0) != 0) M = sh.size(1);
+  torch::Tensor k_bg, k_lbg, k_means, k_sh, k_col, k_op, k_sc, k_rot, k_cov, k_view, k_proj, k_cam;
+  const float* p_bg = fptr(background, means3D, "background", k_bg);
+  const float* p_lbg = fptr(layer_background, means3D, "layer_background", k_lbg);
+  const float* p_means = fptr(means3D, means3D, "means3D", k_means);
+  const float* p_sh = fptr(sh, means3D, "sh", k_sh);
+  const float* p_col = fptr(colors, means3D, "colors_precomp", k_col);
+  const float* p_op = fptr(opacity, means3D, "opacities", k_op);
+  const float* p_sc = fptr(scales, means3D, "scales", k_sc);
+  const float* p_rot = fptr(rotations, means3D, "rotations", k_rot);
+  const float* p_cov = fptr(cov3D_precomp, means3D, "cov3D_precomp", k_cov);
+  const float* p_view = fptr(viewmatrix, means3D, "viewmatrix", k_view);
+  const float* p_proj = fptr(projmatrix, means3D, "projmatrix", k_proj);
+  const float* p_cam = fptr(campos, means3D, "campos", k_cam);
+  TORCH_CHECK(p_bg && p_view && p_proj && p_cam, "bg/viewmatrix/projmatrix/campos must be non-empty");
+  TORCH_CHECK(!layered || p_lbg, "layer_background must be non-empty in a layered frame");
+  EpilogueArgs ea;
+  make_epilogue(ea, means3D, sky_cube, ray_matrix, sky_fill, clamp, want_rgb8, truncate, out_rgb8, H, W);
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  int rendered;
+  {
+    pybind11::gil_scoped_release nogil;
+    rendered = grpg_forward_frame(
+        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, P, degree, M, p_bg, W, H,
+        p_means, p_sh, p_col, p_op, p_sc, scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, tan_fovx, tan_fovy,
+        (layered && P > 0) ? (const unsigned char*)k_cls.data_ptr() : nullptr, p_lbg,
+        want_planes ? out_color.data_ptr<float>() : nullptr, want_planes ? out_depth.data_ptr<float>() : nullptr,
+        want_planes ? out_alpha.data_ptr<float>() : nullptr, layered ? color_bg.data_ptr<float>() : nullptr,
+        layered ? alpha_bg.data_ptr<float>() : nullptr, layered ? color_obj.data_ptr<float>() : nullptr,
+        layered ? alpha_obj.data_ptr<float>() : nullptr, P > 0 ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0,
+        (void*)stream, &ea.e);
+  }
+  if (rendered < 0) raise_abi_error("grpg_forward_frame", rendered);
+  return std::make_tuple(rendered, ea.rgb8, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj,
+                         alpha_obj);
+}
+
 // (ok, num_rendered): ok = 1 valid, 0 the frame must be rendered again, -1 not ready (wait = false)
 std::tuple<int, int> FrameStatus(const int ticket, const bool wait) {
   int R = 0, rc;
@@ -614,6 +734,73 @@ RasterizeGaussiansComposedLayers(const torch::Tensor& background, const torch::T
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj);
 }
 
+// The scene-graph frame as one call (grpg_forward_composed_frame): composition + op (+ layers) + sky + clamp + rgb8.
+FrameResult RasterizeGaussiansComposedFrame(
+    const torch::Tensor& background, const torch::Tensor& layer_background, const torch::Tensor& object_model,
+    const bool layered, const std::vector<torch::Tensor>& xyz, const std::vector<torch::Tensor>& scaling,
+    const std::vector<torch::Tensor>& rotation, const std::vector<torch::Tensor>& opacity,
+    const std::vector<torch::Tensor>& features_dc, const std::vector<torch::Tensor>& features_rest,
+    const std::vector<torch::Tensor>& flip, const torch::Tensor& poses, const torch::Tensor& idft,
+    const float scale_modifier, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+    const float tan_fovx, const float tan_fovy, const int image_height, const int image_width, const int degree,
+    const torch::Tensor& campos, const bool debug, const torch::Tensor& sky_cube, const torch::Tensor& ray_matrix,
+    const float sky_fill, const bool clamp, const bool want_planes, const bool want_rgb8, const bool truncate,
+    const c10::optional<torch::Tensor>& out_rgb8) {
+  SegmentPack pk = pack_segments(xyz, scaling, rotation, opacity, features_dc, features_rest, flip, poses, idft);
+  const torch::Tensor& like = xyz[0];
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
+  TORCH_CHECK(want_planes || want_rgb8, "forward_frame: ask for the float planes, the rgb8 frame, or both");
+  const int H = image_height, W = image_width;
+  const unsigned char* p_cls = nullptr;
+  torch::Tensor k_cls;
+  if (layered && object_model.numel() != 0) {
+    TORCH_CHECK(object_model.numel() == (int64_t)pk.segs.size() && !object_model.is_cuda() &&
+                    (object_model.scalar_type() == torch::kUInt8 || object_model.scalar_type() == torch::kBool),
+                "object_model must be a uint8 / bool HOST tensor with one element per model");
+    k_cls = object_model.contiguous();
+    p_cls = (const unsigned char*)k_cls.data_ptr();
+  }
+  auto fo = like.options().dtype(torch::kFloat32);
+  auto none = [&]() { return torch::empty({0}, fo); };
+  torch::Tensor out_color = want_planes ? torch::empty({GRPG_NUM_CHANNELS, H, W}, fo) : none();
+  torch::Tensor out_depth = want_planes ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor out_alpha = want_planes ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor color_bg = layered ? torch::empty({GRPG_NUM_CHANNELS, H, W}, fo) : none();
+  torch::Tensor alpha_bg = layered ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor color_obj = layered ? torch::empty({GRPG_NUM_CHANNELS, H, W}, fo) : none();
+  torch::Tensor alpha_obj = layered ? torch::empty({1, H, W}, fo) : none();
+  torch::Tensor radii = torch::empty({pk.P}, like.options().dtype(torch::kInt32));
+  auto byte_opts = like.options().dtype(torch::kByte);
+  torch::Tensor geomBuffer = torch::empty({0}, byte_opts), binningBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+  torch::Tensor k_bg, k_lbg, k_view, k_proj, k_cam;
+  const float* p_bg = fptr(background, like, "background", k_bg);
+  const float* p_lbg = fptr(layer_background, like, "layer_background", k_lbg);
+  const float* p_view = fptr(viewmatrix, like, "viewmatrix", k_view);
+  const float* p_proj = fptr(projmatrix, like, "projmatrix", k_proj);
+  const float* p_cam = fptr(campos, like, "campos", k_cam);
+  TORCH_CHECK(p_bg && p_view && p_proj && p_cam, "bg/viewmatrix/projmatrix/campos must be non-empty");
+  TORCH_CHECK(!layered || p_lbg, "layer_background must be non-empty in a layered frame");
+  EpilogueArgs ea;
+  make_epilogue(ea, like, sky_cube, ray_matrix, sky_fill, clamp, want_rgb8, truncate, out_rgb8, H, W);
+  hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  int rendered;
+  {
+    pybind11::gil_scoped_release nogil;
+    rendered = grpg_forward_composed_frame(
+        resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob, &imgBuffer, pk.segs.data(),
+        (int)pk.segs.size(), p_cls, degree, pk.M, p_bg, p_lbg, W, H, scale_modifier, p_view, p_proj, p_cam, tan_fovx,
+        tan_fovy, want_planes ? out_color.data_ptr<float>() : nullptr,
+        want_planes ? out_depth.data_ptr<float>() : nullptr, want_planes ? out_alpha.data_ptr<float>() : nullptr,
+        layered ? color_bg.data_ptr<float>() : nullptr, layered ? alpha_bg.data_ptr<float>() : nullptr,
+        layered ? color_obj.data_ptr<float>() : nullptr, layered ? alpha_obj.data_ptr<float>() : nullptr,
+        radii.data_ptr<int>(), debug ? 1 : 0, (void*)stream, &ea.e);
+  }
+  if (rendered < 0) raise_abi_error("grpg_forward_composed_frame", rendered);
+  return std::make_tuple(rendered, ea.rgb8, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj,
+                         alpha_obj);
+}
+
 // Training backward of the fused composition (grpg_backward_composed): gradients with respect to
 // every model's RAW parameter tensors, means2D [P,3] (densification statistic) and the poses [n,8].
 std::tuple<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>,
@@ -930,6 +1117,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("campos"), pybind11::arg("debug"), pybind11::arg("for_backward") = false);
   m.def("rasterize_gaussians_composed_backward", &RasterizeGaussiansComposedBackward);
   m.def("rasterize_gaussians_composed_layers", &RasterizeGaussiansComposedLayers);
+  m.def("rasterize_gaussians_frame", &RasterizeGaussiansFrame);
+  m.def("rasterize_gaussians_composed_frame", &RasterizeGaussiansComposedFrame);
   m.def("compose", &Compose);
   m.def("sky_composite", &SkyComposite, pybind11::arg("cube"), pybind11::arg("ray_matrix"),
         pybind11::arg("fill"), pybind11::arg("clamp_out"), pybind11::arg("rgb"), pybind11::arg("acc"),

@@ -36,6 +36,17 @@ def ray_matrix(K: torch.Tensor, w2c: torch.Tensor) -> torch.Tensor:
     return (R64.transpose(0, 1) @ torch.linalg.inv_ex(K64).inverse).float().contiguous()
 
 
+def ray_matrix_host(K, w2c) -> torch.Tensor:
+    """The same matrix from HOST values (nested lists / numpy / CPU tensors), as a CPU float32 tensor: the fused frame
+    epilogue (``forward_frame``) then takes it by value as a kernel argument -- no device work at all.  A closed-loop
+    simulator has the frame's pose on the host anyway (it arrives in a message); inverting a 3 x 3 matrix on the
+    device costs a dozen tiny launches (rocSOLVER getrf / substitution / laswp: ~100 us of a 900 us frame)."""
+    import numpy as np
+    K64 = np.asarray(K.detach().cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float64)
+    R64 = np.asarray(w2c.detach().cpu() if isinstance(w2c, torch.Tensor) else w2c, dtype=np.float64)[:3, :3]
+    return torch.from_numpy((R64.T @ np.linalg.inv(K64)).astype(np.float32)).contiguous()
+
+
 def _camera_args(camera):
     """(K, w2c, H, W) of a reference ``Camera`` (lib/utils/camera_utils.py): ``world_view_transform``
     is the TRANSPOSED world-to-camera matrix (sky_cubemap.py:88)."""
