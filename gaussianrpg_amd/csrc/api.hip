@@ -363,9 +363,12 @@ void remember_geom(const void* ptr, int P, bool has_grad) {
   }
   slot->ptr = ptr; slot->P = P; slot->has_grad = has_grad; slot->stamp = ++g_geom_clock;
 }
-// The table is ADVISORY: entries are never invalidated when a caller frees or copies a
-// blob, so only its "yes, the training forward of this P carved that address" answer is taken as is
-// (the training loop's case: no host round trip).  A "no" (possibly stale: a reloaded training blob
+// The table is ADVISORY: every forward of this process overwrites the entry of the address it carves
+// (an evaluation forward at a recycled address turns a "yes" into a "no"), but a blob the CALLER copies into an
+// address a training forward of the same P once carved is invisible to it -- the one case left in which the fast
+// path vouches for a buffer it has not seen (validating every call would cost the training loop a host wait per
+// backward: the host could no longer run ahead of the device).  Only its "yes, the training forward of this P
+// carved that address" answer is taken as is (the training loop's case: no host round trip).  A "no" (possibly stale: a reloaded training blob
 // at an address an evaluation forward used) or an unknown address is settled by the geometry header
 // itself -- one 4-byte read behind the stream's work, off the hot path.
 // returns GRPG_OK, or the error the backward must return
@@ -375,6 +378,14 @@ int geom_check_backward(const void* ptr, int P, hipStream_t stream) {
     for (auto& g : g_geom_seen)
       if (g.ptr == ptr && g.P == P && g.has_grad) return GRPG_OK;
   }
+  // An address the table does not vouch for: the blob's own header decides.  That is a host read behind the
+  // stream's work -- grpg_backward is NOT asynchronous for such a blob (documented in grpg_rasterizer.h), and a
+  // stream that is being captured into a graph cannot be waited for at all: refuse instead of breaking the capture.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(GRPG_ERR_BAD_BUFFER, "grpg_backward under stream capture needs the geometry buffer of a training "
+                                     "forward made by this process (its address is not on record, and reading the "
+                                     "header would synchronize the capturing stream)");
   BlobHeader h;
   hipError_t e = hipMemcpyAsync(&h, ptr, sizeof(BlobHeader), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);

@@ -281,6 +281,9 @@ void launch_emit_coarse(hipStream_t s, const uint32_t* V_dev, const uint32_t* Rc
 //   3. then exactly emit_kernel<true>'s window logic on those offsets.
 // ------------------------------------------------------------------------------------------
 constexpr int FUSED_MAX_BLOCKS = 4 * EMIT_THREADS;   // 2048 blocks = 4 M Gaussians (the fat sort's limit)
+// the fused emit needs the fat sort's depth-ordered payload: whatever the fat sort accepts must fit the spine
+static_assert((size_t)DS_MAX_CHUNKS * DS_CHUNK <= (size_t)FUSED_MAX_BLOCKS * SC_CHUNK,
+              "emit_coarse_fused_kernel: the spine must hold the block sums of the largest fat-sorted frame");
 constexpr int FUSED_WIN = 2 * SC_CHUNK;              // Gaussians whose offsets a workgroup computes
 static_assert(FUSED_WIN == 8 * EMIT_THREADS, "8 counts per thread");
 static_assert(SC_CHUNK == EMIT_PER_BLOCK, "a slot block's owners must fit two Gaussian blocks");
@@ -376,7 +379,7 @@ emit_coarse_fused_kernel(const uint32_t* __restrict__ V_dev, uint32_t* __restric
     for (int k = 0; k < 8; k++) sum += c[k];
     uint32_t dummy;
     uint32_t ex = emit_block_inclusive(sum, s_wave, &dummy) - sum + s_spine[B0];
-    if (tid < 2) s_win[tid] = 0u;
+    if (tid < 2) s_win[tid] = 0xFFFFFFFFu;   // "owner not seen" (a zero count must not go unnoticed)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -390,8 +393,25 @@ emit_coarse_fused_kernel(const uint32_t* __restrict__ V_dev, uint32_t* __restric
     }
   }
   __syncthreads();
+  // The owners of the first and the last slot were seen by the threads that hold them -- as long as every one of
+  // the V entries owns a slot (the fat sort drops culled Gaussians, a visible one covers >= 1 super-tile).  Should a
+  // zero count ever arrive, a slot's owner may go unseen (its offset interval is found by nobody) or lie beyond the
+  // first 2049 entries: fall back to emit_kernel<true>'s search -- the LAST entry whose offset is <= the slot (zero-
+  // count entries share their successor's offset and sort in front of it; step 3's atomicMax resolves such ties the
+  // same way) -- over the 4096 offsets this workgroup holds; a window that would reach past them is clamped (only a
+  // run of > 2048 slot-less entries could do that, and those entries own no output).
+  if (tid < 2 && s_win[tid] == 0xFFFFFFFFu) {
+    const uint32_t slot = tid == 0 ? o0 : o1 - 1u;
+    uint32_t a = 0, b = FUSED_WIN - 1;
+    while (a < b) {
+      const uint32_t mid = a + (b - a + 1) / 2;
+      if (s_off[mid] <= slot) a = mid; else b = mid - 1;
+    }
+    s_win[tid] = a;
+  }
+  __syncthreads();
   const uint32_t lo = s_win[0], hi = max(s_win[1], lo);   // local indices (Gaussian G0 + index)
-  const uint32_t nwin = hi - lo + 1;                      // <= 2049
+  const uint32_t nwin = hi - lo + 1;                      // <= 2049 (<= 4096 after a fallback)
   const uint32_t* __restrict__ woff = s_off + lo;
   // ---- 3. as emit_kernel<true>: run starts marked with the largest window index, then a max-scan ----
   for (uint32_t j = tid; j < nwin; j += EMIT_THREADS) {

@@ -343,8 +343,10 @@ __device__ __forceinline__ void backward_rect(
             r0 = min(r0, PX * ra + k); r1 = max(r1, PX * rb + k);
           }
         }
-        // no active pixel at all: an empty box (every splat misses it)
         rx0 = (float)(x0 + c0); rx1 = (float)(x0 + c1); ry0 = (float)(y0 + r0); ry1 = (float)(y0 + r1);
+        // no active pixel at all (cannot happen while the walk starts at the deepest contributor, kept for the
+        // day it does not): the inverted box above does not make splat_misses_rect reject -- a far-away one does
+        if (r1 < 0) { rx0 = 3e38f; rx1 = -3e38f; ry0 = 3e38f; ry1 = -3e38f; }
       }
       const bool keep = ((uint32_t)lane < ncur) &&
                         !splat_misses_rect(la.x, la.y, lb.x, lb.y, lb.z, la.w, rx0, rx1, ry0, ry1);

@@ -149,6 +149,10 @@ GRPG_API int grpg_forward_flags(grpg_alloc_fn geometry_alloc, void* geometry_use
  * returns for that SUBSET of the Gaussians in the same order (a layer's transmittance chain sees alpha = 0
  * for the other class: exact no-ops).  No semantic planes (S = 0), P < 2^27 (the class travels in bit 27 of
  * the point-list entries), the blobs cannot be handed to grpg_backward.
+ * An EMPTY layer -- no Gaussian of that class, or none at all (P == 0) -- has colour layer_background and alpha 0
+ * everywhere: what the reference's render_kernel returns for a model set without Gaussians
+ * (lib/models/street_gaussian_renderer.py:131-144; it does not call the op then).  The composition's planes of a
+ * P == 0 call are zeros, like grpg_forward's.
  */
 GRPG_API int grpg_forward_layers(grpg_alloc_fn geometry_alloc, void* geometry_user,
                  grpg_alloc_fn binning_alloc, void* binning_user,
@@ -476,6 +480,11 @@ GRPG_API int grpg_set_binning_algorithm(int alg);
  * remembers which of the last 64 geometry blobs were carved with that room and refuses a blob it knows
  * to lack it (GRPG_ERR_BAD_BUFFER) instead of writing out of bounds; debug = 1 additionally reads the
  * blobs' headers (has_grad_rec, pc_timeout, P / R / W / H).
+ * Asynchrony: with the geometry blob of a training forward THIS PROCESS made (the training loop) the call only
+ * enqueues work.  For a blob whose address is not on record (copied, reloaded) its header is read first: one
+ * device->host copy and a hipStreamSynchronize on hip_stream -- such a call is not asynchronous, and under stream
+ * capture it is refused (GRPG_ERR_BAD_BUFFER) instead of breaking the capture.  The record is advisory: a blob
+ * the caller copies into an address a training forward of the same P carved earlier is vouched for unseen.
  * A forward a backward may follow (S == 0) also asks its binning callback for room behind the
  * point list for blend checkpoints of the tile lists with >= 4096 entries (6 KB per 1365 instances of
  * capacity): the backward starts independent walks from them instead of walking

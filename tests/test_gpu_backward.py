@@ -522,7 +522,13 @@ def test_fit_psnr_parity_10k(dev):
     # deterministic one, whose distance has that spread however equal the two implementations are (measured
     # on the MI355X in two runs: sigma 0.0004 / 0.009-0.014 / 0.013-0.022 dB at steps 50 / 100 / 200, |mean
     # difference| 0.001 / 0.022 / 0.031-0.039 dB -- without the term the last bar would fail one run in seven)
+    # The allowance is CAPPED at the spread measured for this op (the largest of the round-5 runs): a noisier or
+    # less deterministic implementation does not earn itself a looser bar, and with N_HIP = 5 a sample
+    # sigma is itself uncertain by a third.  The per-run values stay in the statistics, so a growing spread shows.
+    SIGMA_CAP = {50: 0.001, 100: 0.014, 200: 0.022}
     sigma = {k: float(np.std([h[k] for h in hips], ddof=1)) for k in marks}
     PARITY_STATS[-1]["psnr_hip_sigma"] = {str(k): v for k, v in sigma.items()}
+    PARITY_STATS[-1]["psnr_sigma_cap"] = {str(k): v for k, v in SIGMA_CAP.items()}
     for mark, bar in ((50, 0.01), (100, 0.05), (200, 0.05)):
-        assert abs(hip[mark] - cpu[mark]) <= bar + 2.0 * sigma[mark], (mark, hip, cpu, spread, sigma)
+        allowance = 2.0 * min(sigma[mark], SIGMA_CAP[mark])
+        assert abs(hip[mark] - cpu[mark]) <= bar + allowance, (mark, hip, cpu, spread, sigma)

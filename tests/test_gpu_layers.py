@@ -114,6 +114,18 @@ def test_degenerate_layers(dev):
     one = hz.render_all_fused(d, cam, every)
     assert float((one["rgb_background"] - 1.0).abs().max()) == 0.0
     _same_bits("rgb_object", one["rgb_object"], hz.render_kernel(d, cam, white_background=True)["rgb"])
+    # P == 0: both layers empty -- the same contract as an empty class with P > 0: colour = the layer
+    # background, alpha 0; the composition's planes are the op's zeros (rasterize_points.cu:85-86)
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as _S, GaussianRasterizer as _R
+    r0 = _R(_S(**hz.settings_kwargs(cam, 1)))
+    z = lambda *sh: torch.zeros(*sh, device=dev)   # noqa: E731
+    lbg = torch.tensor([0.25, 0.5, 0.75], device=dev)
+    e = r0.forward_layers(z(0, 3), z(0, 1), torch.zeros(0, dtype=torch.bool, device=dev), shs=z(0, 4, 3), scales=z(0, 3),
+                          rotations=z(0, 4), layer_bg=lbg)
+    for k in ("color_background", "color_object"):
+        assert torch.equal(e[k], lbg[:, None, None].expand(3, 96, 160)), k
+    for k in ("alpha_background", "alpha_object", "color", "alpha", "depth"):
+        assert float(e[k].abs().max()) == 0.0, k
     # argument checks of the additive entry point
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     rast = GaussianRasterizer(GaussianRasterizationSettings(**hz.settings_kwargs(cam, 1)))
