@@ -167,6 +167,10 @@ EXPERIMENT_VARIANTS = {
     "lay_noobj_only0": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=1", "-DGRPG_RENDER_ONLY_CLASS0"]},
     "lay_nobg": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=2"]},
     "lay_none": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=3"]},
+    # round 6: per-workgroup life of the point-list fill (tools/fill_trace.py)
+    # round 6: the fill with every lane reading record 0 / 1 instead of its own (what does the gather cost?)
+    "fill_nogather": {"hier_binning.hip": ["-DGRPG_FILL_ABLATE=2"]},
+    "filltrace": {"hier_binning.hip": ["-DGRPG_FILL_TRACE"]},
     "layers3w": {"render_fwd.hip": ["-DGRPG_LAYERS_MIN_WAVES=3"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},

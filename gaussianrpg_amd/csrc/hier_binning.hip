@@ -30,6 +30,10 @@
 #include "blend_math.h"
 #include "common.h"
 
+#ifndef GRPG_FILL_ABLATE   // experiment builds only
+#define GRPG_FILL_ABLATE 0
+#endif
+
 namespace grpg {
 
 constexpr int HB_SEG = 1024;        // coarse entries per segment
@@ -347,6 +351,11 @@ hb_tile_scan_kernel(const uint32_t T, const uint32_t* __restrict__ tile_tot,
 // Workgroups are persistent and walk the segments with a stride: the descriptor and the (key, id)
 // pairs of the NEXT segment are fetched while the current one is processed, so a segment exposes
 // one memory round trip (the record gather) instead of three.
+#ifdef GRPG_FILL_TRACE   // experiment build (tools/fill_trace.py): per workgroup start / end, segments, instances
+__device__ unsigned long long g_fill_trace[1024][4];
+__device__ unsigned long long g_fill_phase[1024][8];   // wave 0's accumulated ticks per phase
+#endif
+
 __global__ void __launch_bounds__(HB_FILL_THREADS)
 hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nseg_total,
                const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cval, const RecView rec,
@@ -368,6 +377,14 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
   const int col = (int)wave;
   uint16_t* coll = s_col[wave];
   uint32_t sid = blockIdx.x;
+#ifdef GRPG_FILL_TRACE
+  const unsigned long long tr_t0 = wall_clock64();
+  unsigned long long tr_segs = 0, tr_inst = 0;
+  if (tid == 0 && blockIdx.x < 1024) {
+    for (int k = 0; k < 8; k++) g_fill_phase[blockIdx.x][k] = 0ull;
+    g_fill_trace[blockIdx.x][0] = tr_t0; g_fill_trace[blockIdx.x][1] = tr_t0; g_fill_trace[blockIdx.x][2] = 0; g_fill_trace[blockIdx.x][3] = 0;
+  }
+#endif
   if (sid >= nseg) return;
   SegDesc d = seg[sid];
   uint32_t gid[ITEMS], key[ITEMS];
@@ -382,9 +399,20 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
     const uint32_t n = d.end - d.begin;
     const int sy = (int)(d.st / (uint32_t)sgx), sx = (int)(d.st - (uint32_t)sy * (uint32_t)sgx);
     const int tx = sx * STILE + col;
+#ifdef GRPG_FILL_TRACE
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tp = wall_clock64();
+#define FILL_PH(K) do { const unsigned long long t_ = wall_clock64(); ph[K] += t_ - tp; tp = t_; } while (0)
+#else
+#define FILL_PH(K) do {} while (0)
+#endif
     float4 g0[ITEMS], g1[ITEMS];
 #pragma unroll
+#if GRPG_FILL_ABLATE & 2   // experiment build (masks of the wrong splats: images wrong, nothing out of bounds): no gather
+    for (int i = 0; i < ITEMS; i++) { g0[i] = rec.geo0(gid[i] & 1u); g1[i] = rec.geo1(gid[i] & 1u); }
+#else
     for (int i = 0; i < ITEMS; i++) { g0[i] = rec.geo0(gid[i]); g1[i] = rec.geo1(gid[i]); }
+#endif
     // running output position of each of the column's tiles (independent of the gather)
     uint32_t out[STILE];
     {
@@ -400,6 +428,7 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
     const bool more = sid_next < nseg;
     SegDesc dn = d;
     if (more) dn = seg[sid_next];
+    FILL_PH(0);   // records, output positions, next descriptor: issued AND (the adds need them) arrived
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t e = i * HB_FILL_THREADS + tid;
@@ -413,7 +442,9 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
       s_dc[e] = make_float2(q.det, q.ct);
       s_xt[e] = q.xtop;
     }
+    FILL_PH(2);   // quarter_pre + staging
     __syncthreads();
+    FILL_PH(3);   // barrier
     // the next segment's pairs travel while this one is processed
     if (more) {
 #pragma unroll
@@ -435,6 +466,7 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
         ncol += (uint32_t)__popcll(m);
       }
       __builtin_amdgcn_wave_barrier();
+      FILL_PH(4);   // column compaction
       const float tile_x = (float)(tx * TILE), super_y = (float)(sy * STILE * TILE);
       for (uint32_t i0 = 0; i0 < ncol; i0 += WAVE) {
         const uint32_t i = i0 + lane;
@@ -463,9 +495,21 @@ hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nse
             if (pos < R_cap) point_list[pos] = g | (bits << SUBTILE_SHIFT);
           }
           out[r] += (uint32_t)__popcll(m);
+#ifdef GRPG_FILL_TRACE
+          if (wave == 0) tr_inst += (unsigned long long)__popcll(m);
+#endif
         }
       }
     }
+    FILL_PH(5);   // column walk: extents, masks, stores
+#ifdef GRPG_FILL_TRACE
+    tr_segs++;
+    if (tid == 0 && blockIdx.x < 1024) {
+      for (int k = 0; k < 8; k++) g_fill_phase[blockIdx.x][k] += ph[k];
+      g_fill_trace[blockIdx.x][1] = wall_clock64(); g_fill_trace[blockIdx.x][2] = tr_segs; g_fill_trace[blockIdx.x][3] += tr_inst;
+      tr_inst = 0;
+    }
+#endif
     if (!more) break;
     sid = sid_next;
     d = dn;
@@ -509,5 +553,16 @@ void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_
 }
 
 uint32_t hier_max_segments(uint32_t Rcap, uint32_t NS) { return Rcap / HB_SEG + NS + 1; }
+
+#ifdef GRPG_FILL_TRACE
+}  // namespace grpg
+extern "C" __attribute__((visibility("default"))) int grpg_debug_fill_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grpg::g_fill_trace), sizeof(grpg::g_fill_trace));
+}
+extern "C" __attribute__((visibility("default"))) int grpg_debug_fill_phase(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grpg::g_fill_phase), sizeof(grpg::g_fill_phase));
+}
+namespace grpg {
+#endif
 
 }  // namespace grpg
