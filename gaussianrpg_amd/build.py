@@ -155,16 +155,10 @@ EXPERIMENT_VARIANTS = {
                 "hier_binning.hip": ["-DGRPG_RENDER_PC_MIN=16384"]},
     # round 6: the layered kernel allocated for 3 waves per SIMD (168 VGPRs, no scratch) instead of 4
     # round 6 (wrong images): the layered walk without the object layer's state / without the background layer's
-    # round 6: a producer + three consumers for object tiles from 4096 / 8192 entries instead of 2048
-    "lpc4096": {"render_fwd.hip": ["-DGRPG_LAYERS_PC_MIN=4096"], "api.hip": ["-DGRPG_LAYERS_PC_MIN=4096"]},
+    # round 6: one walk per layer for object tiles from 2048 / 8192 entries instead of 4096
+    "lpc2048": {"render_fwd.hip": ["-DGRPG_LAYERS_PC_MIN=2048"], "api.hip": ["-DGRPG_LAYERS_PC_MIN=2048"]},
     "lpc8192": {"render_fwd.hip": ["-DGRPG_LAYERS_PC_MIN=8192"], "api.hip": ["-DGRPG_LAYERS_PC_MIN=8192"]},
-    "lpc1024": {"render_fwd.hip": ["-DGRPG_LAYERS_PC_MIN=1024"], "api.hip": ["-DGRPG_LAYERS_PC_MIN=1024"]},
     "lay_noobj": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=1"]},
-    "lay_onlyA_only0": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=5", "-DGRPG_RENDER_ONLY_CLASS0"]},
-    "lay_onlyB_only0": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=9", "-DGRPG_RENDER_ONLY_CLASS0"]},
-    "lay_plainpairsB_only0": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=48", "-DGRPG_RENDER_ONLY_CLASS0"]},
-    "lay_plainpairs_only0": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=16", "-DGRPG_RENDER_ONLY_CLASS0"]},
-    "lay_noobj_only0": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=1", "-DGRPG_RENDER_ONLY_CLASS0"]},
     "lay_nobg": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=2"]},
     "lay_none": {"render_fwd.hip": ["-DGRPG_LAYERS_ABLATE=3"]},
     # round 6: per-workgroup life of the point-list fill (tools/fill_trace.py)

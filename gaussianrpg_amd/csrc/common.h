@@ -333,8 +333,8 @@ struct TileObjBits {
   int gx;
   __host__ __device__ bool tile(const uint32_t t) const { return flags[t] != 0; }
 };
-#ifndef GRPG_LAYERS_PC_MIN      // experiment builds: from how many entries a tile WITH object entries gets a producer
-#define GRPG_LAYERS_PC_MIN 8192 // wave and one consumer wave per layer (render_fwd.hip pc3_*)
+#ifndef GRPG_LAYERS_PC_MIN      // experiment builds: from how many entries a tile WITH object entries gets one walk
+#define GRPG_LAYERS_PC_MIN 4096 // per layer (render_fwd.hip LayerRoleOut) instead of three states on one wave
 #endif
 constexpr uint32_t LAYERS_PC_MIN = GRPG_LAYERS_PC_MIN;
 struct TileClasses { uint32_t c0_min, c1_min, heavy_min; TileObjBits obj; uint32_t c0_obj_min; };
@@ -353,7 +353,7 @@ __host__ __device__ inline int tile_class(const uint32_t len, const TileClasses 
 // class of tile t (list length len); the object flags are device memory
 __host__ __device__ inline int tile_class_of(const uint32_t t, const uint32_t len, const TileClasses tc) {
   if (tc.obj.flags == nullptr || len == 0u || !tc.obj.tile(t)) return tile_class(len, tc);
-  // a tile WITH object entries (layered frame): class 0 = one producer + three consumer waves per quarter, the
+  // a tile WITH object entries (layered frame): class 0 = one walk per layer (wave pairs or quarter waves), the
   // rest on three-state quarter waves (never the four-pixel light path)
   return len >= tc.c0_obj_min ? 0 : (len >= tc.c1_min ? 1 : 2);
 }

@@ -859,6 +859,13 @@ __device__ __forceinline__ void sem_write(const SemAcc<NSEM>& sa, const int S, f
     if (c < S && inside) out_semantic[(size_t)c * HW + pix] = (c < 8 ? t_lo : t_hi)[(c & 7) * WAVE + lane];
 }
 
+// Which list entries a walk takes -- everything in an ordinary frame; in a layered frame (further down) a layer's
+// own walk of a tile WITH object entries takes the entries of its class: (entry & wmask) == wval, and strips the
+// class bit before it indexes the records (id_and).  The defaults fold away at compile time.
+struct ClassFilter {
+  uint32_t wmask = 0u, wval = 0u, id_and = 0xFFFFFFFFu;
+};
+
 template <bool TRACE, bool AUX = true, int NSEM = 0, class Out = PlainOut>
 __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* __restrict__ qid,
                                             uint32_t* __restrict__ qpos, const int lane,
@@ -869,7 +876,8 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
                                             const RecView rec, const Out& out, WaveTrace* tr,
                                             CkptWriter ckw, const SemSrc sem = SemSrc{nullptr, 0, nullptr},
                                             float* __restrict__ out_semantic = nullptr,
-                                            float* __restrict__ semrows = nullptr /* LDS: WAVE x SEM_ROW */) {
+                                            float* __restrict__ semrows = nullptr /* LDS: WAVE x SEM_ROW */,
+                                            const ClassFilter cf = ClassFilter{}) {
   SemAcc<NSEM> sa;
   sa.clear();
   const SemSrc semb = {sem.semantics, sem.S, semrows};
@@ -921,7 +929,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
 #pragma unroll
       for (int q = 0; q < FILL_Q; q++) {
         const uint32_t i = in_pos + q * WAVE + lane;
-        const bool keep = (i < r_end) && (v[q] & bit);
+        const bool keep = (i < r_end) && (v[q] & bit) && ((v[q] & cf.wmask) == cf.wval);
         const uint64_t m = __ballot(keep);
         if (keep) {
           const uint32_t slot = (head + count + (uint32_t)__popcll(m & lt)) & (QCAP - 1);
@@ -943,7 +951,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
     uint32_t pos_n = 0, id_n = 0;
     if ((uint32_t)lane < nn) {
       const uint32_t slot = (head + lane) & (QCAP - 1);
-      id_n = qid[slot];
+      id_n = qid[slot] & cf.id_and;
       pos_n = qpos[slot];
       rec.load(id_n, a_n, b_n, c_n);
     }
@@ -1103,7 +1111,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
                                             const RecView rec, const PCErr err, WaveTrace* tr = nullptr,
                                             const SemSrc sem = SemSrc{nullptr, 0, nullptr},
                                             float* __restrict__ semrows0 = nullptr /* LDS rows of buf0 / buf1 */,
-                                            float* __restrict__ semrows1 = nullptr) {
+                                            float* __restrict__ semrows1 = nullptr, const ClassFilter cf = ClassFilter{}) {
   const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
   const uint64_t lt = lanemask_lt();
   uint32_t head = 0, count = 0;
@@ -1136,11 +1144,7 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
   for (;;) {
     if (pc_load(&ctl->stop) != 0u) return;
     // ---- FILL: until two batches are queued (ring: < 128 + 256 entries <= QCAP) ----
-#if GRPG_LAYERS_ABLATE & 32   // experiment build (wrong images): the plain pairs walk the non-object entries only
-    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt, POINT_CLASS_BIT, 0u);
-#else
-    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt);
-#endif
+    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt, cf.wmask, cf.wval);
     // the ring entries written by FILL are read by OTHER lanes in POP: keep the compiler from
     // reordering the LDS accesses across this point (costs no instruction)
     __builtin_amdgcn_wave_barrier();
@@ -1150,20 +1154,14 @@ __device__ __forceinline__ void pc_producer(float4* __restrict__ buf0, float4* _
     uint32_t pos0n = 0, id0n = 0, pos1n = 0, id1n = 0;
     if ((uint32_t)lane < nn) {
       const uint32_t slot = (head + lane) & (QCAP - 1);
-      id0n = qid[slot];
+      id0n = qid[slot] & cf.id_and;
       pos0n = qpos[slot];
-#if GRPG_LAYERS_ABLATE & 16
-      id0n &= POINT_CLASS_BIT - 1u;
-#endif
       rec.load(id0n, a0n, b0n, c0n);
     }
     if ((uint32_t)lane + WAVE < nn) {
       const uint32_t slot = (head + WAVE + lane) & (QCAP - 1);
-      id1n = qid[slot];
+      id1n = qid[slot] & cf.id_and;
       pos1n = qpos[slot];
-#if GRPG_LAYERS_ABLATE & 16
-      id1n &= POINT_CLASS_BIT - 1u;
-#endif
       rec.load(id1n, a1n, b1n, c1n);
     }
     head = (head + nn) & (QCAP - 1);
@@ -1304,8 +1302,8 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
 //   * a tile WITH object entries carries three states, one pixel per lane.  Short lists: one quarter wave holds
 //     all three (blend_heavy_layers), and even there the states FORK LATE: until the first object entry survives a
 //     batch's cull the background layer equals the composition bit for bit and is not computed, the object layer
-//     is empty -- a wave whose quarter no object reaches never forks.  Long lists (>= LAYERS_PC_MIN entries): a
-//     producer wave feeds THREE consumer waves, one per layer (pc3_* below);
+//     is empty -- a wave whose quarter no object reaches never forks.  Long lists (>= LAYERS_PC_MIN entries): one
+//     walk per layer on the plain frame's paths (LayerRoleOut below);
 //   * a pixel is finished when all three states are: where no object ever saturates the walk goes on to the
 //     end of the list -- but once the composition and the background are through, FILL keeps OBJECT entries
 //     only (a dead entry costs 1/256 of a FILL step), and the cull box of the non-object entries is that of
@@ -1477,265 +1475,36 @@ __device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// Long tiles WITH object entries: ONE PRODUCER, THREE CONSUMERS (round 6).
+// Long tiles WITH object entries (>= LAYERS_PC_MIN entries): ONE WALK PER LAYER, on the plain frame's own paths.
 //
-// Three states on one consumer wave made its chain twice the plain consumer's (eval + three blend halves per
-// quad, the colour / class blocks fetched inside the quad: 0.41 ms for the class-0 tiles of a frame with ten
-// car-sized actors against 0.19 ms plain) -- and that chain is the launch.  A layer's chain depends on nothing but
-// the compacted batches, so each layer gets a consumer wave of its own: a quarter of such a tile is one workgroup,
-// wave 3 the producer (FILL / POP / cull / compaction into two LDS buffers, as pc_producer), waves 0 / 1 / 2 the
-// consumers of the composition, the background layer and the object layer.  Every consumer evaluates the quads
-// it needs itself (at the end of a launch the SIMDs are idle: recomputing alpha costs nothing that matters) and
-// blends with its class's accept masks -- the same arithmetic on the same operands as blend_quad_layers: the
-// same bits.  The object layer's consumer only touches quads that hold an object slot (a per-batch slot mask
-// from the producer), so it mostly sleeps.  Hand-over: per consumer a flag per buffer (as PCCtrl.flag), the
-// producer refills a buffer when every consumer that has not stopped has released it; every consumer keeps its
-// own live box (inverted once it stops), the producer culls non-object survivors against the union of the
-// composition's and the background's, object survivors against the composition's and the object layer's, and
-// drops a class altogether once nobody wants it.
+// A layer's chain depends on nothing but the list, so a long object tile is not walked with three states at all: the
+// composition, the background layer and the object layer each get a walk of their own that takes the entries of its
+// class (ClassFilter: all / non-objects / objects) and writes its own planes (LayerRoleOut) -- wave pairs from
+// RENDER_PC_MIN entries, four quarter waves below.  Each walk is literally the plain frame's (same functions):
+// bit-identical to the op's call on that subset by construction, and as fast as the plain frame's chain -- the
+// launch's critical path.  History (DESIGN_EXPERIMENTS.md R6.1): three states on one consumer wave made the class-0
+// chain of a ten-actor frame 0.41 ms (plain: 0.19); one producer feeding three consumer waves 0.26 ms (a consumer
+// per layer is as cheap as the plain one, but the shared producer serves the slowest and culls for the union);
+// independent walks: the background layer's own chain, 0.20 ms.  The object layer's walk scans the whole list
+// (FILL drops what is not an object: 1 / 256 of a step per entry) and blends the few object entries.
 // ------------------------------------------------------------------------------------------
-struct PC3Ctrl {
-  // per buffer ONE word, byte c = consumer c's flag: 0 free, cnt + 1 (<= 65) | PC3_SAFE = cnt survivors wait for it,
-  // PC3_DONE end of the list.  The producer publishes a batch with one store and sees all three releases with one
-  // load; a consumer polls and clears its own byte.
-  uint32_t flag[2];
-  uint32_t stop;            // byte c = 0xFF once consumer c has nothing left to blend
-  uint32_t pad;
-  uint32_t objmask[2][2];   // per buffer: which compacted slots hold an object-class splat (low / high word)
-  float box[3][4];
+template <int ROLE, class LOut>
+struct LayerRoleOut {   // ROLE 0 composition (epilogue included), 1 background layer, 2 object layer
+  const LOut& o;
+  template <bool AUX>
+  __device__ __forceinline__ void pixel(const int px, const int py, const float T, const v2f CrCg, const v2f CbD,
+                                        const uint32_t) const {
+    if (ROLE == 0) o.pixel_a(px, py, T, CrCg, CbD);
+    else if (ROLE == 1) o.pixel_b(px, py, T, CrCg, CbD);
+    else o.pixel_o(px, py, T, CrCg, CbD);
+  }
 };
-constexpr uint32_t PC3_SAFE = 0x80u, PC3_DONE = 0xFFu;
-__device__ __forceinline__ uint32_t pc_load_u8(const uint8_t* p) {
-  return (uint32_t)__builtin_amdgcn_readfirstlane(
-      (int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-__device__ __forceinline__ void pc_store_u8(uint8_t* p, const uint8_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-template <class Cond, class Stop>
-__device__ __forceinline__ bool pc_wait_until(const PCErr err, const int lane, Cond ready, Stop stopped) {
-  uint32_t spins = 0;
-  while (!ready()) {
-    if (stopped()) return false;
-    if (++spins > PC_SPIN_LIMIT) { pc_fail(err, lane); return false; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return true;
-}
-
-__device__ __forceinline__ void pc3_producer(float4* __restrict__ buf0, float4* __restrict__ buf1,
-                                             uint32_t* __restrict__ qid, uint32_t* __restrict__ qpos,
-                                             PC3Ctrl* __restrict__ ctl, const int lane, const int quarter,
-                                             const uint32_t r_begin, const uint32_t r_end,
-                                             const uint32_t* __restrict__ point_list, const RecView rec,
-                                             const PCErr err) {
-  const uint32_t bit = 1u << (SUBTILE_SHIFT + quarter);
-  const uint64_t lt = lanemask_lt();
-  uint32_t head = 0, count = 0;
-  ListStream<8> ls;
-  ls.open(point_list, r_begin, r_end, lane);
-  float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, c0 = a0, a1 = a0, b1 = a0, c1 = a0;
-  uint32_t pos0 = 0, id0 = 0, pos1 = 0, id1 = 0, ncur = 0;
-  int cur = 0;
-  // the batch's object slots (slot order) are collected by the object lanes themselves: ds_or into the buffer's mask
-  // words, which begin_batch cleared (one wave: its LDS operations execute in order)
-  const auto begin_batch = [&]() { if (lane == 0) { ctl->objmask[cur][0] = 0u; ctl->objmask[cur][1] = 0u; } };
-  const auto put = [&](float4* __restrict__ my, const bool keep, const uint64_t mask, const int base,
-                       const float4 a, const float4 b, const float4 c, const uint32_t pos, const uint32_t idc) {
-    if (keep) {
-      const int slot = base + (int)__popcll(mask & lt);
-      store_pair_half(my, slot, a.x, a.y, splat_q(b.x, b.y, b.z), a.w, make_float4(b.w, c.x, c.y, a.z), pos);
-      if (idc & LAYER_BIT) atomicOr(&ctl->objmask[cur][slot >> 5], 1u << (slot & 31));
-    }
-  };
-  const auto publish = [&](float4* __restrict__ my, const int cnt, const bool safe) {
-    if (lane < ((4 - (cnt & 3)) & 3)) {
-      const SplatQ zq = {0.f, 0.f, 0.f};
-      store_pair_half(my, cnt + lane, 0.f, 0.f, zq, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u);
-    }
-    const uint32_t f = ((uint32_t)cnt + 1u) | (safe ? PC3_SAFE : 0u);
-    pc_store(&ctl->flag[cur], f * 0x010101u);
-    cur ^= 1;
-  };
-  const auto all_stopped = [&]() { return (pc_load(&ctl->stop) & 0xFFFFFFu) == 0xFFFFFFu; };
-  // buffer `cur` is free once every consumer still running has handed it back
-  const auto buffer_free = [&]() { return (pc_load(&ctl->flag[cur]) & ~pc_load(&ctl->stop) & 0xFFFFFFu) == 0u; };
-  for (;;) {
-    const uint32_t stops = pc_load(&ctl->stop);
-    const bool sA = (stops & 0xFFu) != 0u, sB = (stops & 0xFF00u) != 0u, sO = (stops & 0xFF0000u) != 0u;
-    if (sA && sB && sO) return;
-    // non-object entries feed the composition and the background layer, object entries the composition and
-    // the object layer (a stale "still running" only passes on entries nobody takes any more)
-    const bool need_n = !sA || !sB, need_o = !sA || !sO;
-    const uint32_t wmask = (need_n && need_o) ? 0u : LAYER_BIT, wval = need_n ? 0u : LAYER_BIT;
-    while (count < 2u * WAVE && !ls.exhausted()) ls.fill(qid, qpos, bit, head, count, lane, lt, wmask, wval);
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nn = min(count, 2u * WAVE);
-    float4 a0n = make_float4(0, 0, 0, 0), b0n = a0n, c0n = a0n, a1n = a0n, b1n = a0n, c1n = a0n;
-    uint32_t pos0n = 0, id0n = 0, pos1n = 0, id1n = 0;
-    if ((uint32_t)lane < nn) {
-      const uint32_t slot = (head + lane) & (QCAP - 1);
-      id0n = qid[slot];
-      pos0n = qpos[slot];
-      rec.load(id0n & LAYER_ID_MASK, a0n, b0n, c0n);
-    }
-    if ((uint32_t)lane + WAVE < nn) {
-      const uint32_t slot = (head + WAVE + lane) & (QCAP - 1);
-      id1n = qid[slot];
-      pos1n = qpos[slot];
-      rec.load(id1n & LAYER_ID_MASK, a1n, b1n, c1n);
-    }
-    head = (head + nn) & (QCAP - 1);
-    count -= nn;
-    if (ncur > 0) {
-      // cull boxes: unions of the consumers' live boxes (a stopped consumer's box is inverted: contributes nothing)
-      const float nx0 = fminf(ctl->box[0][0], ctl->box[1][0]), nx1 = fmaxf(ctl->box[0][1], ctl->box[1][1]);
-      const float ny0 = fminf(ctl->box[0][2], ctl->box[1][2]), ny1 = fmaxf(ctl->box[0][3], ctl->box[1][3]);
-      const float ox0 = fminf(ctl->box[0][0], ctl->box[2][0]), ox1 = fmaxf(ctl->box[0][1], ctl->box[2][1]);
-      const float oy0 = fminf(ctl->box[0][2], ctl->box[2][2]), oy1 = fmaxf(ctl->box[0][3], ctl->box[2][3]);
-      const bool o0 = (id0 & LAYER_BIT) != 0u, o1 = (id1 & LAYER_BIT) != 0u;
-      const bool k0 = ((uint32_t)lane < ncur) && (o0 ? need_o : need_n) &&
-                      !splat_misses_rect(a0.x, a0.y, b0.x, b0.y, b0.z, a0.w, o0 ? ox0 : nx0, o0 ? ox1 : nx1,
-                                         o0 ? oy0 : ny0, o0 ? oy1 : ny1);
-      const bool k1 = ((uint32_t)lane + WAVE < ncur) && (o1 ? need_o : need_n) &&
-                      !splat_misses_rect(a1.x, a1.y, b1.x, b1.y, b1.z, a1.w, o1 ? ox0 : nx0, o1 ? ox1 : nx1,
-                                         o1 ? oy0 : ny0, o1 ? oy1 : ny1);
-      const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
-      const int n0 = (int)__popcll(m0), n1 = (int)__popcll(m1);
-      const bool safe0 = __ballot(k0 && !splat_power_never_positive(splat_q(b0.x, b0.y, b0.z))) == 0ull;
-      const bool safe1 = __ballot(k1 && !splat_power_never_positive(splat_q(b1.x, b1.y, b1.z))) == 0ull;
-      if (n0 + n1 > 0) {
-        if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;
-        float4* my = cur ? buf1 : buf0;
-        begin_batch();
-        if (n0 + n1 <= WAVE) {
-          put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
-          put(my, k1, m1, n0, a1, b1, c1, pos1, id1);
-          publish(my, n0 + n1, safe0 && safe1);
-        } else {
-          put(my, k0, m0, 0, a0, b0, c0, pos0, id0);
-          publish(my, n0, safe0);
-          if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;
-          my = cur ? buf1 : buf0;
-          begin_batch();
-          put(my, k1, m1, 0, a1, b1, c1, pos1, id1);
-          publish(my, n1, safe1);
-        }
-      }
-    }
-    a0 = a0n; b0 = b0n; c0 = c0n; pos0 = pos0n; id0 = id0n;
-    a1 = a1n; b1 = b1n; c1 = c1n; pos1 = pos1n; id1 = id1n;
-    ncur = nn;
-    if (ncur == 0 && ls.exhausted()) break;
-  }
-  if (!pc_wait_until(err, lane, buffer_free, all_stopped)) return;   // end-of-list marker
-  pc_store(&ctl->flag[cur], PC3_DONE * 0x010101u);
-}
-
-// one handed-over batch for the consumer of layer ROLE (0 composition, 1 background layer, 2 object layer); om = the
-// batch's object slots.  ROLE 0 / 1: the plain consumer's pipelined loop (pc_blend_batch), the background layer
-// with the object slots' accept masks cleared; ROLE 2: only the quads that hold an object slot.
-template <int ROLE, bool SAFE>
-__device__ __forceinline__ void pc3_blend_batch(WavePix<1>& st, const float4* __restrict__ my, const int cnt,
-                                                const uint64_t om, const float pxf, const float pyf, const int lane) {
-  const SemSrc nosem = {nullptr, 0, nullptr};
-  SemAcc<0>* nosa = nullptr;
-  if (ROLE == 0) {
-    pc_blend_batch<false, 0, SAFE>(st, my, cnt, pxf, pyf, nosa, nosem, lane);
-  } else if (ROLE == 1) {
-    QuadGeom g_n;
-    g_n.load(my);
-    for (int j0 = 0; j0 < cnt; j0 += 4) {
-      const float4* blk = my + (j0 >> 1) * PAIR_F4;
-      const QuadGeom g = g_n;
-      QuadColsReg<false> col;
-      col.load(blk);
-      g_n.load(my + (min(j0 + 4, cnt - 1) >> 1) * PAIR_F4);
-      float alpha[4];
-      uint64_t ok[4];
-      eval_quad<SAFE>(g, pxf, pyf, alpha, ok);
-      const uint32_t cm = (uint32_t)(om >> j0) & 0xFu;   // (wave-uniform)
-#pragma unroll
-      for (int i = 0; i < 4; i++) ok[i] = ((cm >> i) & 1u) ? 0ull : ok[i];
-      blend_quad_tail<false, 0>(st, col, alpha, ok, nosa, nosem, j0, lane);
-    }
-  } else {
-    for (uint64_t m = om; m != 0ull;) {
-      const int j0 = (int)__builtin_ctzll(m) & ~3;
-      const uint32_t cm = (uint32_t)(m >> j0) & 0xFu;
-      m &= ~(0xFull << j0);
-      const float4* blk = my + (j0 >> 1) * PAIR_F4;
-      QuadGeom g;
-      g.load(blk);
-      QuadColsReg<false> col;
-      col.load(blk);
-      float alpha[4];
-      uint64_t ok[4];
-      eval_quad<SAFE>(g, pxf, pyf, alpha, ok);
-#pragma unroll
-      for (int i = 0; i < 4; i++) ok[i] = ((cm >> i) & 1u) ? ok[i] : 0ull;
-      blend_quad_tail<false, 0>(st, col, alpha, ok, nosa, nosem, j0, lane);
-    }
-  }
-}
-
-template <int ROLE, class Out>
-__device__ __forceinline__ void pc3_consumer(const float4* __restrict__ buf0, const float4* __restrict__ buf1,
-                                             PC3Ctrl* __restrict__ ctl, const int lane, const int x0, const int y0,
-                                             const int W, const int H, const Out& out, const PCErr err) {
-  const int px = x0 + (lane & 15), py = y0 + (lane >> 4);
-  const float pxf = (float)px, pyf = (float)py;
-  WavePix<1> st;
-  fresh_state(st, lanes(!(px < W && py < H)));
-  uint64_t prev_alive = ~0ull;
-  int cur = 0;
-  uint8_t* const my_stop = reinterpret_cast<uint8_t*>(&ctl->stop) + ROLE;
-  const auto quit = [&]() {   // nothing left to blend here: take the box out of the producer's unions, then say so
-    if (lane == 0) { ctl->box[ROLE][0] = 3e38f; ctl->box[ROLE][1] = -3e38f; ctl->box[ROLE][2] = 3e38f; ctl->box[ROLE][3] = -3e38f; }
-    pc_store_u8(my_stop, (uint8_t)0xFF);
-  };
-#if GRPG_LAYERS_ABLATE & 1   // experiment build (wrong images): the object layer's consumer gives up at once
-  if (ROLE == 2) st.done[0] = ~0ull;
-#endif
-#if GRPG_LAYERS_ABLATE & 4   // ... and the background layer's
-  if (ROLE == 1) st.done[0] = ~0ull;
-#endif
-#if GRPG_LAYERS_ABLATE & 8   // ... or the composition's
-  if (ROLE == 0) st.done[0] = ~0ull;
-#endif
-  if (~st.done[0] == 0ull) quit();   // quarter outside the image
-  else for (;;) {
-    uint32_t f = 0;
-    uint8_t* const my_flag = reinterpret_cast<uint8_t*>(&ctl->flag[cur]) + ROLE;
-    if (!pc_wait_until(err, lane, [&]() { f = pc_load_u8(my_flag); return f != 0u; }, []() { return false; })) break;
-    if (f == PC3_DONE) break;
-    const int cnt = (int)((f & (PC3_SAFE - 1u)) - 1u);
-    const float4* my = cur ? buf1 : buf0;
-    uint64_t om = 0ull;
-    if (ROLE != 0)
-      om = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->objmask[cur][0]) |
-           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->objmask[cur][1]) << 32);
-    if (f & PC3_SAFE) pc3_blend_batch<ROLE, true>(st, my, cnt, om, pxf, pyf, lane);
-    else pc3_blend_batch<ROLE, false>(st, my, cnt, om, pxf, pyf, lane);
-    pc_store_u8(my_flag, (uint8_t)0);   // hand the buffer back
-    cur ^= 1;
-    const uint64_t alive = ~st.done[0];
-    if (alive == 0ull) { quit(); break; }
-    if (alive != prev_alive) {
-      prev_alive = alive;
-      const MaskBox b = mask_box(alive);
-      if (lane == 0) {
-        ctl->box[ROLE][0] = (float)(x0 + b.c0); ctl->box[ROLE][1] = (float)(x0 + b.c1);
-        ctl->box[ROLE][2] = (float)(y0 + b.r0); ctl->box[ROLE][3] = (float)(y0 + b.r1);
-      }
-    }
-  }
-  if (px < W && py < H) {
-    if (ROLE == 0) out.pixel_a(px, py, st.T[0], st.CrCg[0], st.CbD[0]);
-    else if (ROLE == 1) out.pixel_b(px, py, st.T[0], st.CrCg[0], st.CbD[0]);
-    else out.pixel_o(px, py, st.T[0], st.CrCg[0], st.CbD[0]);
-  }
+__device__ __forceinline__ ClassFilter layer_filter(const int role) {
+  ClassFilter cf;
+  cf.wmask = role == 0 ? 0u : LAYER_BIT;
+  cf.wval = role == 2 ? LAYER_BIT : 0u;
+  cf.id_and = LAYER_ID_MASK;
+  return cf;
 }
 
 // waves per SIMD the register allocator must fit.  4 (128 VGPRs, no spills in the 4-pixel light path,
@@ -1802,50 +1571,48 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   // Class 0 holds the few longest tiles (>= RENDER_PC_MIN entries); each is rendered by two
   // workgroups (half tiles) with a producer and a consumer wave per quarter.  The first pc_slots
   // workgroups are reserved for them (upper bound of 2 n0 computed on the host from num_rendered).
+  // A layered frame puts SIX workgroups per class-0 tile at the front of the grid -- as many as the device finds
+  // (6 n0; the surplus of the host's upper bound idles at the END of the grid, not in front of the other classes):
+  //   tile without object entries: two half-tile wave pairs (workgroups 0, 1), as in a plain frame;
+  //   with object entries, >= RENDER_PC_MIN: per layer two half-tile wave pairs (workgroup = 2 layer + half);
+  //   with object entries, shorter: per layer four quarter waves (workgroups 0 .. 2).
+  const uint32_t pc_n = LAYERS ? min(6u * n0, pc_slots) : pc_slots;
 #ifdef GRPG_RENDER_ONLY_CLASS0   // experiment build: the class-0 tiles alone (their chain, nothing beside it)
-  if (blockIdx.x >= pc_slots) return;
+  if (blockIdx.x >= pc_n) return;
 #endif
 #ifdef GRPG_RENDER_NO_CLASS0     // experiment build: everything BUT the class-0 tiles (the throughput part)
-  if (blockIdx.x < pc_slots) return;
+  if (blockIdx.x < pc_n) return;
 #endif
-  if (blockIdx.x < pc_slots) {
-    // a layered frame reserves FOUR workgroups per class-0 tile: one per quarter where the tile holds object
-    // entries (producer + three consumers, pc3_* above), the first two as half tiles otherwise
-    const uint32_t pc_ti = LAYERS ? blockIdx.x >> 2 : blockIdx.x >> 1;
-    const uint32_t pc_sub = LAYERS ? blockIdx.x & 3u : blockIdx.x & 1u;
+  if (blockIdx.x < pc_n) {
+    const uint32_t pc_ti = LAYERS ? blockIdx.x / 6u : blockIdx.x >> 1;
+    uint32_t pc_sub = LAYERS ? blockIdx.x - 6u * pc_ti : blockIdx.x & 1u;
     if (pc_ti >= n0) return;
     const uint32_t tile = lists[pc_ti];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
     const uint2 range = ranges[tile];
     const uint32_t rb = __builtin_amdgcn_readfirstlane(range.x);
     const uint32_t re = __builtin_amdgcn_readfirstlane(range.y);
+    int role = -1;   // -1: one state for all planes (no object entry in the list)
     if constexpr (LAYERS) {
-#if GRPG_LAYERS_ABLATE & 16   // experiment build (wrong images): long object tiles on the plain frame's wave pairs
-      if (false) {
-#else
       if (ob.tile(tile)) {   // (workgroup-uniform)
-#endif
-        __shared__ PC3Ctrl s_ctl3;
-        const int q3 = (int)pc_sub, x03 = tx * TILE, y03 = ty * TILE + q3 * 4;
-        if (threadIdx.x == 0) {
-          s_ctl3.flag[0] = 0u; s_ctl3.flag[1] = 0u; s_ctl3.stop = 0u; s_ctl3.pad = 0u;
-          for (int c = 0; c < 3; c++) {
-            s_ctl3.box[c][0] = (float)x03; s_ctl3.box[c][1] = (float)(x03 + 15);
-            s_ctl3.box[c][2] = (float)y03; s_ctl3.box[c][3] = (float)(y03 + 3);
-          }
+        if (re - rb < RENDER_PC_MIN) {   // three workgroups, one per layer: four quarter waves each
+          if (pc_sub >= 3u) return;
+          const ClassFilter cf = layer_filter((int)pc_sub);
+          const CkptWriter nock = ckpt_writer(ck, tile, wave, rb, re);
+          const SemSrc nosem = {nullptr, 0, nullptr};
+#define LAYER_HEAVY(R)                                                                                                \
+          blend_heavy<false, false, 0>(s_rec[wave], s_qid[wave], s_qpos[wave], lane, wave, rb, re, tx * TILE,         \
+                                       ty * TILE + wave * 4, W, H, point_list, rec, LayerRoleOut<R, Out>{out}, nullptr, \
+                                       nock, nosem, nullptr, nullptr, cf)
+          if (pc_sub == 0u) LAYER_HEAVY(0); else if (pc_sub == 1u) LAYER_HEAVY(1); else LAYER_HEAVY(2);
+#undef LAYER_HEAVY
+          return;
         }
-        __syncthreads();
-        if (wave == 3)
-          pc3_producer(s_rec[0], s_rec[1], s_qid[3], s_qpos[3], &s_ctl3, lane, q3, rb, re, point_list, rec, pc_err);
-        else if (wave == 0)
-          pc3_consumer<0>(s_rec[0], s_rec[1], &s_ctl3, lane, x03, y03, W, H, out, pc_err);
-        else if (wave == 1)
-          pc3_consumer<1>(s_rec[0], s_rec[1], &s_ctl3, lane, x03, y03, W, H, out, pc_err);
-        else
-          pc3_consumer<2>(s_rec[0], s_rec[1], &s_ctl3, lane, x03, y03, W, H, out, pc_err);
+        role = (int)(pc_sub >> 1);
+        pc_sub &= 1u;
+      } else if (pc_sub >= 2u) {
         return;
       }
-      if (pc_sub >= 2u) return;
     }
     const int slot = wave & 1;                                   // quarter slot inside this workgroup
     const int q = (int)pc_sub * 2 + slot;                        // quarter of the tile
@@ -1857,6 +1624,23 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     }
     __syncthreads();   // the only workgroup barrier: all 4 waves of the workgroup take this branch
     WaveTrace* const trp = TRACE ? &tr : nullptr;
+    if constexpr (LAYERS) {
+      if (role >= 0) {   // a layer's own wave pairs on a tile with object entries
+        const SemSrc nosem = {nullptr, 0, nullptr};
+        if (wave < 2) {
+          const CkptWriter nock = ckpt_writer(ck, tile, q, rb, re);
+#define LAYER_CONSUMER(R)                                                                                          \
+          pc_consumer<false, 0>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H,                     \
+                                LayerRoleOut<R, Out>{out}, nock, re - rb, pc_err)
+          if (role == 0) LAYER_CONSUMER(0); else if (role == 1) LAYER_CONSUMER(1); else LAYER_CONSUMER(2);
+#undef LAYER_CONSUMER
+        } else {
+          pc_producer<false>(s_rec[slot], s_rec[slot + 2], s_qid[wave], s_qpos[wave], &s_ctl[slot], lane, q, rb, re,
+                             point_list, rec, pc_err, nullptr, nosem, nullptr, nullptr, layer_filter(role));
+        }
+        return;
+      }
+    }
     if (wave < 2) {
       pc_consumer<WRITE_AUX, NSEM>(s_rec[slot], s_rec[slot + 2], &s_ctl[slot], lane, x0, y0, W, H, out,
                   ckpt_writer(ck, tile, q, rb, re), re - rb, pc_err, sem,
@@ -1880,7 +1664,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   // A light tile is a whole tile on one wave (measured 40-70 us for 100-250 entries), longer than
   // a quarter wave of a class-2 tile (20-30 us), so it must not come last.
   const uint32_t nlwg = (nlight + RW_WAVES - 1) / RW_WAVES;
-  const uint32_t b0 = blockIdx.x - pc_slots;
+  const uint32_t b0 = blockIdx.x - pc_n;
   const bool is_heavy = b0 < n1 || b0 >= n1 + nlwg;
   const uint32_t b = b0 < n1 ? b0 : (is_heavy ? b0 - nlwg : b0 - n1);   // index in its kind
   if (is_heavy) {
@@ -1997,9 +1781,10 @@ void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_li
   if (!classified)
     classify_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, s>>>((uint32_t)ntiles, ranges, cls, work);
   const LayerOut lo = {layer_background, out_color_bg, out_alpha_bg, out_color_obj, out_alpha_obj};
-  // four workgroups per class-0 tile; in a layered frame a tile with object entries is class 0 from
-  // cls.c0_obj_min entries (common.h tile_class_of): at most cap / c0_obj_min tiles
-  const uint32_t pc_slots = 4u * (uint32_t)((size_t)cap / (cls.c0_obj_min < cls.c0_min ? cls.c0_obj_min : cls.c0_min) + 1);
+  // six workgroups per class-0 tile; in a layered frame a tile with object entries is class 0 from
+  // cls.c0_obj_min entries (common.h tile_class_of): at most cap / c0_obj_min tiles.  An upper bound of the grid
+  // only: the kernel maps by the device's count and the surplus exits at the end of the grid.
+  const uint32_t pc_slots = 6u * (uint32_t)((size_t)cap / (cls.c0_obj_min < cls.c0_min ? cls.c0_obj_min : cls.c0_min) + 1);
   const CkptArgs ck = CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
   const SemSrc sem = {nullptr, 0, nullptr};
   if (epi)
