@@ -30,7 +30,7 @@ Extra objects in the line:
                   HIP events on the op's stream around the launch with one frame in flight (a pass of
                   20 frames right behind the timed region; agrees with the rocprofv3 average committed
                   under profiles/), vs 8 TB/s.  `traffic` = HBM bytes per launch from the committed PMC
-                  passes of this round (profiles/round5_traffic.json), null if absent.
+                  passes of this round (profiles/round6_traffic.json), null if absent.
   roofline_overlapped  the same kernel's wall duration INSIDE the timed region, where several
                   frames share the chip: time-sharing, not the kernel's speed.
   roofline_valu   the render kernel's real bound: VALU busy time from the committed PMC pass
@@ -837,9 +837,23 @@ def main():
             t1 = _t(lambda: hz.render_all_fused(sc, cam0, obj))
             render_all_leg = {"three_op_calls_ms": t3, "one_pass_ms": t1, "speedup": t3 / t1,
                               "objects": int(obj.sum().item()),
+                              "objects_are": "the 10 k scene Gaussians nearest to ten road points (round 5's case): the "
+                                             "selection sweeps up metre-sized ground splats, so two thirds of the "
+                                             "frame's tiles hold object entries",
                               "what": "harness.render_all (the reference's render_all pattern: subset tensors + three "
                                       "op calls) vs harness.render_all_fused (grpg_forward_layers), wall time per "
                                       "frame incl. clamps; planes bit-identical (tests/test_gpu_layers.py)"}
+            # the same leg with ACTOR-like objects: ten car-sized boxes of small Gaussians on the road (harness.actor_scene,
+            # the shape of the scene graph's actor models): a tenth of the tiles hold object entries
+            del obj
+            sc_a, obj_a = hz.actor_scene()
+            sc_a, obj_a = sc_a.to(dev), obj_a.to(dev)
+            t3a = _t(lambda: hz.render_all(sc_a, cam0, obj_a))
+            t1a = _t(lambda: hz.render_all_fused(sc_a, cam0, obj_a))
+            render_all_leg["actors"] = {"three_op_calls_ms": t3a, "one_pass_ms": t1a, "speedup": t3a / t1a,
+                                        "objects": int(obj_a.sum().item()),
+                                        "objects_are": "ten car-sized boxes of 10 k small Gaussians (harness.actor_scene)"}
+            del sc_a, obj_a
 
         if world > 1:
             te = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
@@ -934,13 +948,15 @@ def main():
         # MI355X_MICROARCH.md prescribes), if a profile of this same workload AND this round's kernels
         # has been committed; otherwise null.  Not measurable inside this process.
         traffic, pmc, pmc_file = None, None, None
-        for name in ("round5_traffic.json", "round4_traffic.json", "round3_traffic.json"):
+        for name in ("round6_traffic.json", "round5_traffic.json", "round4_traffic.json", "round3_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 wl = tr.get("workload", {})
                 if wl.get("P") == P and wl.get("width") == W and wl.get("height") == H:
                     pmc = tr["render_forward_kernel"]
-                    traffic = pmc["hbm_bytes_corrected"]
+                    # round 6: record gathers count in full in FETCH_SIZE, streams at one half (calibrated,
+                    # profiles/round6_fetch_calibration.json); older files only have the all-streams correction
+                    traffic = pmc.get("hbm_bytes_calibrated", pmc["hbm_bytes_corrected"])
                     pmc_file = "profiles/" + name
                     break
             except Exception:

@@ -160,6 +160,30 @@ def street_scene(P=1_000_000, seed=149, sh_degree=1, scale_mul=1.0) -> Scene:
                  sh_degree)
 
 
+def actor_scene(NB=1_900_000, NA=10, PA=10_000, seed=2):
+    """(Scene, object mask): a street scene of NB background Gaussians plus NA actor-like objects -- car-sized boxes
+    (4.5 x 1.6 x 2 m) of PA small Gaussians (sigma ~ 5 cm, log-normal) standing on the road ahead, the shape
+    tools/bench_compose.py poses its actor models in ("10 actors of 10 k").  The flat-tensor
+    twin of the scene graph: what ``pc.set_visibility(all models)`` hands the op, with the actors' Gaussians last."""
+    g = torch.Generator().manual_seed(seed)
+    parts = [street_scene(NB, seed=seed)]
+    for k in range(NA):
+        a = 0.05 * k
+        loc = (torch.rand(PA, 3, generator=g) - 0.5) * torch.tensor([4.5, 1.6, 2.0])
+        ca, sa = math.cos(a), math.sin(a)
+        rot = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]])
+        xyz = loc @ rot.T + torch.tensor([-12.0 + 2.5 * k, 0.8, 10.0 + 8.0 * k])
+        q = torch.nn.functional.normalize(torch.randn(PA, 4, generator=g), dim=1)
+        parts.append(Scene(xyz, torch.sigmoid(1.0 + 2.0 * torch.randn(PA, 1, generator=g)),
+                           torch.exp(math.log(0.05) + 0.5 * torch.randn(PA, 3, generator=g)), q,
+                           torch.cat((0.5 * torch.randn(PA, 1, 3, generator=g), 0.15 * torch.randn(PA, 3, 3, generator=g)), 1), 1))
+    cat = lambda k: torch.cat([getattr(p, k) for p in parts]).contiguous()   # noqa: E731
+    sc = Scene(cat("means3D"), cat("opacity"), cat("scales"), cat("rotations"), cat("shs"), 1)
+    obj = torch.zeros(sc.means3D.shape[0], dtype=torch.bool)
+    obj[NB:] = True
+    return sc, obj
+
+
 def toy_scene(P=2000, seed=1, sh_degree=1, depth=6.0, spread=2.5, scale=0.08) -> Scene:
     """Small cloud in front of an identity camera, for fast parity tests."""
     g = torch.Generator().manual_seed(seed)

@@ -173,3 +173,33 @@ def test_frame_without_gaussians_and_argument_errors(dev):
     with pytest.raises(RuntimeError, match="ray_matrix"):
         rast.forward_frame(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
                            sky_cube=sky.sky_cube_map)
+
+
+def test_frame_epilogue_full_size(dev):
+    """configs[2]'s frame (P = 2 M @1920x1280) with a 256^2 sky: bytes and planes of the one-call frame against the
+    three-launch chain, plain and layered (ten actor-sized object clusters)."""
+    from gaussianrpg_amd.sky import ray_matrix
+    sc, obj = hz.actor_scene()
+    d, m = sc.to(dev), obj.to(dev)
+    cam = hz.trajectory_camera(5, device=dev)
+    K, w2c = _K_w2c(cam)
+    sky = _sky(dev, res=256, seed=11)
+    rast = _rast(cam, 1, dev)
+    kw = dict(shs=d.shs, scales=d.scales, rotations=d.rotations)
+    rm = ray_matrix(K.to(dev), w2c.to(dev))
+    with torch.no_grad():
+        color, radii, depth, alpha, _ = rast(means3D=d.means3D, means2D=None, opacities=d.opacity, **kw)
+        rgb_ref, bytes_ref = _chain(sky, torch.clamp(color, 0.0, 1.0), alpha, K, w2c)
+        res = rast.forward_frame(d.means3D, d.opacity, sky_cube=sky.sky_cube_map, ray_matrix=rm, planes=True, **kw)
+        lay_ref = rast.forward_layers(d.means3D, d.opacity, m, **kw)
+        lay = rast.forward_frame(d.means3D, d.opacity, layer_class=m, sky_cube=sky.sky_cube_map, ray_matrix=rm, **kw)
+    torch.cuda.synchronize()
+    _same("rgb8", res["rgb8"], bytes_ref)
+    _same("rgb", res["rgb"], rgb_ref)
+    _same("depth", res["depth"], depth)
+    _same("rgb8 (layered)", lay["rgb8"], bytes_ref)
+    for k in ("color_background", "alpha_background", "color_object", "alpha_object"):
+        _same(k, lay[k], lay_ref[k])
+    # the frame is not trivial: sky shows through and the actors are there
+    assert float((rgb_ref - torch.clamp(color, 0, 1)).abs().max()) > 0.05
+    assert float(lay_ref["alpha_object"].max()) > 0.5

@@ -64,24 +64,8 @@ with torch.no_grad():
 # on the road ahead, the shape tools/bench_compose.py poses its actor models in ("10 actors of
 # 10 k"), appended to a 1.9 M background.  The first case marks the 10 k scene Gaussians NEAREST to ten road points
 # as objects, which sweeps up metre-sized ground splats: two thirds of the frame's tiles then hold object entries.
-import math
-g = torch.Generator().manual_seed(2)
-bgs = hz.street_scene(1_900_000, seed=2)
-parts, NA, PA = [bgs], 10, 10_000
-for k in range(NA):
-    a = 0.05 * k
-    loc = (torch.rand(PA, 3, generator=g) - 0.5) * torch.tensor([4.5, 1.6, 2.0])
-    ca, sa = math.cos(a), math.sin(a)
-    rot = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]])
-    xyz = loc @ rot.T + torch.tensor([-12.0 + 2.5 * k, 0.8, 10.0 + 8.0 * k])
-    q = torch.nn.functional.normalize(torch.randn(PA, 4, generator=g), dim=1)
-    parts.append(hz.Scene(xyz, torch.sigmoid(1.0 + 2.0 * torch.randn(PA, 1, generator=g)),
-                          torch.exp(math.log(0.05) + 0.5 * torch.randn(PA, 3, generator=g)), q,
-                          torch.cat((0.5 * torch.randn(PA, 1, 3, generator=g), 0.15 * torch.randn(PA, 3, 3, generator=g)), 1), 1))
-cat = lambda k: torch.cat([getattr(p, k) for p in parts]).contiguous().to(dev)   # noqa: E731
-sc2 = hz.Scene(cat("means3D"), cat("opacity"), cat("scales"), cat("rotations"), cat("shs"), 1)
-obj2 = torch.zeros(sc2.means3D.shape[0], dtype=torch.bool, device=dev)
-obj2[1_900_000:] = True
+sc2, obj2 = hz.actor_scene()
+sc2, obj2 = sc2.to(dev), obj2.to(dev)
 kw2 = dict(shs=sc2.shs, scales=sc2.scales, rotations=sc2.rotations)
 with torch.no_grad():
     plain2 = lambda: rast(means3D=sc2.means3D, means2D=None, opacities=sc2.opacity, **kw2)   # noqa: E731

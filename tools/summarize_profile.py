@@ -81,6 +81,22 @@ for k in agg:
         # launches); the render kernel is additionally listed under its bare name for bench.py
         entry = {"fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_corrected": 2.0 * f + w,
                  "launches_sampled": len(agg[k]["FETCH_SIZE"])}
+        # Round 6 calibration (tools/ubench/gather_fetch.hip, profiles/round6_fetch_calibration.json): FETCH_SIZE
+        # counts a wide STREAMING read at 1/2 of its bytes (the guide's case) but a GATHERED 64-byte record at 64
+        # bytes, and WRITE_SIZE is exact.  So 2 F + W (hbm_bytes_corrected) is right for the streaming kernels
+        # (preprocess, the sort and scan passes) and an UPPER bound for the two kernels that gather records by
+        # index; for those: hbm_bytes_calibrated = F + W + (the half of their STREAMED bytes the counter missed).
+        R_avg = float(bj["config"].get("R_avg") or 0.0)
+        if k.startswith("render_forward_kernel"):
+            # streams: the point list, at most 4 R bytes from memory (the quarter waves of a tile re-read it from L2)
+            entry["hbm_bytes_calibrated"] = f + w + 2.0 * R_avg
+            entry["calibration"] = "F + W + 2 R_avg: record gathers count in full, the point-list stream (<= 4 R bytes) at one half"
+        elif k.startswith("hb_fill_kernel"):
+            # streams: 8 bytes per coarse pair (key, id); Rc ~ 0.22 R; tables are a few MB
+            entry["hbm_bytes_calibrated"] = f + w + 4.0 * 0.22 * R_avg
+            entry["calibration"] = "F + W + 4 Rc (Rc ~ 0.22 R_avg): one 64-byte record line per coarse pair counts in full, the pairs' stream at one half"
+        else:
+            entry["hbm_bytes_calibrated"] = 2.0 * f + w
         # instruction counters of the same kernel (other PMC passes), mean per dispatch: bench.py's
         # roofline_valu reads SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU (quad-cycles) of the render kernel
         for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES",
