@@ -77,20 +77,29 @@ def idft_weights(time: float, dim: int) -> List[float]:
     return [float(v) for v in idft[0]]
 
 
+_IDFT_CONST = {}   # dims tuple -> (multiplier [1, MAX_FOURIER] int64, is_even mask, keep mask [n, MAX_FOURIER], zero)
+
+
 def _idft_rows(times: Sequence[float], dims: Sequence[int]) -> torch.Tensor:
     """IDFT(time_i, dim_i) for all models at once, [n, MAX_FOURIER] float32 (zero beyond dim_i): the
     reference's formula (sh_utils.py:120-130) applied to a column of times -- the same float32
-    elementwise operations, hence the same bits as one call per model, at one fiftieth of the host
-    time (a per-actor call costs 50 us of Python / dispatcher overhead)."""
-    n = len(times)
+    elementwise operations in the same order ((pi t) k, then cos / sin), hence the same bits as one call per
+    model (tests/test_compose.py pins both against the reference-derived fixture), at a fraction of the host time:
+    a per-actor call costs 50 us of Python / dispatcher overhead, and everything that depends on the models only
+    (the index pattern, which columns a model uses) is built once per set of Fourier dimensions -- this runs once
+    per FRAME in the simulator's loop (round 6: 60 -> 25 us)."""
+    key = tuple(int(d) for d in dims)
+    c = _IDFT_CONST.get(key)
+    if c is None:
+        indices = torch.arange(MAX_FOURIER)
+        is_even = (indices % 2 == 0).view(1, -1)
+        mult = torch.where(is_even, indices.view(1, -1), indices.view(1, -1) + 1)     # k (even k), k + 1 (odd k)
+        keep = indices.view(1, -1) < torch.tensor(key).view(-1, 1)
+        c = _IDFT_CONST[key] = (mult, is_even, keep, torch.zeros(()))
+    mult, is_even, keep, zero = c
     t = torch.tensor([float(x) for x in times], dtype=torch.float32).view(-1, 1)
-    idft = torch.zeros(n, MAX_FOURIER)
-    indices = torch.arange(MAX_FOURIER)
-    even, odd = indices[::2], indices[1::2]
-    idft[:, even] = torch.cos(torch.pi * t * even)
-    idft[:, odd] = torch.sin(torch.pi * t * (odd + 1))
-    keep = indices.view(1, -1) < torch.tensor([int(d) for d in dims]).view(-1, 1)
-    return torch.where(keep, idft, torch.zeros(()))
+    arg = torch.pi * t * mult                       # (pi t) k in float32, like torch.pi * t * even / (odd + 1)
+    return torch.where(keep & is_even, torch.cos(arg), torch.where(keep, torch.sin(arg), zero))
 
 
 def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
