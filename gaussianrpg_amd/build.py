@@ -166,6 +166,9 @@ EXPERIMENT_VARIANTS = {
     "fill_nogather": {"hier_binning.hip": ["-DGRPG_FILL_ABLATE=2"]},
     "filltrace": {"hier_binning.hip": ["-DGRPG_FILL_TRACE"]},
     "layers3w": {"render_fwd.hip": ["-DGRPG_LAYERS_MIN_WAVES=3"]},
+    # round 6 (wrong host bytes): a drained frame whose drain workgroups exit at once -- what the blending waves' share
+    # of a host-destination frame costs (write-through staging stores, the arrival's wait and atomic)
+    "drainidle": {"render_fwd.hip": ["-DGRPG_DRAIN_IDLE"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

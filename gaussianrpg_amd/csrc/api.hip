@@ -625,6 +625,29 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
   uint32_t* work = (uint32_t*)(img + IL.work);
 
+  // A frame whose bytes go to pinned host memory is DRAINED (render_fwd.hip FrameEpi) when its width allows whole
+  // 64-byte lines per unit: staging bytes in the n_contrib plane (an evaluation frame tracks no n_contrib: 4 bytes
+  // per pixel lie idle), the units' arrival counters behind the layered frame's tile flags in the checkpoint-count
+  // area (a training forward's; T / 4 of its 4 T words).  GRPG_DRAIN_WGS (experiments): workgroups that carry the
+  // units, 0 = the blending waves store straight into host memory.
+  FrameEpilogue epi_drained;
+  uint32_t drain_cnt_words = 0u;
+  if (epi && epi->rgb8 && epi->rgb8_host && (width & 63) == 0 && P > 0) {
+    static const int drain_cfg = [] { const char* v = getenv("GRPG_DRAIN_WGS"); return v ? atoi(v) : FRAME_DRAIN_WGS; }();
+    // every unit needs a slot (64 per drain wave, RW_WAVES waves per workgroup), the counters 3 T words at most
+    const uint32_t NU = (uint32_t)(width / 64) * (uint32_t)cam.gy;
+    uint32_t wgs = (uint32_t)drain_cfg > (NU + 255u) / 256u ? (uint32_t)drain_cfg : (NU + 255u) / 256u;
+    if (wgs > 3u * T / 256u) wgs = 3u * T / 256u;
+    if (drain_cfg > 0 && wgs > 0u && wgs * 256u >= NU) {
+      epi_drained = *epi;
+      epi_drained.drain_stage = (unsigned char*)(img + IL.n_contrib);
+      epi_drained.drain_cnt = (uint32_t*)(img + IL.ck_count) + T;
+      epi_drained.drain_wgs = (int)wgs;
+      drain_cnt_words = wgs * 256u;
+      epi = &epi_drained;
+    }
+  }
+
   StageTimer tm(stream, g_timing_enabled);
   uint32_t R = 0;
 
@@ -685,7 +708,9 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
     launch_frame_init(stream, geom, bin, img, (uint32_t)P, fat_sort ? 0u : (uint32_t)P, Rcap,
                       (uint32_t)width, (uint32_t)height, (uint32_t)S, ranges, T, work,
                       geom + GL.zero_begin, GL.zero_end - GL.zero_begin,
-                      (flags & GRPG_FORWARD_NO_BACKWARD) == 0u, (uint32_t*)tile_obj, tile_obj_words);
+                      (flags & GRPG_FORWARD_NO_BACKWARD) == 0u,
+                      drain_cnt_words ? (uint32_t*)(img + IL.ck_count) : (uint32_t*)tile_obj,
+                      drain_cnt_words ? T + drain_cnt_words : tile_obj_words);   // (drained: flags and counters in one sweep)
     uint2* rects = hier ? (uint2*)(geom + GL.rects) : nullptr;
     uint2* rect_sorted = (uint2*)(geom + GL.rect_sorted);
     uint4* pre_counts = (uint4*)(geom + GL.pre_counts);
@@ -1239,6 +1264,7 @@ static int resolve_epilogue(const grpg_frame_epilogue* e, bool planes, FrameEpil
   out->ray_m_dev = (e->sky_cube && e->ray_matrix_on_device) ? e->ray_matrix : nullptr;
   for (int i = 0; i < 9; i++) out->ray_m[i] = (e->sky_cube && !e->ray_matrix_on_device) ? e->ray_matrix[i] : 0.f;
   out->sky_fill = e->sky_fill; out->clamp = e->clamp; out->rgb8 = e->out_rgb8; out->truncate = e->truncate;
+  out->rgb8_host = (e->out_rgb8 != nullptr && e->out_rgb8_on_host) ? 1 : 0;
   out->planes = planes ? 1 : 0;
   return GRPG_OK;
 }

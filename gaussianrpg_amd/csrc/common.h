@@ -491,6 +491,7 @@ struct PCErr {
   uint32_t* header_word;   // image blob header: pc_timeout
   uint32_t* host_word;     // the calling thread's sticky error word (pinned, device-mapped), may be NULL
 };
+constexpr int FRAME_DRAIN_WGS = 16;   // workgroups of a drained frame's render that carry finished units to the host
 // grpg_frame_epilogue with its pointers checked (render_fwd.hip FrameEpi): sky composite, clamps, rgb8 bytes
 struct FrameEpilogue {
   const float* sky_cube; int sky_res;   // NULL: no sky composite
@@ -499,6 +500,12 @@ struct FrameEpilogue {
   float sky_fill;
   int clamp;
   unsigned char* rgb8;                  // device [H,W,3] or NULL
+  int rgb8_host;                        // rgb8 is device-mapped pinned HOST memory: write-through stores
+  // a host frame is DRAINED when the render can (render_fwd.hip FrameEpi): staging bytes + per-unit arrival counters
+  // in the image blob (api.hip), workgroups reserved for carrying finished units across the link
+  unsigned char* drain_stage;           // device [H,W,3], 16-byte aligned, or NULL
+  uint32_t* drain_cnt;                  // device [drain_wgs * 256], zero when the render starts
+  int drain_wgs;
   int truncate;
   int planes;                           // write the float planes as well
 };

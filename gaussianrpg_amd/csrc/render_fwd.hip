@@ -455,6 +455,16 @@ struct FrameEpi {
   unsigned char* rgb8;      // [H,W,3] interleaved bytes, or NULL
   float bias;               // 0 = truncate like astype(np.uint8), 0.5 = round to nearest
   int planes;               // the float planes are written too (colour = the FINAL rgb, depth, alpha)
+  int host;                 // how rgb8 is stored: 0 plain; 1 rgb8 IS device-mapped pinned host memory
+                            // (grpg_frame_epilogue.out_rgb8_on_host), system-scope write-through; 2 rgb8 is the
+                            // device STAGING frame of a drained frame (below), agent-scope write-through
+  // Drained frame (host destination, W % 64 == 0): the blending waves never touch the link.  They store their bytes
+  // into a device staging frame and count their pixels into the counter of their UNIT (64 x 16 pixels = four tiles
+  // side by side = 16 rows x three whole 64-byte lines); drain_wgs workgroups at the front of the grid watch the
+  // counters and carry every complete unit to host8 in whole lines while the launch is still blending.
+  unsigned char* host8;     // the pinned host frame (drained frame), or NULL
+  uint32_t* unit_cnt;       // [drain waves][64] pixels arrived per unit (zero at launch, zero again at its end)
+  int drain_wgs, units_x;
 };
 // final rgb of a pixel from its blended colour (background included) and T; optional byte store
 template <bool EPI>
@@ -472,8 +482,126 @@ __device__ __forceinline__ void frame_finish(const FrameEpi& e, const int px, co
       rgb[2] = sky_over(rgb[2], sky[2], tr, e.clamp);
     }
     if (e.rgb8 != nullptr) {
-      unsigned char* d = e.rgb8 + 3 * pix;
-      d[0] = colour_u8(rgb[0], e.bias); d[1] = colour_u8(rgb[1], e.bias); d[2] = colour_u8(rgb[2], e.bias);
+      const uint32_t r8 = colour_u8(rgb[0], e.bias), g8 = colour_u8(rgb[1], e.bias), b8 = colour_u8(rgb[2], e.bias);
+      if (((W & 3) | (int)((uintptr_t)e.rgb8 & 3)) == 0) {
+        // Four neighbouring lanes hold four neighbouring pixels of a row (px = x0 + (lane & 15) on every path, x0 a
+        // multiple of 16; W % 4 == 0: the quad is inside the image or outside as a whole): 12 bytes = three aligned
+        // dwords, assembled in lanes 0-2 of the quad from the lane's own pixel and its right neighbour's.  One store
+        // instead of three, and -- what the host destination needs -- whole dwords: a write-through BYTE store
+        // crosses the link on its own (tools/ubench/host_store.hip: 176 ms per frame, against 0.21 for dwords).
+        const uint32_t pk = r8 | (g8 << 8) | (b8 << 16);
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xF9 /* quad_perm:[1,2,3,3] */, 0xF, 0xF, false);
+        const int j = px & 3;
+        const uint32_t v = (pk >> (8 * j)) | (nx << (24 - 8 * j));
+        if (j < 3) {
+          uint32_t* d = (uint32_t*)(e.rgb8 + 3 * (pix - (size_t)j) + 4 * j);
+          // host destination: system-scope store (sc0 sc1), the line leaves the L2 now instead of at the end-of-kernel
+          // write-back -- the frame crosses the link while the launch is still blending its long tiles
+          if (e.host == 1) __hip_atomic_store(d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          else if (e.host == 2) __hip_atomic_store(d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // staging: sc1
+          else *d = v;
+        }
+      } else {
+        unsigned char* d = e.rgb8 + 3 * pix;
+        d[0] = (unsigned char)r8; d[1] = (unsigned char)g8; d[2] = (unsigned char)b8;
+      }
+    }
+  }
+}
+
+// Drained frame: a wave has stored all its pixels of one tile (npix of them inside the image; the call is
+// wave-uniform, after the wave's last pixel()).  Its write-through stores are complete once vmcnt reaches zero
+// (gfx9: stores count there too) -- only then does the unit's counter learn of them.
+template <bool EPI>
+__device__ __forceinline__ void frame_arrive(const FrameEpi& e, const int x0, const int y0, const uint32_t npix) {
+  if constexpr (EPI) {
+    if (e.unit_cnt != nullptr && npix != 0u) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt / lgkmcnt left alone)
+      if (__lane_id() == 0) {
+        const uint32_t u = (uint32_t)(y0 >> 4) * (uint32_t)e.units_x + (uint32_t)(x0 >> 6);
+        const uint32_t nd = (uint32_t)e.drain_wgs * RW_WAVES;   // counter of unit u: drain wave u % nd, slot u / nd
+        __hip_atomic_fetch_add(e.unit_cnt + (size_t)(u % nd) * 64u + u / nd, npix, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+// pixels of a wave's rows that lie inside the image (lanes & 15 -> x, the wave-uniform rest -> rows)
+__device__ __forceinline__ uint32_t wave_pixels_inside(const bool inside) { return (uint32_t)__popcll(__ballot(inside)); }
+
+__device__ __forceinline__ void pc_fail(const PCErr err, const int lane);   // (below, with the wave pairs)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// One wave of a drain workgroup.  It owns the units  wid + nd * lane  (nd = drain waves of the launch), polls their
+// counters and copies a unit the moment it is complete: rows x 192 bytes = whole 64-byte lines, read past the L2
+// (the blending waves sit on other XCDs: agent scope) and written through to the host in 16-byte pieces -- four
+// neighbouring lanes make a line, so the link carries 64-byte writes (tools/ubench/host_store.hip: 0.145 ms of link
+// time per 1920x1280 frame, against 0.21 for the tiles' own 48-byte row segments).  A unit's counter goes back to
+// zero behind its copy: a frame that is rendered twice (capacity overflow) starts clean.  The wait is bounded like
+// the wave pairs' (pc_fail): a lost arrival is reported, not waited for.
+__device__ __forceinline__ void drain_units(const FrameEpi& e, const int W, const int H, const uint32_t wid,
+                                            const uint32_t nd, const int lane, const PCErr err) {
+#ifdef GRPG_DRAIN_IDLE   // experiment build: nobody drains (the blending waves' share of the cost; wrong host bytes)
+  return;
+#endif
+  const uint32_t gy = (uint32_t)(H + 15) >> 4, NU = (uint32_t)e.units_x * gy;
+  const size_t pitch = (size_t)3 * W;
+  // unit u belongs to wave u % nd, slot u / nd (< 64: the launch has >= NU / 64 drain waves); a wave's 64 counters
+  // are contiguous (one 256-byte poll), its units spread over the frame (neighbours finish together: not one
+  // wave's burst)
+  const uint32_t u = (uint32_t)lane * nd + wid;
+  const bool valid = u < NU;
+  const uint32_t uy = valid ? u / (uint32_t)e.units_x : 0u;
+  const uint32_t target = 64u * (uint32_t)min(16, H - 16 * (int)uy);
+  uint32_t* const my_cnt = e.unit_cnt + (size_t)wid * 64u + (uint32_t)lane;
+  uint64_t pending = __ballot(valid);
+  const uint64_t t0 = wall_clock64();
+  while (pending != 0ull) {
+    const bool mine = (pending >> lane) & 1ull;
+    const uint32_t c = mine ? __hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint64_t ready = __ballot(mine && c >= target);
+    if (ready == 0ull) {
+      if (wall_clock64() - t0 > 50000000ull) { pc_fail(err, lane); return; }   // 0.5 s of the 100 MHz clock
+      __builtin_amdgcn_s_sleep(32);
+      continue;
+    }
+    pending &= ~ready;
+    if (mine && c >= target) __hip_atomic_store(my_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (ready != 0ull) {   // two units per trip: six 16-byte reads in flight per lane
+      const int b0 = (int)__builtin_ctzll(ready);
+      ready &= ready - 1ull;
+      const bool two = ready != 0ull;
+      const int b1 = two ? (int)__builtin_ctzll(ready) : b0;
+      ready &= ready - 1ull;   // (0 & anything stays 0)
+      size_t off[2][3];
+      uint64_t v[2][3][2];
+      int chunks[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint32_t uu = (uint32_t)(k == 0 ? b0 : b1) * nd + wid;
+        const uint32_t ry = uu / (uint32_t)e.units_x, rx = uu - ry * (uint32_t)e.units_x;
+        chunks[k] = (k == 1 && !two) ? 0 : 12 * min(16, H - 16 * (int)ry);   // 16-byte pieces of the unit
+        const size_t org = (size_t)16 * ry * pitch + (size_t)192 * rx;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int cidx = min(i * 64 + lane, 12 * min(16, H - 16 * (int)ry) - 1);   // (beyond the unit: a harmless second read)
+          off[k][i] = org + (size_t)(cidx / 12) * pitch + (size_t)16 * (cidx % 12);
+          const uint64_t* src = (const uint64_t*)(e.rgb8 + off[k][i]);
+          v[k][i][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v[k][i][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          if (i * 64 + lane < chunks[k]) {
+            const u32x4 q = {(uint32_t)v[k][i][0], (uint32_t)(v[k][i][0] >> 32), (uint32_t)v[k][i][1],
+                             (uint32_t)(v[k][i][1] >> 32)};
+            unsigned char* dst = e.host8 + off[k][i];
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(q) : "memory");
+          }
+        }
+      }
     }
   }
 }
@@ -497,6 +625,10 @@ struct PlainOutT {
       out_depth[pix] = CbD.y;
     }
     if (AUX) n_contrib[pix] = last;
+  }
+  // the wave's pixels of tile (x0, y0 / 16) are stored (drained frame: frame_arrive)
+  __device__ __forceinline__ void arrive(const int x0, const int y0, const uint32_t npix) const {
+    frame_arrive<EPI>(epi, x0, y0, npix);
   }
 };
 typedef PlainOutT<false> PlainOut;
@@ -550,6 +682,10 @@ struct LayersOutT {
   __device__ __forceinline__ void pixel(const int px, const int py, const float T, const v2f CrCg, const v2f CbD,
                                         const uint32_t) const {
     pixel3(px, py, T, CrCg, CbD, T, CrCg, CbD, 1.0f, (v2f){0.f, 0.f}, (v2f){0.f, 0.f});
+  }
+  // (the epilogue belongs to the composition: every path that writes pixel_a arrives once per wave)
+  __device__ __forceinline__ void arrive(const int x0, const int y0, const uint32_t npix) const {
+    frame_arrive<EPI>(epi, x0, y0, npix);
   }
 };
 typedef LayersOutT<false> LayersOut;
@@ -666,11 +802,14 @@ __device__ __forceinline__ void blend_rect(float4* __restrict__ my, const int la
     __builtin_amdgcn_wave_barrier();
   }
 
+  uint32_t npix = 0u;
 #pragma unroll
   for (int k = 0; k < PX; k++) {
     const int py = py0 + k;
     if (px < W && py < H) out.template pixel<WRITE_AUX>(px, py, st.T[k], st.CrCg[k], st.CbD[k], st.last[k]);
+    npix += wave_pixels_inside(px < W && py < H);
   }
+  out.arrive(x0, y0, npix);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1010,6 +1149,7 @@ __device__ __forceinline__ void blend_heavy(float4* __restrict__ my, uint32_t* _
   if (AUX) ckpt_finish(ckw, lane, st, r_end - r_begin);
 
   if (px < W && py < H) out.template pixel<AUX>(px, py, st.T[0], st.CrCg[0], st.CbD[0], st.last[0]);
+  out.arrive(x0, y0, wave_pixels_inside(px < W && py < H));
   if (NSEM > 0)   // (all lanes: the accumulators are spread over the wave; the ring is dead by now)
     sem_write<NSEM>(sa, sem.S, out_semantic, (size_t)H * W, (size_t)py * W + px, px < W && py < H, lane,
                     reinterpret_cast<float*>(qid), reinterpret_cast<float*>(qpos));
@@ -1280,6 +1420,7 @@ __device__ __forceinline__ void pc_consumer(const float4* __restrict__ buf0,
   }
   if (AUX) ckpt_finish(ckw, lane, st, len);
   if (px < W && py < H) out.template pixel<AUX>(px, py, st.T[0], st.CrCg[0], st.CbD[0], st.last[0]);
+  out.arrive(x0, y0, wave_pixels_inside(px < W && py < H));
   if (NSEM > 0)
     sem_write<NSEM>(sa, sem.S, out_semantic, (size_t)H * W, (size_t)py * W + px, px < W && py < H, lane, t_lo, t_hi);
 }
@@ -1472,6 +1613,7 @@ __device__ __forceinline__ void blend_heavy_layers(float4* __restrict__ my, uint
     if (ncur == 0 && ls.exhausted()) break;
   }
   L.write(out, px, py, W, H);
+  out.arrive(x0, y0, wave_pixels_inside(px < W && py < H));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1497,6 +1639,9 @@ struct LayerRoleOut {   // ROLE 0 composition (epilogue included), 1 background 
     if (ROLE == 0) o.pixel_a(px, py, T, CrCg, CbD);
     else if (ROLE == 1) o.pixel_b(px, py, T, CrCg, CbD);
     else o.pixel_o(px, py, T, CrCg, CbD);
+  }
+  __device__ __forceinline__ void arrive(const int x0, const int y0, const uint32_t npix) const {
+    if (ROLE == 0) o.arrive(x0, y0, npix);
   }
 };
 __device__ __forceinline__ ClassFilter layer_filter(const int role) {
@@ -1577,15 +1722,27 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   //   with object entries, >= RENDER_PC_MIN: per layer two half-tile wave pairs (workgroup = 2 layer + half);
   //   with object entries, shorter: per layer four quarter waves (workgroups 0 .. 2).
   const uint32_t pc_n = LAYERS ? min(6u * n0, pc_slots) : pc_slots;
+  // a drained frame (FrameEpi::host8): the first drain_wgs workgroups carry finished units to the host
+  uint32_t bx = blockIdx.x;
+  if constexpr (EPI) {
+    if (epi.host8 != nullptr) {
+      const uint32_t ndw = (uint32_t)epi.drain_wgs;
+      if (bx < ndw) {
+        drain_units(epi, W, H, bx * RW_WAVES + (uint32_t)wave, ndw * RW_WAVES, lane, pc_err);
+        return;
+      }
+      bx -= ndw;
+    }
+  }
 #ifdef GRPG_RENDER_ONLY_CLASS0   // experiment build: the class-0 tiles alone (their chain, nothing beside it)
-  if (blockIdx.x >= pc_n) return;
+  if (bx >= pc_n) return;
 #endif
 #ifdef GRPG_RENDER_NO_CLASS0     // experiment build: everything BUT the class-0 tiles (the throughput part)
-  if (blockIdx.x < pc_n) return;
+  if (bx < pc_n) return;
 #endif
-  if (blockIdx.x < pc_n) {
-    const uint32_t pc_ti = LAYERS ? blockIdx.x / 6u : blockIdx.x >> 1;
-    uint32_t pc_sub = LAYERS ? blockIdx.x - 6u * pc_ti : blockIdx.x & 1u;
+  if (bx < pc_n) {
+    const uint32_t pc_ti = LAYERS ? bx / 6u : bx >> 1;
+    uint32_t pc_sub = LAYERS ? bx - 6u * pc_ti : bx & 1u;
     if (pc_ti >= n0) return;
     const uint32_t tile = lists[pc_ti];
     const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile - (uint32_t)ty * (uint32_t)gx);
@@ -1664,7 +1821,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   // A light tile is a whole tile on one wave (measured 40-70 us for 100-250 entries), longer than
   // a quarter wave of a class-2 tile (20-30 us), so it must not come last.
   const uint32_t nlwg = (nlight + RW_WAVES - 1) / RW_WAVES;
-  const uint32_t b0 = blockIdx.x - pc_n;
+  const uint32_t b0 = bx - pc_n;
   const bool is_heavy = b0 < n1 || b0 >= n1 + nlwg;
   const uint32_t b = b0 < n1 ? b0 : (is_heavy ? b0 - nlwg : b0 - n1);   // index in its kind
   if (is_heavy) {
@@ -1723,13 +1880,19 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
   }
 }
 
-static FrameEpi make_frame_epi(const FrameEpilogue* e) {
+static FrameEpi make_frame_epi(const FrameEpilogue* e, const int W = 0, const bool may_drain = false) {
   FrameEpi d{};
   if (e == nullptr) return d;
   d.sky.cube = e->sky_cube; d.sky.res = e->sky_res; d.sky.fill = e->sky_fill; d.sky.clamp_out = e->clamp;
   d.sky.m_dev = e->ray_m_dev; d.sky.mask = nullptr; d.sky.jitter = nullptr;
   for (int i = 0; i < 9; i++) d.sky.m[i] = e->ray_m_dev ? 0.f : e->ray_m[i];
   d.clamp = e->clamp; d.rgb8 = e->rgb8; d.bias = e->truncate ? 0.0f : 0.5f; d.planes = e->planes;
+  d.host = e->rgb8_host;
+  if (may_drain && e->rgb8_host && e->drain_stage != nullptr && e->drain_cnt != nullptr && e->drain_wgs > 0 &&
+      (W & 63) == 0 && ((uintptr_t)e->rgb8 & 15) == 0 && ((uintptr_t)e->drain_stage & 15) == 0) {
+    d.host8 = e->rgb8; d.rgb8 = e->drain_stage; d.host = 2;
+    d.unit_cnt = e->drain_cnt; d.drain_wgs = e->drain_wgs; d.units_x = W / 64;
+  }
   return d;
 }
 
@@ -1787,11 +1950,12 @@ void launch_render_layers(hipStream_t s, const uint2* ranges, uint32_t* point_li
   const uint32_t pc_slots = 6u * (uint32_t)((size_t)cap / (cls.c0_obj_min < cls.c0_min ? cls.c0_obj_min : cls.c0_min) + 1);
   const CkptArgs ck = CkptArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
   const SemSrc sem = {nullptr, 0, nullptr};
-  if (epi)
-    render_forward_kernel<false, 2, false, 0, true, true><<<ntiles + pc_slots, 256, 0, s>>>(
+  if (epi) {
+    const FrameEpi fe = make_frame_epi(epi, W, true);
+    render_forward_kernel<false, 2, false, 0, true, true><<<ntiles + pc_slots + fe.drain_wgs, 256, 0, s>>>(
         ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, out_alpha, nullptr,
-        pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj, make_frame_epi(epi));
-  else
+        pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj, fe);
+  } else
     render_forward_kernel<false, 2, false, 0, true><<<ntiles + pc_slots, 256, 0, s>>>(
         ranges, point_list, rec, W, H, gx, (uint32_t)ntiles, work, bg, out_color, out_depth, out_alpha, nullptr,
         pc_slots, ck, pc_err, sem, nullptr, nullptr, 0, lo, cls.obj);
@@ -1926,9 +2090,9 @@ void launch_render_forward(hipStream_t s, const uint2* ranges, const uint32_t* p
   // the light (4 pixels per lane) path evaluates two splats per inner iteration (one: measured
   // slower); the heavy path always evaluates quads
   if (epi != nullptr && !aux && S == 0) {   // evaluation frame with the callers' epilogue fused in (grpg_forward_frame)
-    render_forward_kernel<false, 2, false, 0, false, true><<<ntiles + pc_slots, 256, 0, s>>>(
-        RF_ARGS, nullptr, 0, LayerOut{nullptr, nullptr, nullptr, nullptr, nullptr}, TileObjBits{nullptr, 0},
-        make_frame_epi(epi));
+    const FrameEpi fe = make_frame_epi(epi, W, true);
+    render_forward_kernel<false, 2, false, 0, false, true><<<ntiles + pc_slots + fe.drain_wgs, 256, 0, s>>>(
+        RF_ARGS, nullptr, 0, LayerOut{nullptr, nullptr, nullptr, nullptr, nullptr}, TileObjBits{nullptr, 0}, fe);
   } else if (S > 0) {
     // semantic planes ride in the heavy path: up to RENDER_NSEM channels in this launch, the rest
     // (S > RENDER_NSEM) in the stand-alone kernel below

@@ -231,7 +231,7 @@ RasterizeGaussiansLayers(const torch::Tensor& background, const torch::Tensor& l
   return std::make_tuple(rendered, out_color, out_depth, out_alpha, radii, color_bg, alpha_bg, color_obj, alpha_obj);
 }
 
-// ---- the frame epilogue (grpg_forward_frame / grpg_forward_composed_frame, ABI 6) ----
+// ---- the frame epilogue (grpg_forward_frame / grpg_forward_composed_frame, ABI 6; host destination: ABI 7) ----
 // sky_cube: [6,res,res,3] float32 on the device, or an empty tensor (no sky composite); ray_matrix: 9 floats, CPU
 // (taken by value) or device (read by the kernel: no host round trip).
 struct EpilogueArgs {
@@ -241,7 +241,7 @@ struct EpilogueArgs {
 static void make_epilogue(EpilogueArgs& a, const torch::Tensor& like, const torch::Tensor& sky_cube,
                           const torch::Tensor& ray_matrix, const float sky_fill, const bool clamp, const bool want_rgb8,
                           const bool truncate, const c10::optional<torch::Tensor>& out_rgb8, const int H, const int W) {
-  a.e = grpg_frame_epilogue{nullptr, 0, nullptr, 0, sky_fill, clamp ? 1 : 0, nullptr, truncate ? 1 : 0};
+  a.e = grpg_frame_epilogue{nullptr, 0, nullptr, 0, sky_fill, clamp ? 1 : 0, nullptr, truncate ? 1 : 0, 0};
   if (sky_cube.defined() && sky_cube.numel() != 0) {
     TORCH_CHECK(sky_cube.dim() == 4 && sky_cube.size(0) == 6 && sky_cube.size(1) == sky_cube.size(2) &&
                     sky_cube.size(3) == 3 && sky_cube.scalar_type() == torch::kFloat32 && sky_cube.device() == like.device(),
@@ -258,10 +258,16 @@ static void make_epilogue(EpilogueArgs& a, const torch::Tensor& like, const torc
   }
   if (want_rgb8) {
     if (out_rgb8.has_value() && out_rgb8->defined()) {
+      // a PINNED host tensor is a destination too (ABI 7: the epilogue stores the bytes through the link while the
+      // render runs; the caller synchronises with the stream before reading, as after a non_blocking copy)
+      const bool on_host = out_rgb8->is_cpu();
       TORCH_CHECK(out_rgb8->scalar_type() == torch::kByte && out_rgb8->numel() == (int64_t)3 * H * W &&
-                      out_rgb8->is_contiguous() && out_rgb8->device() == like.device(),
-                  "out must be a contiguous uint8 tensor of H*W*3 elements on the frame's device");
+                      out_rgb8->is_contiguous() &&
+                      (on_host ? out_rgb8->is_pinned() : out_rgb8->device() == like.device()),
+                  "out must be a contiguous uint8 tensor of H*W*3 elements on the frame's device, or in pinned host "
+                  "memory (Tensor.pin_memory())");
       a.rgb8 = *out_rgb8;
+      a.e.out_rgb8_on_host = on_host ? 1 : 0;
     } else {
       a.rgb8 = torch::empty({H, W, 3}, like.options().dtype(torch::kByte));
     }

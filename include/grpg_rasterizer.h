@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GRPG_ABI_VERSION 6   /* 6: grpg_forward_frame / grpg_forward_composed_frame (the callers' per-frame epilogue inside the render); 5: grpg_forward_layers (one-pass render_all); 4: grpg_set_capacity_hint, asynchronous-error reporting, backward argument checks */
+#define GRPG_ABI_VERSION 7   /* 7: grpg_frame_epilogue.out_rgb8_on_host (the frame's bytes stored straight into pinned host memory while the render runs); 6: grpg_forward_frame / grpg_forward_composed_frame (the callers' per-frame epilogue inside the render); 5: grpg_forward_layers (one-pass render_all); 4: grpg_set_capacity_hint, asynchronous-error reporting, backward argument checks */
 
 /* Exported symbol (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -186,6 +186,15 @@ GRPG_API int grpg_forward_layers(grpg_alloc_fn geometry_alloc, void* geometry_us
  *   clamp                  != 0: both evaluation clamps above
  *   out_rgb8               device [H,W,3] interleaved bytes (a sensor_msgs/Image "rgb8" payload), or NULL
  *   truncate               != 0: astype(np.uint8) truncation (the simulator); 0: round to nearest
+ *   out_rgb8_on_host       (ABI 7) != 0: out_rgb8 is PINNED HOST memory mapped into the device's address space
+ *                          (hipHostMalloc / hipHostRegister; torch: Tensor.pin_memory()).  The simulator consumes its
+ *                          frame on the host (simulator.py:313-328): with this flag the epilogue's stores are
+ *                          write-through (system scope), so the bytes cross the link WHILE the render's other tiles
+ *                          are still being blended, and the 7.4 MB device->host copy behind the launch (0.13 ms at
+ *                          1920x1280, a third of the render) disappears.  The bytes are complete once the stream has
+ *                          reached the end of the call (stream / event synchronisation, as for a copy).  Same bytes
+ *                          as with a device destination.  (A device pointer with the flag set still works: its lines
+ *                          merely bypass the L2's write-back.)
  * Results are bit-identical to the chain of separate calls: grpg_forward* -> clamp -> grpg_sky_composite(clamp_out)
  * -> grpg_pack_rgb_u8_hwc (tests/test_gpu_frame.py).
  *
@@ -209,6 +218,7 @@ typedef struct grpg_frame_epilogue {
   int clamp;
   unsigned char* out_rgb8;
   int truncate;
+  int out_rgb8_on_host;
 } grpg_frame_epilogue;
 
 GRPG_API int grpg_forward_frame(grpg_alloc_fn geometry_alloc, void* geometry_user,

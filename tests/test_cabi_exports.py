@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_loud_failure_without_gpu(lib):
     lib.grpg_abi_version.restype = ctypes.c_int
-    assert lib.grpg_abi_version() == 6
+    assert lib.grpg_abi_version() == 7
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present; the no-device path cannot be exercised")

@@ -152,6 +152,53 @@ def test_composed_frame_is_the_simulators_frame(dev):
     assert set(res) == {"num_rendered", "radii", "rgb8"}      # nothing else was even allocated
 
 
+@pytest.mark.parametrize("W,H", [(200, 136), (203, 121), (256, 100), (1920, 1280)])
+def test_frame_bytes_straight_into_pinned_host_memory(dev, W, H):
+    """ABI 7 (grpg_frame_epilogue.out_rgb8_on_host): ``out`` = a pinned HOST tensor -- the epilogue stores the
+    simulator's frame (simulator.py:313-328 consumes it on the host) through the link while the render runs; no
+    copy behind the launch.  Same bytes as the device destination: W % 64 == 0 is a DRAINED frame (staging bytes,
+    per-unit arrival counters, reserved workgroups that carry whole 64-byte lines to the host; 256x100: a last unit
+    row of 4 pixel rows), W % 4 == 0 the packed dword stores straight into host memory, any other width byte stores;
+    plain and layered frames, twice into the same buffers (the counters clean up behind themselves), and a frame
+    without Gaussians."""
+    from gaussianrpg_amd.sky import ray_matrix
+    if W == 1920:
+        sc, obj = hz.actor_scene()
+        cam = hz.trajectory_camera(5, device=dev)
+    else:
+        from test_gpu_layers import _objects_scene
+        sc, obj = _objects_scene(6000, 900, seed=3)
+        cam = hz.trajectory_camera(1, W=W, H=H, device=dev)
+    d, m = sc.to(dev), obj.to(dev)
+    K, w2c = _K_w2c(cam)
+    sky = _sky(dev, res=64, seed=2)
+    rast = _rast(cam, 1, dev)
+    kw = dict(shs=d.shs, scales=d.scales, rotations=d.rotations, sky_cube=sky.sky_cube_map,
+              ray_matrix=ray_matrix(K.to(dev), w2c.to(dev)))
+    host = torch.full((H, W, 3), 7, dtype=torch.uint8).pin_memory()
+    host_l = torch.full((H, W, 3), 9, dtype=torch.uint8).pin_memory()
+    host_0 = torch.full((H, W, 3), 11, dtype=torch.uint8).pin_memory()
+    z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+    with torch.no_grad():
+        ref = rast.forward_frame(d.means3D, d.opacity, **kw)["rgb8"]
+        for _ in range(2):
+            host.fill_(7), host_l.fill_(9)
+            res = rast.forward_frame(d.means3D, d.opacity, out=host, **kw)
+            rast.forward_frame(d.means3D, d.opacity, layer_class=m, out=host_l, **kw)
+            torch.cuda.synchronize()
+        ref_0 = rast.forward_frame(z(0, 3), z(0, 1), shs=z(0, 4, 3), scales=z(0, 3), rotations=z(0, 4),
+                                   sky_cube=kw["sky_cube"], ray_matrix=kw["ray_matrix"])["rgb8"]
+        rast.forward_frame(z(0, 3), z(0, 1), shs=z(0, 4, 3), scales=z(0, 3), rotations=z(0, 4), out=host_0,
+                           sky_cube=kw["sky_cube"], ray_matrix=kw["ray_matrix"])
+    torch.cuda.synchronize()      # the bytes are complete when the stream is (as after a non_blocking copy)
+    assert res["rgb8"].data_ptr() == host.data_ptr() and res["rgb8"].is_pinned()
+    _same("rgb8 in pinned host memory", host, ref)
+    _same("rgb8 in pinned host memory (layered)", host_l, ref)
+    _same("rgb8 in pinned host memory (no Gaussians)", host_0, ref_0)
+    with pytest.raises(RuntimeError, match="pinned"):     # pageable host memory is not device-visible: refused
+        rast.forward_frame(d.means3D, d.opacity, out=torch.empty(H, W, 3, dtype=torch.uint8), **kw)
+
+
 def test_frame_without_gaussians_and_argument_errors(dev):
     from gaussianrpg_amd.sky import ray_matrix
     cam = hz.trajectory_camera(0, W=70, H=50, device=dev)
