@@ -824,6 +824,35 @@ def main():
                         "bytes_per_frame": 3 * H * W,
                         "what": "rgb8 [H,W,3] in pinned host memory (device pack + async D2H), "
                                 "consumer one frame behind"}
+            # the same loop with the frame epilogue's host destination (ABI 7): clamp + bytes inside the render,
+            # stored into the pinned slot while the launch runs -- no pack launch, no copy
+            try:
+                def frame_to(i, buf):
+                    rasterizers[i % NUM_FRAMES].forward_frame(sc.means3D, sc.opacity, shs=sc.shs, scales=sc.scales,
+                                                              rotations=sc.rotations, out=buf)
+                fd2 = tj.FrameDelivery(H, W, depth=2 * ns, truncate=True)
+                for s in range(2 * ns):
+                    with torch.cuda.stream(streams[s % ns]):
+                        frame_to(frames_of(s), fd2.begin())
+                        fd2.get(fd2.commit())
+                torch.cuda.synchronize()
+                te0 = time.perf_counter()
+                tickets, checksum2 = [], 0
+                for s in range(nd):
+                    with torch.cuda.stream(streams[s % ns]):
+                        frame_to(frames_of(s), fd2.begin())
+                        tickets.append(fd2.commit())
+                    if s >= ns:
+                        checksum2 += int(fd2.get(tickets[s - ns])[0, 0, 0])
+                for s in range(max(0, nd - ns), nd):
+                    checksum2 += int(fd2.get(tickets[s])[0, 0, 0])
+                te1 = time.perf_counter()
+                delivery["host_epilogue_frames_per_s"] = nd / (te1 - te0)
+                delivery["host_epilogue_same_first_bytes"] = checksum2 == checksum
+                delivery["host_epilogue_what"] = ("forward_frame(out = the pinned slot): clamp and byte conversion in "
+                                                  "the render's epilogue, the bytes cross the link while it runs")
+            except Exception as exc:   # a side leg must never take the headline line down
+                delivery["host_epilogue_error"] = repr(exc)
 
         # The reference's non-lite evaluation path renders every frame three times (render_all: all models,
         # background alone, objects alone -- street_gaussian_renderer.py:13-40); the additive layered forward

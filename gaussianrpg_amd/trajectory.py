@@ -110,6 +110,20 @@ class FrameDelivery:
         self.n += 1
         return self.n - 1
 
+    def begin(self) -> torch.Tensor:
+        """The pinned host slot the NEXT frame lands in -- for renders that store their bytes there themselves
+        (``GaussianRasterizer.forward_frame(..., out=fd.begin())`` / ``ComposedRasterizer.forward_frame``: the
+        frame epilogue's host destination, C ABI 7): no device staging tensor, no copy behind the launch.  Follow
+        the render with ``commit()`` on the same stream."""
+        return self.host[self.n % len(self.host)]
+
+    def commit(self) -> int:
+        slot = self.n % len(self.host)
+        self.events[slot].record()
+        self.keep[slot] = None
+        self.n += 1
+        return self.n - 1
+
     def get(self, ticket: int):
         if ticket < self.n - len(self.host) or ticket >= self.n:
             raise ValueError("frame %d is no longer (or not yet) in the delivery ring" % ticket)
