@@ -199,6 +199,47 @@ def test_frame_bytes_straight_into_pinned_host_memory(dev, W, H):
         rast.forward_frame(d.means3D, d.opacity, out=torch.empty(H, W, 3, dtype=torch.uint8), **kw)
 
 
+def test_host_frames_of_many_shapes_and_streams(dev):
+    """Drained / direct / byte-store host frames over a sweep of shapes (unit rows cut by the image's bottom edge, grids
+    too small for a drain workgroup, widths that are no multiple of 64 or 4), and three frames in flight on three
+    streams into three pinned buffers: always the device destination's bytes."""
+    from gaussianrpg_amd.sky import ray_matrix
+    rng = np.random.default_rng(5)
+    shapes = [(64, 20), (128, 33), (192, 160), (320, 47), (448, 100), (512, 129), (640, 360), (100, 60), (130, 50)]
+    sc = hz.toy_scene(4000, seed=4, sh_degree=1).to(dev)
+    kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    sky = _sky(dev, res=16, seed=7)
+    for (W, H) in shapes:
+        cam = hz.trajectory_camera(int(rng.integers(0, 6)), W=W, H=H, device=dev)
+        K, w2c = _K_w2c(cam)
+        rast = _rast(cam, 1, dev, bg=[0.1, 0.2, 0.3])
+        e = dict(sky_cube=sky.sky_cube_map, ray_matrix=ray_matrix(K.to(dev), w2c.to(dev)))
+        host = torch.full((H, W, 3), 3, dtype=torch.uint8).pin_memory()
+        with torch.no_grad():
+            ref = rast.forward_frame(sc.means3D, sc.opacity, **kw, **e)["rgb8"]
+            rast.forward_frame(sc.means3D, sc.opacity, out=host, **kw, **e)
+        torch.cuda.synchronize()
+        _same("host frame %dx%d" % (W, H), host, ref)
+    # three streams, three frames in flight (each call carves its own image blob: staging and counters are per frame)
+    W, H = 640, 360
+    cams = [hz.trajectory_camera(f, W=W, H=H, device=dev) for f in range(6)]
+    rasts = [_rast(c, 1, dev) for c in cams]
+    with torch.no_grad():
+        refs = [r.forward_frame(sc.means3D, sc.opacity, **kw)["rgb8"].clone() for r in rasts]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    hosts = [torch.zeros((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(6)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad():
+        for f in range(6):
+            with torch.cuda.stream(streams[f % 3]):
+                rasts[f].forward_frame(sc.means3D, sc.opacity, out=hosts[f], **kw)
+    torch.cuda.synchronize()
+    for f in range(6):
+        _same("frame %d of the three-stream loop" % f, hosts[f], refs[f])
+
+
 def test_frame_without_gaussians_and_argument_errors(dev):
     from gaussianrpg_amd.sky import ray_matrix
     cam = hz.trajectory_camera(0, W=70, H=50, device=dev)
