@@ -165,6 +165,8 @@ EXPERIMENT_VARIANTS = {
     # round 6: the fill with every lane reading record 0 / 1 instead of its own (what does the gather cost?)
     "fill_nogather": {"hier_binning.hip": ["-DGRPG_FILL_ABLATE=2"]},
     "filltrace": {"hier_binning.hip": ["-DGRPG_FILL_TRACE"]},
+    # round 6: 512-entry segments in the hierarchical binning (26 KB of LDS, 52 registers: four fill workgroups per CU)
+    "hbseg512": {"hier_binning.hip": ["-DGRPG_HB_SEG=512"]},
     "layers3w": {"render_fwd.hip": ["-DGRPG_LAYERS_MIN_WAVES=3"]},
     # round 6 (wrong host bytes): a drained frame whose drain workgroups exit at once -- what the blending waves' share
     # of a host-destination frame costs (write-through staging stores, the arrival's wait and atomic)

@@ -36,7 +36,10 @@
 
 namespace grpg {
 
-constexpr int HB_SEG = 1024;        // coarse entries per segment
+#ifndef GRPG_HB_SEG   // experiment builds: 512
+#define GRPG_HB_SEG 1024
+#endif
+constexpr int HB_SEG = GRPG_HB_SEG;  // coarse entries per segment
 constexpr int HB_CNT_THREADS = 256;
 constexpr int HB_FILL_THREADS = 512;   // 8 waves: one per tile column of the super-tile
 
@@ -356,7 +359,7 @@ __device__ unsigned long long g_fill_trace[1024][4];
 __device__ unsigned long long g_fill_phase[1024][8];   // wave 0's accumulated ticks per phase
 #endif
 
-__global__ void __launch_bounds__(HB_FILL_THREADS)
+__global__ void __launch_bounds__(HB_FILL_THREADS, HB_SEG <= 512 ? 8 : 1)
 hb_fill_kernel(const SegDesc* __restrict__ seg, const uint32_t* __restrict__ nseg_total,
                const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cval, const RecView rec,
                const int sgx, const int gx, const int gy, const uint32_t* __restrict__ table,
@@ -546,7 +549,8 @@ void launch_hier_fill(hipStream_t s, const char* seg_desc, const uint32_t* nseg_
                       uint32_t R_cap, uint32_t* point_list) {
   const int sgx = (gx + STILE - 1) / STILE;
   // persistent workgroups: 3 fit a CU (LDS), 256 CUs
-  const uint32_t grid = max_seg < 768u ? max_seg : 768u;
+  const uint32_t wgs = HB_SEG <= 512 ? 1024u : 768u;   // (512-entry segments: 26 KB of LDS, four workgroups per CU)
+  const uint32_t grid = max_seg < wgs ? max_seg : wgs;
   hb_fill_kernel<<<grid, HB_FILL_THREADS, 0, s>>>((const SegDesc*)seg_desc, nseg_total, ckey_sorted,
                                                      cval_sorted, rec, sgx, gx, gy, seg_table, tile_start,
                                                      R_cap, point_list);
