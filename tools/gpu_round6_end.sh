@@ -12,3 +12,9 @@ cd $ROOT
 LD_PRELOAD=$ROOT/build/variants/libgrpg_rasterizer_trace.so GRPG_BWD_STATS=1 timeout 300 python tools/bench_train.py --steps 2 --warmup 1 > /dev/null 2> $OUT/bwd_stats.txt
 grep "bwd stats" $OUT/bwd_stats.txt | tail -5 > $OUT/bwd_reduction_stats.txt; cat $OUT/bwd_reduction_stats.txt
 LD_PRELOAD=$ROOT/build/variants/libgrpg_rasterizer_filltrace.so timeout 200 python tools/fill_trace.py > $OUT/fill_trace.txt 2>&1; tail -3 $OUT/fill_trace.txt
+# the host-destination frame: link micro-benchmark, the simulator leg per drain setting, the render launch's kernel time
+cd $ROOT
+[ -x tools/ubench/host_store ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/host_store tools/ubench/host_store.hip
+timeout 120 tools/ubench/host_store > $OUT/host_store.json 2> $OUT/host_store.err; cat $OUT/host_store.json
+bash tools/gpu_r6_drain.sh 0 16 2>&1 | tail -4
+bash tools/gpu_prof_sim_env.sh 0 16 2>&1 | grep -E "drain_wgs|render_forward"
