@@ -29,6 +29,7 @@ augmentation of rigid actors (street_gaussian_model.py:286-293) is ``ModelParams
 import math
 from typing import List, NamedTuple, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -77,7 +78,9 @@ def idft_weights(time: float, dim: int) -> List[float]:
     return [float(v) for v in idft[0]]
 
 
-_IDFT_CONST = {}   # dims tuple -> (multiplier [1, MAX_FOURIER] int64, is_even mask, keep mask [n, MAX_FOURIER], zero)
+_ZERO_ROW = [0.0] * 8
+_NO_FLIP = torch.empty(0, dtype=torch.bool)
+_IDFT_CONST = {}   # dims tuple -> (multiplier [1, MAX_FOURIER] float32, takes-cos mask, drop mask [n, MAX_FOURIER])
 
 
 def _idft_rows(times: Sequence[float], dims: Sequence[int]) -> torch.Tensor:
@@ -86,37 +89,48 @@ def _idft_rows(times: Sequence[float], dims: Sequence[int]) -> torch.Tensor:
     elementwise operations in the same order ((pi t) k, then cos / sin), hence the same bits as one call per
     model (tests/test_compose.py pins both against the reference-derived fixture), at a fraction of the host time:
     a per-actor call costs 50 us of Python / dispatcher overhead, and everything that depends on the models only
-    (the index pattern, which columns a model uses) is built once per set of Fourier dimensions -- this runs once
-    per FRAME in the simulator's loop (round 6: 60 -> 25 us)."""
-    key = tuple(int(d) for d in dims)
+    (the multipliers as float32 -- exact small integers, what the reference's int64 -> float32 promotion yields --,
+    which columns take the cosine, which columns a model does not use) is built once per set of Fourier dimensions.
+    This runs once per FRAME in the simulator's loop, in front of the frame's first launch (the GPU waits for it):
+    seven small tensor operations (round 6: 60 -> 25 -> 17 us)."""
+    key = dims if isinstance(dims, tuple) else tuple(int(d) for d in dims)
     c = _IDFT_CONST.get(key)
     if c is None:
         indices = torch.arange(MAX_FOURIER)
         is_even = (indices % 2 == 0).view(1, -1)
-        mult = torch.where(is_even, indices.view(1, -1), indices.view(1, -1) + 1)     # k (even k), k + 1 (odd k)
+        mult = torch.where(is_even, indices.view(1, -1), indices.view(1, -1) + 1).float()   # k (even k), k + 1 (odd k)
         keep = indices.view(1, -1) < torch.tensor(key).view(-1, 1)
-        c = _IDFT_CONST[key] = (mult, is_even, keep, torch.zeros(()))
-    mult, is_even, keep, zero = c
-    t = torch.tensor([float(x) for x in times], dtype=torch.float32).view(-1, 1)
-    arg = torch.pi * t * mult                       # (pi t) k in float32, like torch.pi * t * even / (odd + 1)
-    return torch.where(keep & is_even, torch.cos(arg), torch.where(keep, torch.sin(arg), zero))
+        c = _IDFT_CONST[key] = (mult, is_even.expand(len(key), -1).contiguous(), ~keep)
+    mult, takes_cos, drop = c
+    t = torch.from_numpy(np.asarray(times, dtype=np.float32)).view(-1, 1)
+    arg = (torch.pi * t) * mult                     # (pi t) k in float32, like torch.pi * t * even / (odd + 1)
+    return torch.where(takes_cos, torch.cos(arg), torch.sin(arg)).masked_fill_(drop, 0.0)
+
+
+def _model_lists(models: Sequence[ModelParams]):
+    dims = []
+    for m in models:
+        F = int(m.features_dc.shape[1])
+        if F > MAX_FOURIER:
+            raise ValueError("fourier_dim %d > %d" % (F, MAX_FOURIER))
+        dims.append(F)
+    lists = [[m[f] for m in models] for f in range(6)]
+    lists.append([_NO_FLIP if m.flip is None else m.flip for m in models])
+    return lists, tuple(dims)
 
 
 def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
     if len(models) != len(poses):
         raise ValueError("one pose entry (None for a static model) per model")
-    rows, times, dims = [], [], []
+    lists, dims = _model_lists(models)
+    rows, times = [], []
     tens, slots = [], []   # tensor-valued pose parts and where they go: ONE host copy for all of them
-    for i, (m, p) in enumerate(zip(models, poses)):
-        F = int(m.features_dc.shape[1])
-        if F > MAX_FOURIER:
-            raise ValueError("fourier_dim %d > %d" % (F, MAX_FOURIER))
-        dims.append(F)
+    for i, p in enumerate(poses):
         if p is None:      # a static model has fourier_dim 1: weight cos(0) = 1
-            rows.append([0.0] * 8)
+            rows.append(_ZERO_ROW)
             times.append(0.0)
             continue
-        row = [1.0] + [0.0] * 7
+        row = [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
         for off, v, n in ((1, p.obj_rot, 4), (5, p.obj_trans, 3)):
             if isinstance(v, torch.Tensor):
                 if v.numel() != n:
@@ -124,9 +138,11 @@ def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
                 tens.append(v.detach().reshape(-1).float())
                 slots.append((i, off, n))
             else:
+                if len(v) != n:
+                    raise ValueError("pose component of %d elements, expected %d" % (len(v), n))
                 row[off:off + n] = [float(x) for x in v]
         rows.append(row)
-        times.append(float(p.fourier_time))
+        times.append(p.fourier_time)
     if tens:
         # tracked poses usually live on the GPU: a .cpu() per actor would be a device sync per actor and
         # frame; stack them first (one small kernel) and copy once
@@ -138,11 +154,8 @@ def _pack(models: Sequence[ModelParams], poses: Sequence[Optional[ActorPose]]):
         for i, off, n in slots:
             rows[i][off:off + n] = flat_vals[k:k + n]
             k += n
-    pose_t = torch.tensor(rows, dtype=torch.float32).reshape(len(models), 8)
+    pose_t = torch.from_numpy(np.asarray(rows, dtype=np.float32))     # [n, 8] (float64 -> float32 like torch.tensor)
     idft_t = _idft_rows(times, dims)
-    lists = [[getattr(m, f) for m in models] for f in ModelParams._fields[:6]]
-    none = torch.empty(0, dtype=torch.bool)
-    lists.append([none if m.flip is None else m.flip for m in models])
     return lists, pose_t, idft_t
 
 

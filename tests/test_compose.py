@@ -29,6 +29,26 @@ def test_idft_weights_match_reference_fixture():
             np.testing.assert_array_equal(ct.idft(float(t), d)[0].numpy(), ref)
 
 
+def test_batched_idft_rows_match_reference_fixture():
+    """The per-frame form (_idft_rows: all models' weights from one column of times) against the same fixture: the same
+    bits as one reference call per model, zero beyond a model's own dimension."""
+    from gaussianrpg_amd.composed import MAX_FOURIER, _idft_rows
+    z = np.load(os.path.join(GOLDEN, "ref_idft.npz"))
+    dims = [1, 2, 3, 5, 8]
+    for i, t in enumerate(z["times"]):
+        for order in (dims, dims[::-1], [5, 5, 1, 8]):
+            rows = _idft_rows([float(t)] * len(order), order).numpy()
+            assert rows.shape == (len(order), MAX_FOURIER) and rows.dtype == np.float32
+            for r, d in zip(rows, order):
+                np.testing.assert_array_equal(r[:d].view(np.uint32), z["dim%d" % d][i].astype(np.float32).view(np.uint32))
+                assert not r[d:].view(np.uint32).any()      # +0.0, not -0.0
+    # different times per row
+    ts = [float(x) for x in z["times"][:5]]
+    rows = _idft_rows(ts, dims).numpy()
+    for k, (t_i, d) in enumerate(zip(range(5), dims)):
+        np.testing.assert_array_equal(rows[k][:d], z["dim%d" % d][t_i])
+
+
 def _to(m, dev, grad=False):
     """ModelParams on a device (the optional flip mask may be None); grad: fresh leaves."""
     f = lambda t: t.to(dev).clone().requires_grad_(True) if grad else t.to(dev)   # noqa: E731
