@@ -240,6 +240,30 @@ def test_host_frames_of_many_shapes_and_streams(dev):
         _same("frame %d of the three-stream loop" % f, hosts[f], refs[f])
 
 
+def test_delivery_ring_filled_by_the_epilogue(dev):
+    """trajectory.FrameDelivery.begin() / commit(): the render stores each frame into the ring's pinned slot itself
+    (no pack launch, no copy); the consumer, one frame behind, gets the frames submit() would have delivered."""
+    from gaussianrpg_amd import trajectory as tj
+    W, H = 320, 192
+    sc = hz.toy_scene(5000, seed=2, sh_degree=1).to(dev)
+    kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    cams = [hz.trajectory_camera(f, W=W, H=H, device=dev) for f in range(5)]
+    rasts = [_rast(c, 1, dev, bg=[0.2, 0.1, 0.0]) for c in cams]
+    fd_ref, fd = tj.FrameDelivery(H, W, depth=2), tj.FrameDelivery(H, W, depth=2)
+    with torch.no_grad():
+        for k, r in enumerate(rasts):
+            color = r(means3D=sc.means3D, means2D=None, opacities=sc.opacity, **kw)[0]
+            t_ref = fd_ref.submit(color)                       # pack launch + copy
+            r.forward_frame(sc.means3D, sc.opacity, out=fd.begin(), **kw)
+            t = fd.commit()
+            assert t == t_ref == k
+            if k >= 1:
+                np.testing.assert_array_equal(fd.get(k - 1), fd_ref.get(k - 1))
+        np.testing.assert_array_equal(fd.get(4), fd_ref.get(4))
+    with pytest.raises(ValueError):
+        fd.get(1)          # fell out of the ring
+
+
 def test_frame_without_gaussians_and_argument_errors(dev):
     from gaussianrpg_amd.sky import ray_matrix
     cam = hz.trajectory_camera(0, W=70, H=50, device=dev)
