@@ -626,16 +626,16 @@ int forward_impl(grpg_alloc_fn geometry_alloc, void* geometry_user, grpg_alloc_f
   uint32_t* work = (uint32_t*)(img + IL.work);
 
   // A frame whose bytes go to pinned host memory is DRAINED (render_fwd.hip FrameEpi) when its width allows whole
-  // 64-byte lines per unit: staging bytes in the n_contrib plane (an evaluation frame tracks no n_contrib: 4 bytes
+  // 16-byte pieces per tile row (W % 16 == 0; whole 64-byte lines per unit when W % 64 == 0): staging bytes in the n_contrib plane (an evaluation frame tracks no n_contrib: 4 bytes
   // per pixel lie idle), the units' arrival counters behind the layered frame's tile flags in the checkpoint-count
   // area (a training forward's; T / 4 of its 4 T words).  GRPG_DRAIN_WGS (experiments): workgroups that carry the
   // units, 0 = the blending waves store straight into host memory.
   FrameEpilogue epi_drained;
   uint32_t drain_cnt_words = 0u;
-  if (epi && epi->rgb8 && epi->rgb8_host && (width & 63) == 0 && P > 0) {
+  if (epi && epi->rgb8 && epi->rgb8_host && (width & 15) == 0 && P > 0) {
     static const int drain_cfg = [] { const char* v = getenv("GRPG_DRAIN_WGS"); return v ? atoi(v) : FRAME_DRAIN_WGS; }();
     // every unit needs a slot (64 per drain wave, RW_WAVES waves per workgroup), the counters 3 T words at most
-    const uint32_t NU = (uint32_t)(width / 64) * (uint32_t)cam.gy;
+    const uint32_t NU = (uint32_t)((width + 63) / 64) * (uint32_t)cam.gy;
     uint32_t wgs = (uint32_t)drain_cfg > (NU + 255u) / 256u ? (uint32_t)drain_cfg : (NU + 255u) / 256u;
     if (wgs > 3u * T / 256u) wgs = 3u * T / 256u;
     if (drain_cfg > 0 && wgs > 0u && wgs * 256u >= NU) {

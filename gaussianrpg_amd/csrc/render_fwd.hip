@@ -458,10 +458,11 @@ struct FrameEpi {
   int host;                 // how rgb8 is stored: 0 plain; 1 rgb8 IS device-mapped pinned host memory
                             // (grpg_frame_epilogue.out_rgb8_on_host), system-scope write-through; 2 rgb8 is the
                             // device STAGING frame of a drained frame (below), agent-scope write-through
-  // Drained frame (host destination, W % 64 == 0): the blending waves never touch the link.  They store their bytes
+  // Drained frame (host destination, W % 16 == 0): the blending waves never touch the link.  They store their bytes
   // into a device staging frame and count their pixels into the counter of their UNIT (64 x 16 pixels = four tiles
-  // side by side = 16 rows x three whole 64-byte lines); drain_wgs workgroups at the front of the grid watch the
-  // counters and carry every complete unit to host8 in whole lines while the launch is still blending.
+  // side by side = 16 rows x three whole 64-byte lines when W % 64 == 0; otherwise rows of 16-byte pieces, and the last
+  // unit of a row is narrower); drain_wgs workgroups at the front of the grid watch the counters and carry every
+  // complete unit to host8 while the launch is still blending.
   unsigned char* host8;     // the pinned host frame (drained frame), or NULL
   uint32_t* unit_cnt;       // [drain waves][64] pixels arrived per unit (zero at launch, zero again at its end)
   int drain_wgs, units_x;
@@ -550,8 +551,9 @@ __device__ __forceinline__ void drain_units(const FrameEpi& e, const int W, cons
   // wave's burst)
   const uint32_t u = (uint32_t)lane * nd + wid;
   const bool valid = u < NU;
-  const uint32_t uy = valid ? u / (uint32_t)e.units_x : 0u;
-  const uint32_t target = 64u * (uint32_t)min(16, H - 16 * (int)uy);
+  const uint32_t uy = valid ? u / (uint32_t)e.units_x : 0u, ux = u - uy * (uint32_t)e.units_x;
+  // (the last unit of a row is narrower when W is no multiple of 64: W % 16 == 0 keeps its rows whole 16-byte pieces)
+  const uint32_t target = (uint32_t)min(64, W - 64 * (int)ux) * (uint32_t)min(16, H - 16 * (int)uy);
   uint32_t* const my_cnt = e.unit_cnt + (size_t)wid * 64u + (uint32_t)lane;
   uint64_t pending = __ballot(valid);
   const uint64_t t0 = wall_clock64();
@@ -579,12 +581,15 @@ __device__ __forceinline__ void drain_units(const FrameEpi& e, const int W, cons
       for (int k = 0; k < 2; k++) {
         const uint32_t uu = (uint32_t)(k == 0 ? b0 : b1) * nd + wid;
         const uint32_t ry = uu / (uint32_t)e.units_x, rx = uu - ry * (uint32_t)e.units_x;
-        chunks[k] = (k == 1 && !two) ? 0 : 12 * min(16, H - 16 * (int)ry);   // 16-byte pieces of the unit
+        const int cpr = 3 * min(64, W - 64 * (int)rx) / 16;                  // 16-byte pieces per row: 12, fewer in a last unit
+        const int nch = cpr * min(16, H - 16 * (int)ry);                    // ... of the unit
+        chunks[k] = (k == 1 && !two) ? 0 : nch;
         const size_t org = (size_t)16 * ry * pitch + (size_t)192 * rx;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          const int cidx = min(i * 64 + lane, 12 * min(16, H - 16 * (int)ry) - 1);   // (beyond the unit: a harmless second read)
-          off[k][i] = org + (size_t)(cidx / 12) * pitch + (size_t)16 * (cidx % 12);
+          const int cidx = min(i * 64 + lane, nch - 1);   // (beyond the unit: a harmless second read)
+          const int crow = cidx / cpr;
+          off[k][i] = org + (size_t)crow * pitch + (size_t)16 * (cidx - crow * cpr);
           const uint64_t* src = (const uint64_t*)(e.rgb8 + off[k][i]);
           v[k][i][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           v[k][i][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1889,9 +1894,9 @@ static FrameEpi make_frame_epi(const FrameEpilogue* e, const int W = 0, const bo
   d.clamp = e->clamp; d.rgb8 = e->rgb8; d.bias = e->truncate ? 0.0f : 0.5f; d.planes = e->planes;
   d.host = e->rgb8_host;
   if (may_drain && e->rgb8_host && e->drain_stage != nullptr && e->drain_cnt != nullptr && e->drain_wgs > 0 &&
-      (W & 63) == 0 && ((uintptr_t)e->rgb8 & 15) == 0 && ((uintptr_t)e->drain_stage & 15) == 0) {
+      (W & 15) == 0 && ((uintptr_t)e->rgb8 & 15) == 0 && ((uintptr_t)e->drain_stage & 15) == 0) {
     d.host8 = e->rgb8; d.rgb8 = e->drain_stage; d.host = 2;
-    d.unit_cnt = e->drain_cnt; d.drain_wgs = e->drain_wgs; d.units_x = W / 64;
+    d.unit_cnt = e->drain_cnt; d.drain_wgs = e->drain_wgs; d.units_x = (W + 63) / 64;
   }
   return d;
 }

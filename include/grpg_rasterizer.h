@@ -191,7 +191,10 @@ GRPG_API int grpg_forward_layers(grpg_alloc_fn geometry_alloc, void* geometry_us
  *                          frame on the host (simulator.py:313-328): with this flag the epilogue's stores are
  *                          write-through (system scope), so the bytes cross the link WHILE the render's other tiles
  *                          are still being blended, and the 7.4 MB device->host copy behind the launch (0.13 ms at
- *                          1920x1280, a third of the render) disappears.  The bytes are complete once the stream has
+ *                          1920x1280, a third of the render) disappears.  (Widths that are a multiple of 16: the
+ *                          blending waves stage their bytes on the device and reserved workgroups carry finished
+ *                          64 x 16-pixel units across the link, in whole 64-byte lines when the width is a multiple
+ *                          of 64; other widths: the blending waves store into host memory themselves.)  The bytes are complete once the stream has
  *                          reached the end of the call (stream / event synchronisation, as for a copy).  Same bytes
  *                          as with a device destination.  (A device pointer with the flag set still works: its lines
  *                          merely bypass the L2's write-back.)

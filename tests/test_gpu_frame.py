@@ -152,13 +152,14 @@ def test_composed_frame_is_the_simulators_frame(dev):
     assert set(res) == {"num_rendered", "radii", "rgb8"}      # nothing else was even allocated
 
 
-@pytest.mark.parametrize("W,H", [(200, 136), (203, 121), (256, 100), (1920, 1280)])
+@pytest.mark.parametrize("W,H", [(200, 136), (203, 121), (256, 100), (400, 300), (1920, 1280)])
 def test_frame_bytes_straight_into_pinned_host_memory(dev, W, H):
     """ABI 7 (grpg_frame_epilogue.out_rgb8_on_host): ``out`` = a pinned HOST tensor -- the epilogue stores the
     simulator's frame (simulator.py:313-328 consumes it on the host) through the link while the render runs; no
-    copy behind the launch.  Same bytes as the device destination: W % 64 == 0 is a DRAINED frame (staging bytes,
-    per-unit arrival counters, reserved workgroups that carry whole 64-byte lines to the host; 256x100: a last unit
-    row of 4 pixel rows), W % 4 == 0 the packed dword stores straight into host memory, any other width byte stores;
+    copy behind the launch.  Same bytes as the device destination: W % 16 == 0 is a DRAINED frame (staging bytes,
+    per-unit arrival counters, reserved workgroups that carry finished units to the host -- whole 64-byte lines when
+    W % 64 == 0; 256x100: a last unit row of 4 pixel rows; 400x300: a last unit column of one tile), W % 4 == 0 the
+    packed dword stores straight into host memory, any other width byte stores;
     plain and layered frames, twice into the same buffers (the counters clean up behind themselves), and a frame
     without Gaussians."""
     from gaussianrpg_amd.sky import ray_matrix
@@ -205,7 +206,8 @@ def test_host_frames_of_many_shapes_and_streams(dev):
     streams into three pinned buffers: always the device destination's bytes."""
     from gaussianrpg_amd.sky import ray_matrix
     rng = np.random.default_rng(5)
-    shapes = [(64, 20), (128, 33), (192, 160), (320, 47), (448, 100), (512, 129), (640, 360), (100, 60), (130, 50)]
+    shapes = [(64, 20), (128, 33), (192, 160), (320, 47), (448, 100), (512, 129), (640, 360), (100, 60), (130, 50),
+              (208, 100), (336, 200), (400, 240), (1200, 80), (1584, 100)]
     sc = hz.toy_scene(4000, seed=4, sh_degree=1).to(dev)
     kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
     sky = _sky(dev, res=16, seed=7)
