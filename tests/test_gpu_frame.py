@@ -218,10 +218,13 @@ def test_host_frames_of_many_shapes_and_streams(dev):
         e = dict(sky_cube=sky.sky_cube_map, ray_matrix=ray_matrix(K.to(dev), w2c.to(dev)))
         host = torch.full((H, W, 3), 3, dtype=torch.uint8).pin_memory()
         with torch.no_grad():
-            ref = rast.forward_frame(sc.means3D, sc.opacity, **kw, **e)["rgb8"]
-            rast.forward_frame(sc.means3D, sc.opacity, out=host, **kw, **e)
+            ref = rast.forward_frame(sc.means3D, sc.opacity, planes=True, **kw, **e)
+            got = rast.forward_frame(sc.means3D, sc.opacity, out=host, planes=(W % 3 == 0), **kw, **e)
         torch.cuda.synchronize()
-        _same("host frame %dx%d" % (W, H), host, ref)
+        _same("host frame %dx%d" % (W, H), host, ref["rgb8"])
+        if W % 3 == 0:      # the float planes ride along on the device
+            for k in ("rgb", "depth", "alpha"):
+                _same("%s beside a host frame %dx%d" % (k, W, H), got[k], ref[k])
     # three streams, three frames in flight (each call carves its own image blob: staging and counters are per frame)
     W, H = 640, 360
     cams = [hz.trajectory_camera(f, W=W, H=H, device=dev) for f in range(6)]
