@@ -246,6 +246,39 @@ def render_sharded(render_frame: Optional[Callable[[int], torch.Tensor]], num_fr
     return out
 
 
+def render_to_host(frame_call: Callable[[int, torch.Tensor], None], num_frames: int, height: int, width: int,
+                   consume: Callable[[int, "object"], None], *, num_streams: int = 3, truncate: bool = True,
+                   streams=None, ring: Optional["FrameDelivery"] = None) -> int:
+    """A trajectory's frames as rgb8 [H,W,3] images ON THE HOST (render.py's video / image writers, a recorder, a
+    ROS publisher: street_gaussian_visualizer.py:205-216, simulator.py:313-328), without a device frame, a pack
+    launch or a copy: ``frame_call(i, out)`` renders frame i with a frame epilogue whose destination is the pinned
+    host tensor ``out`` (``GaussianRasterizer.forward_frame(..., out=out)`` /
+    ``ComposedRasterizer.forward_frame(..., out=out)``; C ABI 7), frames alternate over ``num_streams`` HIP streams,
+    and ``consume(i, image)`` gets frame i as a numpy view ``num_streams`` frames behind the producer (valid until
+    ``num_streams`` more frames have been consumed).  ``ring``: a FrameDelivery of at least 2 x streams slots to
+    reuse (pinning host memory costs milliseconds).  Returns the number of frames delivered."""
+    ns = max(1, int(num_streams))
+    streams = list(streams) if streams else [torch.cuda.Stream() for _ in range(ns)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    fd = ring if ring is not None else FrameDelivery(height, width, depth=2 * len(streams), truncate=truncate)
+    if len(fd.host) < 2 * len(streams) or fd.shape != (int(height), int(width), 3):
+        raise ValueError("the delivery ring needs >= 2 slots per stream of shape [H,W,3]")
+    tickets = []
+    with torch.no_grad():
+        for i in range(num_frames):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                frame_call(i, fd.begin())
+                tickets.append(fd.commit())
+            if i >= len(streams):
+                consume(i - len(streams), fd.get(tickets[i - len(streams)]))
+        for i in range(max(0, num_frames - len(streams)), num_frames):
+            consume(i, fd.get(tickets[i]))
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    return num_frames
+
+
 class DeferredFrames:
     """Frame loop without the per-frame host wait (GaussianRasterizer.forward_deferred).
 

@@ -269,6 +269,24 @@ def test_delivery_ring_filled_by_the_epilogue(dev):
         fd.get(1)          # fell out of the ring
 
 
+def test_render_to_host_delivers_every_frame(dev):
+    """trajectory.render_to_host: a tape's frames land on the host as rgb8 images, in order, equal to the device
+    frames of the same calls."""
+    from gaussianrpg_amd import trajectory as tj
+    W, H, N = 256, 144, 8
+    sc = hz.toy_scene(4000, seed=6, sh_degree=1).to(dev)
+    kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    rasts = [_rast(hz.trajectory_camera(f, W=W, H=H, device=dev), 1, dev) for f in range(N)]
+    with torch.no_grad():
+        refs = [r.forward_frame(sc.means3D, sc.opacity, **kw)["rgb8"].cpu().numpy() for r in rasts]
+    got = {}
+    n = tj.render_to_host(lambda i, out: rasts[i].forward_frame(sc.means3D, sc.opacity, out=out, **kw), N, H, W,
+                          lambda i, img: got.__setitem__(i, img.copy()))
+    assert n == N and sorted(got) == list(range(N))
+    for i in range(N):
+        np.testing.assert_array_equal(got[i], refs[i])
+
+
 def test_frame_without_gaussians_and_argument_errors(dev):
     from gaussianrpg_amd.sky import ray_matrix
     cam = hz.trajectory_camera(0, W=70, H=50, device=dev)
