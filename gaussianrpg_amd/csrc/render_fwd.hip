@@ -537,7 +537,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (the blending waves sit on other XCDs: agent scope) and written through to the host in 16-byte pieces -- four
 // neighbouring lanes make a line, so the link carries 64-byte writes (tools/ubench/host_store.hip: 0.145 ms of link
 // time per 1920x1280 frame, against 0.21 for the tiles' own 48-byte row segments).  A unit's counter goes back to
-// zero behind its copy: a frame that is rendered twice (capacity overflow) starts clean.  The wait is bounded like
+// zero when the unit is taken (nobody arrives at a complete unit): a frame that is rendered twice (capacity overflow)
+// starts clean.  The wait is bounded like
 // the wave pairs' (pc_fail): a lost arrival is reported, not waited for.
 __device__ __forceinline__ void drain_units(const FrameEpi& e, const int W, const int H, const uint32_t wid,
                                             const uint32_t nd, const int lane, const PCErr err) {
