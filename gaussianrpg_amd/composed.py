@@ -251,7 +251,9 @@ class ComposedRasterizer(nn.Module):
         236-237) and the simulator's uint8 [H,W,3] conversion (simulator.py:313-314) -- the last three inside the
         render's epilogue.  ``layers=True`` also returns render_all's two layer renders (forward_layers); the
         simulator reads ``result['rgb']`` only and does not need them.  Returns a dict: ``rgb8`` (uint8 [H,W,3] on the
-        device; ``out``: a preallocated one), with ``planes=True`` also ``rgb`` (the FINAL colour) / ``depth`` /
+        device; ``out``: a preallocated device tensor, or a PINNED HOST tensor -- the bytes then land in host memory
+        while the render runs, no copy behind the launch: what the simulator wants; synchronise with the stream before
+        reading), with ``planes=True`` also ``rgb`` (the FINAL colour) / ``depth`` /
         ``alpha``, with ``layers=True`` the four layer planes; ``radii``, ``num_rendered``."""
         rs = self.raster_settings
         lists, pose_t, idft_t = _pack(models, poses)
