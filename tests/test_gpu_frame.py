@@ -287,6 +287,21 @@ def test_render_to_host_delivers_every_frame(dev):
         np.testing.assert_array_equal(got[i], refs[i])
 
 
+@pytest.mark.parametrize("W,H", [(320, 200), (203, 121)])
+def test_harness_simulator_frame_both_ways(dev, W, H):
+    """harness.simulator_frame: the reference's pattern (op, clamp, sky composite, float planes to the host, numpy
+    conversion: simulator.py:309-328) and the one-call form with a pinned host destination give the same image."""
+    sc = hz.toy_scene(5000, seed=9, sh_degree=1).to(dev)
+    cam = hz.trajectory_camera(3, W=W, H=H, device=dev)
+    K, w2c = _K_w2c(cam)
+    sky = _sky(dev, res=32, seed=4)
+    ref = hz.simulator_frame(sc, cam, sky, K, w2c, fused=False)
+    got = hz.simulator_frame(sc, cam, sky, K, w2c)
+    assert got.shape == (H, W, 3) and got.dtype == np.uint8
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(hz.simulator_frame(sc, cam), hz.simulator_frame(sc, cam, fused=False))   # no sky
+
+
 def test_frame_without_gaussians_and_argument_errors(dev):
     from gaussianrpg_amd.sky import ray_matrix
     cam = hz.trajectory_camera(0, W=70, H=50, device=dev)
