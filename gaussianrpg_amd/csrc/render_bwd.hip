@@ -175,16 +175,21 @@ __device__ __forceinline__ void backward_rect(
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-  // Per-pixel state.  The reference carries (last_alpha, last_color) and forms
+  // Per-pixel state.  The reference carries (last_alpha, last_color) per channel and forms
   //   accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec        (backward.cu:556-561)
   // at the NEXT contributor; the same value is obtained by blending the current contributor into
-  // the accumulator right after it has been used, acc += alpha (c - acc), which needs no copy of
-  // the previous splat's colour per pixel and reuses the difference (c - acc) that dL/dalpha needs
-  // anyway.  Plain (unpacked) fp32 throughout: on gfx950 a v_pk_fma_f32 occupies the VALU 1.8x as
-  // long as a v_fma_f32 (tools/ubench/valu_rate.hip), so packing buys nothing and costs moves.
-  float T[PX], nTfBg[PX], dLa[PX], acc_a[PX];
-  float dLc[PX][4], acc[PX][4];          // channels: r, g, b, depth
-  float dLs[PX][SM], acc_s[PX][SM];
+  // the accumulator right after it has been used, acc += alpha (c - acc).  The accumulators are
+  // only ever used inside ONE sum, dL/dalpha = sum_ch (c_ch - acc_ch) dL_ch (colour, depth,
+  // accumulated alpha with c = 1, semantics: backward.cu:565,584,594,600), and both that sum and the
+  // update are linear in them -- so the pixel carries the single scalar
+  //   A = sum_ch acc_ch dL_ch,        d = (sum_ch c_ch dL_ch) - A,        A += alpha d
+  // instead of 5 + S accumulators (round 6: 9 of the 56 vector instructions per (pixel, splat) and 8
+  // registers gone; the difference is formed once instead of per channel, which moves the result by
+  // rounding only).  Plain (unpacked) fp32 throughout: on gfx950 a v_pk_fma_f32 occupies the VALU
+  // 1.8x as long as a v_fma_f32 (tools/ubench/valu_rate.hip), so packing buys nothing and costs moves.
+  float T[PX], nTfBg[PX], dLa[PX], A[PX];
+  float dLc[PX][4];                      // channels: r, g, b, depth
+  float dLs[PX][SM];
   float pyf[PX];
   uint32_t lastc[PX];
   uint32_t maxlast = 0;
@@ -204,14 +209,10 @@ __device__ __forceinline__ void backward_rect(
     // background term of backward.cu:611-614: (-T_final / (1 - alpha)) * (bg . dL_dpixel)
     nTfBg[k] = -T_final * (bg0 * dLc[k][0] + bg1 * dLc[k][1] + bg2 * dLc[k][2]);
     pyf[k] = (float)py;
+    A[k] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; c++) acc[k][c] = 0.f;
-    acc_a[k] = 0.f;
-#pragma unroll
-    for (int c = 0; c < SM; c++) {
+    for (int c = 0; c < SM; c++)
       dLs[k][c] = (SMAX > 0 && c < S && inside) ? dL_dpix_semantic[(size_t)c * HW + pix] : 0.f;
-      acc_s[k][c] = 0.f;
-    }
     maxlast = max(maxlast, lastc[k]);
   }
   if (SEG && ck_end != nullptr) {
@@ -224,9 +225,11 @@ __device__ __forceinline__ void backward_rect(
     const float inv = 1.0f / fmaxf(Tk, 1e-30f);
     const float Tf = T[0];
     T[0] = Tk;
+    float a0 = (1.0f - Tf * inv) * dLa[0];
 #pragma unroll
-    for (int c = 0; c < 4; c++) acc[0][c] = (ck_final[64 * (c + 1) + lane] - ck_end[64 * (c + 1) + lane]) * inv;
-    acc_a[0] = 1.0f - Tf * inv;
+    for (int c = 0; c < 4; c++)
+      a0 = fmaf((ck_final[64 * (c + 1) + lane] - ck_end[64 * (c + 1) + lane]) * inv, dLc[0][c], a0);
+    A[0] = a0;
   }
   maxlast = wave_max_u32(maxlast);   // nothing behind the tile's deepest contributor matters
   const float nddelx = -(float)(0.5 * W), nddely = -(float)(0.5 * H);   // -ddelx_dx, -ddely_dy (backward.cu:501-502)
@@ -355,10 +358,12 @@ __device__ __forceinline__ void backward_rect(
       if (keep) {
         const int slot = (int)__popcll(mask & lt);
         const SplatQ sq = splat_q(lb.x, lb.y, lb.z);   // once per survivor, not once per (wave, survivor)
+        // the conic enters the trip loop only through dL_dmean2D = -ddel (conic t): its four products
+        // with -ddelx_dx / -ddely_dy are formed here, once per survivor, not per (pixel, survivor)
         my[slot * BREC + 0] = la;
-        my[slot * BREC + 1] = lb;
+        my[slot * BREC + 1] = make_float4(nddelx * lb.x, nddelx * lb.y, nddely * lb.z, lb.w);
         my[slot * BREC + 2] = make_float4(lc.x, lc.y, __uint_as_float(lpos), __uint_as_float(lid));
-        my[slot * BREC + 3] = make_float4(sq.A, sq.B, sq.C, 0.f);
+        my[slot * BREC + 3] = make_float4(sq.A, sq.B, sq.C, nddely * lb.y);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -367,9 +372,9 @@ __device__ __forceinline__ void backward_rect(
     const int cnt_u = __builtin_amdgcn_readfirstlane(cnt);   // loop control on the scalar unit
     for (int j = 0; j < cnt_u; j++) {
       const float4 a = my[j * BREC + 0];   // px, py, depth, opacity
-      const float4 b = my[j * BREC + 1];   // conic.x, conic.y, conic.z, R
+      const float4 b = my[j * BREC + 1];   // -ddelx conic.x, -ddelx conic.y, -ddely conic.z, R
       const float4 c = my[j * BREC + 2];   // G, B, list position, Gaussian id
-      const float4 q = my[j * BREC + 3];   // pre-scaled conic A, B, C (blend_math.h)
+      const float4 q = my[j * BREC + 3];   // pre-scaled conic A, B, C (blend_math.h), -ddely conic.y
       const uint32_t pos = __float_as_uint(c.z);   // 0-based == the reference's `contributor`
       const uint32_t gid = __float_as_uint(c.w);
       const float dx = a.x - pxf;
@@ -412,36 +417,33 @@ __device__ __forceinline__ void backward_rect(
         const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
         T[k] = T[k] * inv_1ma;
         const float dch = alpha * T[k];
-        // dL/dalpha through what lies behind this splat: sum_c (c - acc_c) dL_c  (backward.cu:556-602)
-        float dL_dopa = 0.f;
+        // dL/dalpha through what lies behind this splat: sum_c (c - acc_c) dL_c = (sum_c c dL_c) - A
+        // (backward.cu:556-602; the accumulated alpha is the channel with c = 1)
+        float cD = dLa[k];
 #pragma unroll
         for (int ch = 0; ch < 4; ch++) {
-          const float d = col[ch] - acc[k][ch];
-          dL_dopa = fmaf(d, dLc[k][ch], dL_dopa);
+          cD = fmaf(col[ch], dLc[k][ch], cD);
           g_c[ch] = fmaf(dch, dLc[k][ch], g_c[ch]);
-          acc[k][ch] = fmaf(alpha, d, acc[k][ch]);      // alpha c + (1 - alpha) acc
         }
         if (SMAX > 0) {
 #pragma unroll
           for (int cc = 0; cc < SM; cc++) {
             if (cc < S) {
-              const float d = semantics[(size_t)gid * S + cc] - acc_s[k][cc];
-              dL_dopa = fmaf(d, dLs[k][cc], dL_dopa);
+              cD = fmaf(semantics[(size_t)gid * S + cc], dLs[k][cc], cD);
               g_s[cc] = fmaf(dch, dLs[k][cc], g_s[cc]);
-              acc_s[k][cc] = fmaf(alpha, d, acc_s[k][cc]);
             }
           }
         }
-        const float da = 1.f - acc_a[k];
-        dL_dopa = fmaf(da, dLa[k], dL_dopa);
-        acc_a[k] = fmaf(alpha, da, acc_a[k]);           // alpha + (1 - alpha) acc_a
-        dL_dopa = fmaf(inv_1ma, nTfBg[k], dL_dopa * T[k]);
-        g_op = fmaf(G, dL_dopa, g_op);
-        const float dL_dG = a.w * dL_dopa;
-        // t = dL_dG G (dx, dy):  dL_dmean2D = -ddel (conic t),  dL_dconic = -1/2 t (dx, dy)^T
-        const float tdx = dL_dG * (G * dx), tdy = dL_dG * (G * dy);
-        const float mx = nddelx * fmaf(b.y, tdy, b.x * tdx);
-        const float my_ = nddely * fmaf(b.y, tdx, b.z * tdy);
+        const float d = cD - A[k];
+        A[k] = fmaf(alpha, d, A[k]);                    // every accumulator: alpha c + (1 - alpha) acc
+        const float dL_dopa = fmaf(inv_1ma, nTfBg[k], d * T[k]);
+        const float gd = G * dL_dopa;
+        g_op += gd;
+        // t = dL_dG G (dx, dy), dL_dG = opacity dL_dopa:  dL_dmean2D = -ddel (conic t),  dL_dconic = -1/2 t (dx, dy)^T
+        const float w = a.w * gd;
+        const float tdx = w * dx, tdy = w * dy;
+        const float mx = fmaf(b.y, tdy, b.x * tdx);
+        const float my_ = fmaf(q.w, tdx, b.z * tdy);
         g_mx += mx;
         g_my += my_;
         g_mabs += fabsf(mx);
