@@ -160,9 +160,16 @@ __device__ __forceinline__ void backward_rect(
     const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth,
     const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpix_semantic,
-    float* __restrict__ grad_rec, float* __restrict__ dL_dsemantic, const int ablate,
-    unsigned long long* __restrict__ stats, const uint32_t seg_lo = 0u, const uint32_t seg_hi = 0u,
+    float* __restrict__ grad_rec, float* __restrict__ dL_dsemantic, const int ablate_in,
+    unsigned long long* __restrict__ stats_in, const uint32_t seg_lo = 0u, const uint32_t seg_hi = 0u,
     const float* __restrict__ ck_end = nullptr, const float* __restrict__ ck_final = nullptr) {
+#ifdef GRPG_TRACE   // experiment build: ablation switches and loop counters are live
+  const int ablate = ablate_in;
+  unsigned long long* const stats = stats_in;
+#else               // production: constants, so that the counters and the switches' masks cost nothing in the trip loop
+  constexpr int ablate = 0;
+  constexpr unsigned long long* stats = nullptr;
+#endif
   constexpr int SM = SMAX > 0 ? SMAX : 1;
   const int px = x0 + (lane & 15);
   const int py0 = y0 + (lane >> 4) * PX;
@@ -187,7 +194,11 @@ __device__ __forceinline__ void backward_rect(
   // registers gone; the difference is formed once instead of per channel, which moves the result by
   // rounding only).  Plain (unpacked) fp32 throughout: on gfx950 a v_pk_fma_f32 occupies the VALU
   // 1.8x as long as a v_fma_f32 (tools/ubench/valu_rate.hip), so packing buys nothing and costs moves.
-  float T[PX], nTfBg[PX], dLa[PX], A[PX];
+  // The accumulated-alpha plane needs no state at all: its channel has c = 1, so (1 - acc) is the
+  // transmittance of everything BEHIND the splat, T (1 - acc) = T_final / (1 - alpha) -- the very factor
+  // of the background term (backward.cu:600,611-614), which takes dL_dalpha in with it (nTfBg below).
+  // (Inside A it would be the one badly conditioned channel: acc -> 1 on opaque pixels.)
+  float T[PX], nTfBg[PX], A[PX];
   float dLc[PX][4];                      // channels: r, g, b, depth
   float dLs[PX][SM];
   float pyf[PX];
@@ -205,9 +216,10 @@ __device__ __forceinline__ void backward_rect(
     dLc[k][1] = inside ? dL_dpix[HW + pix] : 0.f;
     dLc[k][2] = inside ? dL_dpix[2 * HW + pix] : 0.f;
     dLc[k][3] = inside ? dL_dpix_depth[pix] : 0.f;
-    dLa[k] = inside ? dL_dalphas[pix] : 0.f;
-    // background term of backward.cu:611-614: (-T_final / (1 - alpha)) * (bg . dL_dpixel)
-    nTfBg[k] = -T_final * (bg0 * dLc[k][0] + bg1 * dLc[k][1] + bg2 * dLc[k][2]);
+    const float dLa = inside ? dL_dalphas[pix] : 0.f;
+    // background term of backward.cu:611-614, (-T_final / (1 - alpha)) * (bg . dL_dpixel), and the
+    // accumulated alpha's T (1 - accum_alpha_rec) dL_dalpha = (T_final / (1 - alpha)) dL_dalpha (:600)
+    nTfBg[k] = T_final * (dLa - (bg0 * dLc[k][0] + bg1 * dLc[k][1] + bg2 * dLc[k][2]));
     pyf[k] = (float)py;
     A[k] = 0.f;
 #pragma unroll
@@ -218,14 +230,13 @@ __device__ __forceinline__ void backward_rect(
   if (SEG && ck_end != nullptr) {
     // Start in the MIDDLE of the list, from the forward's state right behind position seg_hi:
     // T there, and what the back-to-front walk would have accumulated by then -- the composite of
-    // everything behind, as seen from this depth: (C_final - C_k) / T_k per channel, 1 - T_final / T_k
-    // for the accumulated alpha.  A pixel that terminated in front of seg_hi has T_k == T_final and
-    // C_k == C_final (its state stopped changing): zeros, and pos < lastc rejects every entry anyway.
+    // everything behind, as seen from this depth: (C_final - C_k) / T_k per channel, folded into A.
+    // A pixel that terminated in front of seg_hi has T_k == T_final and C_k == C_final (its state
+    // stopped changing): zeros, and pos < lastc rejects every entry anyway.
     const float Tk = ck_end[lane];
     const float inv = 1.0f / fmaxf(Tk, 1e-30f);
-    const float Tf = T[0];
     T[0] = Tk;
-    float a0 = (1.0f - Tf * inv) * dLa[0];
+    float a0 = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; c++)
       a0 = fmaf((ck_final[64 * (c + 1) + lane] - ck_end[64 * (c + 1) + lane]) * inv, dLc[0][c], a0);
@@ -418,8 +429,8 @@ __device__ __forceinline__ void backward_rect(
         T[k] = T[k] * inv_1ma;
         const float dch = alpha * T[k];
         // dL/dalpha through what lies behind this splat: sum_c (c - acc_c) dL_c = (sum_c c dL_c) - A
-        // (backward.cu:556-602; the accumulated alpha is the channel with c = 1)
-        float cD = dLa[k];
+        // (backward.cu:556-596: colour, semantics, depth)
+        float cD = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 4; ch++) {
           cD = fmaf(col[ch], dLc[k][ch], cD);
