@@ -171,6 +171,8 @@ EXPERIMENT_VARIANTS = {
     # round 6 (wrong host bytes): a drained frame whose drain workgroups exit at once -- what the blending waves' share
     # of a host-destination frame costs (write-through staging stores, the arrival's wait and atomic)
     "drainidle": {"render_fwd.hip": ["-DGRPG_DRAIN_IDLE"]},
+    # round 6: light / mid tiles of the backward by ONE wave at 4 pixels per lane (half the reductions there)
+    "bwdpx4": {"render_bwd.hip": ["-DGRPG_BWD_LIGHT_SPLIT=1"]},
     "pad12": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=12288"]},
     "pad26": {"render_fwd.hip": ["-DGRPG_RENDER_LDS_PAD=26624"]},
 }

@@ -650,8 +650,11 @@ void launch_render_backward(hipStream_t s, const uint2* ranges, const uint32_t* 
   // SIMD (one wave at 4 pixels per lane / 160 VGPRs and an uncapped allocation measured within 1 %;
   // 96 VGPRs with 36 spilled: 8 % slower).
   const int grid = ntiles + ntiles / 2 + 1 + (int)items_cap;
+#ifndef GRPG_BWD_LIGHT_SPLIT   // experiment switch: 1 = one wave per light / mid tile at 4 pixels per lane
+#define GRPG_BWD_LIGHT_SPLIT 2
+#endif
   if (S <= 0) {
-    render_backward_kernel<0, 2, 4><<<grid, 256, 0, s>>>(RB_ARGS);
+    render_backward_kernel<0, GRPG_BWD_LIGHT_SPLIT, 4><<<grid, 256, 0, s>>>(RB_ARGS);
   } else if (S <= 4) {
     render_backward_kernel<4, 2><<<grid, 256, 0, s>>>(RB_ARGS);
   } else {
