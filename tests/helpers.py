@@ -136,11 +136,15 @@ def float64_truth_gradients(sc, okw, gc, gd, ga, gs=None, semantics=None, colors
     if semantics is not None:
         loss = loss + (out["semantic"] * gs.double()).sum()
     m2 = out["pre"]["means2D"]          # pixel coordinates; the op reports d/d(NDC): x 0.5 W, 0.5 H
-    m2.retain_grad()
-    loss.backward()
-    g = lambda k: None if lv[k] is None else lv[k].grad.numpy()   # noqa: E731
+    culled_all = not loss.requires_grad   # every Gaussian culled: the images are constants, every gradient is
+    if not culled_all:                    # exactly zero -- the sweep draws such frames
+        m2.retain_grad()
+        loss.backward()
+    zeros = lambda t: np.zeros(tuple(t.shape))                                         # noqa: E731
+    g = lambda k: None if lv[k] is None else (zeros(lv[k]) if lv[k].grad is None else lv[k].grad.numpy())   # noqa: E731
     half = np.array([0.5 * int(okw["image_width"]), 0.5 * int(okw["image_height"])])
-    return dict(dL_dmeans2D_xy=m2.grad.numpy()[:, :2] * half[None, :],
+    m2g = zeros(m2) if culled_all else m2.grad.numpy()
+    return dict(dL_dmeans2D_xy=m2g[:, :2] * half[None, :],
                 dL_dmeans3D=g("means3D"), dL_dopacity=g("opacity"), dL_dsh=g("shs"), dL_dcolors=g("colors"),
                 dL_dscales=g("scales"), dL_drotations=g("rotations"), dL_dcov3D=g("cov"), dL_dsemantic=g("sem"))
 
