@@ -511,8 +511,9 @@ __device__ __forceinline__ void backward_rect(
 // counts[4] (three heavy classes, light), then four lists of T tile ids.
 constexpr int NUM_CLASSES_B = 4;
 
-// MINW: waves per SIMD the register allocator must fit (4 -> 128 VGPRs, 24 B of scratch per lane in
-// the S = 0 / two-pixel-light variant; 1 -> whatever it takes: 138 VGPRs, 3 waves per SIMD)
+// MINW: waves per SIMD the register allocator must fit.  Since the scalar accumulator (round 6) the
+// S = 0 variant takes 96 VGPRs (five waves per SIMD, no scratch; rounds 3-5: 128 with 24 B of scratch per
+// lane), the S <= 4 variant 114 (four waves; before: 139, three), the S <= 32 variant all 256 + 31 AGPRs
 template <int SMAX, int LIGHT_SPLIT, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW)
 render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
